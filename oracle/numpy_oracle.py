@@ -1,0 +1,360 @@
+"""CPU oracle for the image-matching hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a numpy restatement of the reference's algorithm (the reference is
+pure Python on torch; its arithmetic lives in ATen CPU kernels, torch==2.6.0 per
+reference requirements.txt:1-3).  It exists to CHECK the HIP path.  Only
+`tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py`
+may import it; the product package never does.
+
+Parity pin: every function here is checked in tests/test_oracle_golden.py
+against vectors produced by running the reference itself in the build
+container (tests/golden/make_golden.py, torch 2.10.0+rocm7.0 CPU).  The
+reference ships no golden vectors of its own for this path.
+
+Deliberate differences from the reference, all documented in DESIGN.md:
+  * top-k tie order: torch.topk's is implementation-defined; the oracle (and
+    the HIP path) use (score descending, linear index ascending).
+  * BAD box means are evaluated in exact arithmetic (float64 summed-area
+    table) instead of the reference's fp32 conv with weights fp32(1/area);
+    the two agree to <= ~2.1e-4 per response, so a hard bit can differ only
+    where |response - threshold| is below that ("fragile" bits, reported).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------
+# detector: reference pytorch_model/detector/shi_tomasi.py:66-112
+# --------------------------------------------------------------------------
+def shi_tomasi_score(image: np.ndarray, block_size: int = 3, return_sqrt_term: bool = False) -> np.ndarray:
+    """lambda_min of the Sobel structure tensor; (N,1,H,W) f32 -> (N,1,H,W) f32.
+
+    shi_tomasi.py:78-83  replicate pad 1 + unnormalised 3x3 Sobel (cross-correlation)
+    shi_tomasi.py:88-96  products, replicate pad bs//2 OF THE PRODUCTS, box sum
+    shi_tomasi.py:102-110 (a+c)/2 - sqrt(((a-c)/2)^2 + b^2 + 1e-10), clamp >= 0
+    Every step is an individually rounded fp32 op, as in the reference; sqrt is the
+    IEEE correctly-rounded one (what ONNX Runtime, torch-CUDA and torch-CPU's own
+    vectorised path use).  torch-CPU with MKL routes large contiguous tensors through
+    VML vsSqrt, which is 1 ulp off on ~0.7 % of inputs -- the golden check allows that.
+    """
+    if block_size <= 0 or block_size % 2 == 0:
+        raise ValueError(f"block_size must be a positive odd integer, got {block_size}")
+    img = np.asarray(image).astype(F32)
+    n, c, h, w = img.shape
+    assert c == 1
+    p = np.pad(img[:, 0], ((0, 0), (1, 1), (1, 1)), mode="edge")
+    top, mid, bot = p[:, :-2], p[:, 1:-1], p[:, 2:]
+    # column difference per row, then 1-2-1 vertically (same taps as the 3x3 kernel)
+    ix = (top[:, :, 2:] - top[:, :, :-2]) + F32(2) * (mid[:, :, 2:] - mid[:, :, :-2]) + (bot[:, :, 2:] - bot[:, :, :-2])
+    iy = (bot[:, :, :-2] - top[:, :, :-2]) + F32(2) * (bot[:, :, 1:-1] - top[:, :, 1:-1]) + (bot[:, :, 2:] - top[:, :, 2:])
+    r = block_size // 2
+
+    def box(q: np.ndarray) -> np.ndarray:
+        e = np.pad(q, ((0, 0), (r, r), (r, r)), mode="edge")
+        acc = np.zeros_like(q)
+        for dy in range(block_size):
+            for dx in range(block_size):
+                acc = acc + e[:, dy:dy + h, dx:dx + w]
+        return acc
+
+    a, cc, b = box(ix * ix), box(iy * iy), box(ix * iy)
+    half_trace = (a + cc) / F32(2)
+    half_diff = (a - cc) / F32(2)
+    disc = half_diff * half_diff + b * b
+    root = np.sqrt(disc + F32(1e-10))
+    lam = half_trace - root
+    out = np.maximum(lam, F32(0))[:, None].astype(F32)
+    if return_sqrt_term:
+        return out, root[:, None]
+    return out
+
+
+# --------------------------------------------------------------------------
+# NMS + top-k: reference pytorch_model/utils/keypoint_utils.py:12-117
+# --------------------------------------------------------------------------
+def nms_mask(scores: np.ndarray, nms_radius: int) -> np.ndarray:
+    """keypoint_utils.py:26-43: square (2r+1)^2 window max with -inf outside the
+    image; keep where s >= max - 1e-7 (fp32).  (B,H,W) f32 -> (B,H,W) f32 {0,1}."""
+    s = np.asarray(scores, F32)
+    b, h, w = s.shape
+    r = int(nms_radius)
+    e = np.pad(s, ((0, 0), (r, r), (r, r)), mode="constant", constant_values=-np.inf)
+    rowmax = e[:, :, 0:w]
+    for dx in range(1, 2 * r + 1):
+        rowmax = np.maximum(rowmax, e[:, :, dx:dx + w])
+    win = rowmax[:, 0:h]
+    for dy in range(1, 2 * r + 1):
+        win = np.maximum(win, rowmax[:, dy:dy + h])
+    return (s >= (win - F32(1e-7))).astype(F32)
+
+
+def masked_scores(scores, mask, score_threshold=0.0, border_margin=0) -> np.ndarray:
+    """keypoint_utils.py:77-92: s*mask*border, zero where <= threshold."""
+    s = np.asarray(scores, F32)
+    b, h, w = s.shape
+    m = s * np.asarray(mask, F32)
+    if border_margin > 0:
+        g = int(border_margin)
+        yv = ((np.arange(h) >= g) & (np.arange(h) < h - g)).astype(F32)
+        xv = ((np.arange(w) >= g) & (np.arange(w) < w - g)).astype(F32)
+        m = m * (yv[None, :, None] * xv[None, None, :])
+    return np.where(m > F32(score_threshold), m, F32(0)).astype(F32)
+
+
+def select_topk_keypoints(scores, mask, max_keypoints, score_threshold=0.0, border_margin=0):
+    """keypoint_utils.py:94-115 with the tie policy (score desc, index asc).
+
+    Returns keypoints (B,K,2) f32 (y,x; invalid = -1,-1), scores (B,K) f32 and the
+    flat indices (B,K) int64 (-1 for invalid) for test bookkeeping."""
+    m = masked_scores(scores, mask, score_threshold, border_margin)
+    b, h, w = m.shape
+    k = int(max_keypoints)
+    flat = m.reshape(b, -1)
+    if flat.shape[1] < k:
+        raise RuntimeError("selected index k out of range")  # torch.topk's own failure mode
+    kp = np.empty((b, k, 2), F32)
+    sc = np.empty((b, k), F32)
+    ids = np.empty((b, k), np.int64)
+    for i in range(b):
+        order = np.argsort(-flat[i].astype(np.float64), kind="stable")[:k]
+        v = flat[i][order]
+        ok = v > 0
+        kp[i, :, 0] = np.where(ok, order // w, -1)
+        kp[i, :, 1] = np.where(ok, order % w, -1)
+        sc[i] = np.where(ok, v, 0)
+        ids[i] = np.where(ok, order, -1)
+    return kp, sc, ids
+
+
+# --------------------------------------------------------------------------
+# Sparse BAD: reference pytorch_model/descriptor/bad.py:436-576
+# --------------------------------------------------------------------------
+def _nearest_centre(pos: np.ndarray, size: int) -> np.ndarray:
+    """bad.py:469-470,518-535 + ATen grid_sampler(nearest, border, align_corners):
+    g = pos*fp32(2/(size-1+1e-8)) - 1 ; x = ((g+1)/2)*(size-1) ; clip ; nearbyint."""
+    scale = F32(2.0 / (size - 1 + 1e-8))
+    g = pos.astype(F32) * scale - F32(1)
+    x = ((g + F32(1)) / F32(2)) * F32(size - 1)
+    x = np.minimum(np.maximum(x, F32(0)), F32(size - 1))
+    return np.rint(x).astype(np.int64)  # rint = round half to even = std::nearbyint
+
+
+def sparse_bad(
+    image: np.ndarray,
+    keypoints: np.ndarray,
+    box_params: np.ndarray,
+    thresholds: np.ndarray,
+    binarize: bool = False,
+    soft_binarize: bool = True,
+    temperature: float = 10.0,
+    normalize_descriptors: bool = True,
+    return_aux: bool = False,
+):
+    """Non-oriented, nearest-mode SparseBAD.forward (bad.py:458-574).
+
+    image (B,1,H,W) f32, keypoints (B,K,2) f32 (y,x) -> desc (B,K,P) f32.
+    box_params (P,5) = (x1,x2,y1,y2,r) in the 32x32 patch frame (offsets = value-16,
+    bad.py:403-406); box content is taken from the replicate-padded image
+    (bad.py:474-478), the box CENTRE is clamped to the image (padding_mode="border").
+    aux = dict(centered f64 (B,K,P), bits bool (B,K,P), valid bool (B,K)).
+    """
+    img = np.asarray(image, F32)
+    bsz, _, h, w = img.shape
+    kp = np.asarray(keypoints, F32)
+    box = np.asarray(box_params).astype(np.int64)
+    thr = np.asarray(thresholds, F32).astype(np.float64)
+    rmax = int(box[:, 4].max())
+    valid = kp[:, :, 0] >= 0                                           # bad.py:461
+    ky = np.clip(kp[:, :, 0], F32(0), F32(h - 1))                      # bad.py:464-465
+    kx = np.clip(kp[:, :, 1], F32(0), F32(w - 1))
+    ox1, ox2, oy1, oy2 = [(box[:, i] - 16).astype(F32) for i in range(4)]
+    rad = box[:, 4]
+    area = ((2 * rad + 1) ** 2).astype(np.float64)
+
+    centered = np.empty((bsz, kp.shape[1], box.shape[0]), np.float64)
+    for b in range(bsz):
+        e = np.pad(img[b, 0].astype(np.float64), rmax, mode="edge")
+        sat = np.zeros((e.shape[0] + 1, e.shape[1] + 1), np.float64)
+        sat[1:, 1:] = e.cumsum(0).cumsum(1)
+
+        def mean_box(cy, cx):
+            y0 = cy - rad[None, :] + rmax
+            y1 = cy + rad[None, :] + rmax + 1
+            x0 = cx - rad[None, :] + rmax
+            x1 = cx + rad[None, :] + rmax + 1
+            s = sat[y1, x1] - sat[y0, x1] - sat[y1, x0] + sat[y0, x0]
+            return s / area[None, :]
+
+        c1y = _nearest_centre(ky[b][:, None] + oy1[None, :], h)
+        c1x = _nearest_centre(kx[b][:, None] + ox1[None, :], w)
+        c2y = _nearest_centre(ky[b][:, None] + oy2[None, :], h)
+        c2x = _nearest_centre(kx[b][:, None] + ox2[None, :], w)
+        centered[b] = mean_box(c1y, c1x) - mean_box(c2y, c2x) - thr[None, :]
+
+    bits = centered <= 0
+    if not binarize:
+        desc = centered.astype(F32)
+    elif soft_binarize:
+        z = (-(centered.astype(F32)) * F32(temperature)).astype(F32)
+        with np.errstate(over="ignore"):
+            desc = (F32(1) / (F32(1) + np.exp(-z))).astype(F32)
+    else:
+        desc = bits.astype(F32)
+    desc = desc * valid[:, :, None].astype(F32)
+    if normalize_descriptors:                                          # F.normalize, eps 1e-12
+        nrm = np.sqrt((desc * desc).sum(-1, dtype=F32, keepdims=True)).astype(F32)
+        desc = (desc / np.maximum(nrm, F32(1e-12))).astype(F32)
+    if return_aux:
+        return desc, {"centered": centered, "bits": bits & valid[:, :, None], "valid": valid}
+    return desc
+
+
+def pack_bits(bits: np.ndarray) -> np.ndarray:
+    """bool (...,P) -> uint32 (...,P/32); bit p lives in word p//32, position p%32."""
+    b = np.asarray(bits, bool)
+    p = b.shape[-1]
+    assert p % 32 == 0
+    w = b.reshape(*b.shape[:-1], p // 32, 32).astype(np.uint64)
+    return (w << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32)
+
+
+# --------------------------------------------------------------------------
+# cost + Sinkhorn: reference pytorch_model/matching/sinkhorn.py:79-208
+# --------------------------------------------------------------------------
+def cost_matrix(desc1: np.ndarray, desc2: np.ndarray, distance_type: str = "l2", dtype=F32) -> np.ndarray:
+    """sinkhorn.py:95-108."""
+    a = np.asarray(desc1, dtype)
+    b = np.asarray(desc2, dtype)
+    if distance_type == "l2":
+        n1 = (a * a).sum(-1, keepdims=True)
+        n2 = (b * b).sum(-1, keepdims=True)
+        c = n1 + np.swapaxes(n2, -1, -2) - dtype(2) * (a @ np.swapaxes(b, -1, -2))
+        return np.maximum(c, dtype(0))
+    if distance_type == "l1":
+        return np.abs(a[:, :, None, :] - b[:, None, :, :]).sum(-1)
+    raise ValueError(f"distance_type must be 'l1' or 'l2', got {distance_type}")
+
+
+def _lse(x: np.ndarray, axis: int) -> np.ndarray:
+    m = x.max(axis=axis, keepdims=True)
+    m = np.where(np.isfinite(m), m, 0)
+    return (np.log(np.exp(x - m).sum(axis=axis, keepdims=True)) + m).squeeze(axis)
+
+
+def sinkhorn_from_cost(cost, iterations=20, epsilon=1.0, unused_score=1.0, dtype=F32, return_duals=False):
+    """sinkhorn.py:170-206: Z = pad(-cost/eps, dustbin=-unused/eps); log mu / log nu;
+    `iterations` x { u = log mu - LSE_j(Z+v) ; v = log nu - LSE_i(Z+u) } ; P = exp(Z+u+v)."""
+    c = np.asarray(cost, dtype)
+    bsz, n, m = c.shape
+    z = np.full((bsz, n + 1, m + 1), dtype(-unused_score / epsilon), dtype)
+    z[:, :n, :m] = -c / dtype(epsilon)
+    log_mu = np.zeros((bsz, n + 1), dtype)
+    log_nu = np.zeros((bsz, m + 1), dtype)
+    log_mu[:, n] = np.log(dtype(m))
+    log_nu[:, m] = np.log(dtype(n))
+    u = np.zeros_like(log_mu)
+    v = np.zeros_like(log_nu)
+    for _ in range(int(iterations)):
+        u = (log_mu - _lse(z + v[:, None, :], 2)).astype(dtype)
+        v = (log_nu - _lse(z + u[:, :, None], 1)).astype(dtype)
+    p = np.exp(z + u[:, :, None] + v[:, None, :]).astype(dtype)
+    if return_duals:
+        return p, z, u, v
+    return p
+
+
+def sinkhorn_match(desc1, desc2, iterations=20, epsilon=1.0, unused_score=1.0, distance_type="l2", dtype=F32):
+    """SinkhornMatcher.forward (sinkhorn.py:149-208)."""
+    if iterations <= 0:
+        raise ValueError(f"iterations must be positive, got {iterations}")
+    if epsilon <= 0:
+        raise ValueError(f"epsilon must be positive, got {epsilon}")
+    return sinkhorn_from_cost(cost_matrix(desc1, desc2, distance_type, dtype), iterations, epsilon, unused_score, dtype)
+
+
+# --------------------------------------------------------------------------
+# MNN extraction: reference pytorch_model/matching/match_extraction.py:72-181
+# --------------------------------------------------------------------------
+def mnn_extract(p, kpts1, kpts2, max_matches=100, threshold=0.1):
+    """Mutual argmax on P[:N,:M] (first index on ties), score >= threshold, top
+    `max_matches` by score (ties: lower row index first), zero padded.
+    Returns mk1 (B,Mx,2), mk2 (B,Mx,2), scores (B,Mx), valid (B,Mx) bool, and the
+    (i, j) index pairs (B,Mx,2) int64 (-1 where invalid)."""
+    p = np.asarray(p, F32)
+    k1 = np.asarray(kpts1, F32)
+    k2 = np.asarray(kpts2, F32)
+    bsz, n, m = p.shape[0], k1.shape[1], k2.shape[1]
+    mx = int(max_matches)
+    mk1 = np.zeros((bsz, mx, 2), F32)
+    mk2 = np.zeros((bsz, mx, 2), F32)
+    sc = np.zeros((bsz, mx), F32)
+    ij = np.full((bsz, mx, 2), -1, np.int64)
+    for b in range(bsz):
+        core = p[b, :n, :m]
+        jbest = core.argmax(1)
+        ibest = core.argmax(0)
+        best = core.max(1)
+        keep = (ibest[jbest] == np.arange(n)) & (best >= F32(threshold))
+        key = np.where(keep, best, F32(-1))
+        order = np.argsort(-key.astype(np.float64), kind="stable")[: min(mx, n)]
+        cnt = order.shape[0]
+        sc[b, :cnt] = key[order]
+        idx = np.zeros(mx, np.int64)
+        idx[:cnt] = order
+        mk1[b] = k1[b, idx]
+        mk2[b] = k2[b, jbest[idx]]
+        ok = sc[b] > 0
+        ij[b, ok, 0] = idx[ok]
+        ij[b, ok, 1] = jbest[idx][ok]
+    return mk1, mk2, sc, sc > 0, ij
+
+
+# --------------------------------------------------------------------------
+# composite: reference feature_detection/shi_tomasi_sparse_bad_sinkhorn.py:134-182
+# --------------------------------------------------------------------------
+def match_pair(
+    image1,
+    image2,
+    box_params,
+    thresholds,
+    max_keypoints,
+    block_size=3,
+    binarize=False,
+    soft_binarize=True,
+    temperature=10.0,
+    sinkhorn_iterations=20,
+    epsilon=1.0,
+    unused_score=1.0,
+    distance_type="l2",
+    nms_radius=3,
+    score_threshold=0.0,
+    normalize_descriptors=True,
+    border_margin=None,
+    return_aux=False,
+):
+    """scores -> NMS -> top-k -> sparse BAD -> Sinkhorn, for both images.
+    border_margin=None -> max radius of the table (7), as
+    shi_tomasi_sparse_bad_sinkhorn.py:120-124."""
+    if border_margin is None:
+        border_margin = int(np.asarray(box_params)[:, 4].max())
+    out = []
+    aux = {}
+    for tag, im in (("1", image1), ("2", image2)):
+        s = shi_tomasi_score(im, block_size)[:, 0]
+        mk = nms_mask(s, nms_radius)
+        kp, ksc, ids = select_topk_keypoints(s, mk, max_keypoints, score_threshold, border_margin)
+        d, a = sparse_bad(im, kp, box_params, thresholds, binarize, soft_binarize, temperature,
+                          normalize_descriptors, return_aux=True)
+        out.append((kp, d))
+        aux["scores" + tag] = s
+        aux["kscores" + tag] = ksc
+        aux["ids" + tag] = ids
+        aux["bad" + tag] = a
+    p = sinkhorn_match(out[0][1], out[1][1], sinkhorn_iterations, epsilon, unused_score, distance_type)
+    if return_aux:
+        aux["desc1"], aux["desc2"] = out[0][1], out[1][1]
+        return out[0][0], out[1][0], p, aux
+    return out[0][0], out[1][0], p

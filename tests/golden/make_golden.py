@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING THE REFERENCE (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py
+
+Imports the reference from /root/reference (read-only, never copied), feeds it the
+deterministic synthetic inputs of onnx_image_processing_amd/synth.py and stores
+inputs-by-seed + expected outputs as compressed .npz files next to this script.
+The fixtures are DATA (inputs and expected outputs); no reference source travels.
+
+Recorded with every file: torch version, thread count, the exact constructor
+arguments.  Known reference non-determinism that the checkers canonicalise
+(SURVEY.md §8c): torch.topk tie order; BAD bits whose response is within the
+reference's own fp32 box-mean error of the threshold.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(1, "/root/reference")
+
+import torch  # noqa: E402
+
+from onnx_image_processing_amd.synth import synth_batch, synth_image  # noqa: E402
+from pytorch_model.detector.shi_tomasi import ShiTomasiScore  # noqa: E402
+from pytorch_model.utils.keypoint_utils import apply_nms_maxpool, select_topk_keypoints  # noqa: E402
+from pytorch_model.descriptor.bad import SparseBAD  # noqa: E402
+from pytorch_model.matching.sinkhorn import SinkhornMatcher  # noqa: E402
+from pytorch_model.matching.match_extraction import MutualNearestNeighborMatcher  # noqa: E402
+from pytorch_model.feature_detection.shi_tomasi_sparse_bad_sinkhorn import (  # noqa: E402
+    ShiTomasiSparseBADSinkhornMatcher,
+)
+
+torch.manual_seed(0)
+META = dict(torch_version=torch.__version__, threads=torch.get_num_threads())
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def pack(bits: np.ndarray) -> np.ndarray:
+    b = bits.astype(bool)
+    w = b.reshape(*b.shape[:-1], b.shape[-1] // 32, 32).astype(np.uint64)
+    return (w << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32)
+
+
+def save(name, **kw):
+    kw["meta"] = np.array(repr(META))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def run_pipeline(name, seed, h, w, k, cfg, noise=0, store_p=True, mnn=None, blank=None):
+    """Full composite + every intermediate, for one pair."""
+    a, b = synth_batch(seed, 1, h, w, noise=noise)
+    if blank is not None:  # ragged case: flatten most of image 2 so < K corners exist
+        y0, y1, x0, x1 = blank
+        b[:, :, y0:y1, x0:x1] = 77.0
+    model = ShiTomasiSparseBADSinkhornMatcher(max_keypoints=k, **cfg).eval()
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    with torch.no_grad():
+        k1, k2, p = model(ta, tb)
+        out = dict(seed=seed, h=h, w=w, k=k, noise=noise, cfg=np.array(repr(cfg)),
+                   blank=np.array(blank if blank is not None else [-1, -1, -1, -1]),
+                   kpts1=k1.numpy(), kpts2=k2.numpy())
+        raw = SparseBAD(num_pairs=cfg.get("num_pairs", 256), binarize=False, normalize_descriptors=False).eval()
+        for tag, im, kp in (("1", ta, k1), ("2", tb, k2)):
+            s = model.corner_detector(im).squeeze(1)
+            out["score_sha" + tag] = np.array(sha(s.numpy()))
+            mask = apply_nms_maxpool(s, model.nms_radius)
+            out["nms_count" + tag] = int(mask.sum().item())
+            _, ksc = select_topk_keypoints(s, mask, k, model.score_threshold, model.border_margin)
+            out["kscores" + tag] = ksc.numpy()
+            d = model.descriptor(im, kp)
+            c = raw(im, kp)  # centred responses (reference fp32)
+            cn = c.numpy().astype(np.float32)
+            if h * w > 100000:  # full-size: keep only near-threshold responses (|c| < 2e-3)
+                near = np.argwhere(np.abs(cn) < 2e-3)
+                out["near_idx" + tag] = near.astype(np.int32)
+                out["near_val" + tag] = cn[tuple(near.T)]
+                out["min_abs_centered" + tag] = np.float32(np.abs(cn[0][k1.numpy()[0, :, 0] >= 0]).min()) if tag == "1" \
+                    else np.float32(np.abs(cn[0][k2.numpy()[0, :, 0] >= 0]).min())
+            else:
+                out["centered" + tag] = cn
+            if cfg.get("binarize", False) and not cfg.get("soft_binarize", True):
+                nz = d.numpy() != 0
+                out["bits" + tag] = pack(nz)
+                out["desc_sha" + tag] = np.array(sha(d.numpy()))
+            else:
+                out["desc" + tag] = d.numpy()
+        if store_p:
+            out["P"] = p.numpy()
+        out["P_sha"] = np.array(sha(p.numpy()))
+        out["P_rowsum"] = p.sum(-1).numpy()
+        out["P_colsum"] = p.sum(-2).numpy()
+        if mnn is not None:
+            mk1, mk2, sc, valid = MutualNearestNeighborMatcher(**mnn)(p, k1, k2)
+            out.update(mnn_cfg=np.array(repr(mnn)), mk1=mk1.numpy(), mk2=mk2.numpy(),
+                       mscores=sc.numpy(), mvalid=valid.numpy())
+    save(name, **out)
+
+
+EXPORT_CFG = dict(block_size=3, num_pairs=512, binarize=True, soft_binarize=False, sinkhorn_iterations=20,
+                  epsilon=0.05, unused_score=1.0, distance_type="l2", nms_radius=5, score_threshold=0.0,
+                  normalize_descriptors=True, sampling_mode="nearest")
+
+
+def main():
+    # C1: ShiTomasiScore(3) on one 480x640 image (export_shi_tomasi.py path)
+    img = synth_image(1000)[None, None].astype(np.float32)
+    with torch.no_grad():
+        s3 = ShiTomasiScore(3).eval()(torch.from_numpy(img)).numpy()
+        s5 = ShiTomasiScore(5).eval()(torch.from_numpy(img[:, :, :96, :128].copy())).numpy()
+        g = torch.Generator().manual_seed(7)
+        fimg = (torch.rand(2, 1, 61, 83, generator=g) * 255).numpy().astype(np.float32)
+        sf3 = ShiTomasiScore(3).eval()(torch.from_numpy(fimg)).numpy()
+        sf7 = ShiTomasiScore(7).eval()(torch.from_numpy(fimg)).numpy()
+    # NB: torch CPU evaluates sqrt on large contiguous tensors through MKL VML (vsSqrt), which is
+    # faithfully but not correctly rounded (~0.7 % of results are 1 ulp off IEEE sqrt), so the map
+    # is stored in full and compared with a 1-ulp-of-the-sqrt-term allowance (DESIGN.md "sqrt").
+    save("c1_shi_tomasi", seed=1000, score3_sha=np.array(sha(s3)), score3=s3[0, 0],
+         score5_96x128=s5[0, 0], float_img=fimg, float_score3=sf3, float_score7=sf7)
+
+    # NMS / top-k unit vectors on small maps with plateaus, thresholds and margins
+    g = torch.Generator().manual_seed(11)
+    sm = torch.floor(torch.rand(3, 45, 67, generator=g) * 12.0) * 0.25     # many exact ties / plateaus
+    sm[1] = sm[1] * 1e-7                                                   # exercises the "- 1e-7" slack
+    sm[2, 10:20, 10:30] = 0.0
+    nms = {f"mask_r{r}": np.packbits(apply_nms_maxpool(sm, r).numpy().astype(bool)) for r in (1, 2, 3, 5)}
+    g2 = torch.Generator().manual_seed(12)
+    su = torch.rand(2, 45, 67, generator=g2) * 9.0                          # (almost surely) tie-free
+    topk = {}
+    for i, (r, k, thr, margin) in enumerate([(2, 40, 0.0, 0), (3, 64, 4.0, 6), (1, 100, -1.0, 3), (5, 30, 8.5, 0)]):
+        mk = apply_nms_maxpool(su, r)
+        kp, sc = select_topk_keypoints(su, mk, k, thr, margin)
+        topk[f"t{i}_args"] = np.array([r, k, thr, margin], np.float64)
+        topk[f"t{i}_kpts"] = kp.numpy()
+        topk[f"t{i}_scores"] = sc.numpy()
+    save("nms_topk", plateau_scores=sm.numpy(), uniq_scores=su.numpy(), **nms, **topk)
+
+    # C2: the north-star pair (export-CLI hyper-parameters, K=512)
+    run_pipeline("c2_pair_480x640_k512", 1000, 480, 640, 512, EXPORT_CFG,
+                 mnn=dict(max_matches=100, threshold=0.1))
+    # same config, noisy second image, different seed: bits + keypoints only (P by hash/marginals)
+    run_pipeline("c2_pair_noise_seed1001", 1001, 480, 640, 512, EXPORT_CFG, noise=2, store_p=False,
+                 mnn=dict(max_matches=100, threshold=0.1))
+    # small: class-default "soft" configuration (num_pairs 256, no binarisation, eps 1.0, nms 3)
+    run_pipeline("small_default_120x160_k64", 2000, 120, 160, 64, dict(), mnn=dict(max_matches=20, threshold=0.01))
+    # small: hard bits, un-normalised (cost == Hamming distance), eps 8
+    run_pipeline("small_hamming_96x128_k48", 2001, 96, 128, 48,
+                 dict(num_pairs=256, binarize=True, soft_binarize=False, normalize_descriptors=False,
+                      epsilon=8.0, unused_score=40.0, nms_radius=2, sinkhorn_iterations=10))
+    # small: soft sigmoid bits, l1 distance, threshold + explicit margin
+    run_pipeline("small_soft_l1_96x128_k32", 2002, 96, 128, 32,
+                 dict(num_pairs=256, binarize=True, soft_binarize=True, temperature=4.0, distance_type="l1",
+                      epsilon=2.0, nms_radius=4, score_threshold=2500.0, border_margin=9, sinkhorn_iterations=7))
+    # ragged: second image mostly flat -> fewer than K corners -> (-1,-1) keypoints, zero descriptors
+    run_pipeline("ragged_120x160_k96", 2003, 120, 160, 96,
+                 dict(EXPORT_CFG, nms_radius=3), blank=(0, 120, 24, 160),
+                 mnn=dict(max_matches=100, threshold=0.1))
+    # block_size 5 (the Angle-variant default): tolerance parity on scores, exact on the rest
+    run_pipeline("small_bs5_120x160_k64", 2004, 120, 160, 64, dict(EXPORT_CFG, block_size=5, nms_radius=3))
+
+    # SinkhornMatcher unit vectors, N != M, float descriptors
+    g = torch.Generator().manual_seed(21)
+    d1 = torch.nn.functional.normalize(torch.randn(2, 40, 32, generator=g), dim=-1)
+    d2 = torch.nn.functional.normalize(torch.randn(2, 56, 32, generator=g), dim=-1)
+    sk = dict(d1=d1.numpy(), d2=d2.numpy())
+    with torch.no_grad():
+        for i, kw in enumerate([dict(iterations=20, epsilon=1.0), dict(iterations=5, epsilon=0.1, unused_score=0.7),
+                                dict(iterations=9, epsilon=0.5, distance_type="l1"), dict(iterations=1, epsilon=0.05)]):
+            sk[f"s{i}_cfg"] = np.array(repr(kw))
+            sk[f"s{i}_P"] = SinkhornMatcher(**kw).eval()(d1, d2).numpy()
+    save("sinkhorn_unit", **sk)
+
+
+if __name__ == "__main__":
+    main()

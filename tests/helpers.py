@@ -1,0 +1,57 @@
+"""Shared checker utilities (test infrastructure)."""
+from __future__ import annotations
+
+import ast
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name: str):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def cfg_of(g, key="cfg") -> dict:
+    return ast.literal_eval(str(g[key]))
+
+
+def tie_canonical_perm(kpts: np.ndarray, kscores: np.ndarray, width: int) -> np.ndarray:
+    """Permutation that re-orders one image's K keypoints into the build's tie policy
+    (score descending, linear index ascending).  torch.topk's order inside a group of
+    equal scores is implementation-defined; everything else about the
+    order is already fixed, so this only moves entries inside tie groups.  Invalid
+    entries (-1,-1 / score 0) sort last, among themselves by original position."""
+    k = kpts.shape[0]
+    lin = kpts[:, 0].astype(np.int64) * width + kpts[:, 1].astype(np.int64)
+    invalid = kpts[:, 0] < 0
+    lin = np.where(invalid, np.iinfo(np.int64).max - (k - np.arange(k)), lin)
+    return np.lexsort((lin, -kscores.astype(np.float64)))
+
+
+def permute_p(p: np.ndarray, perm_rows: np.ndarray, perm_cols: np.ndarray) -> np.ndarray:
+    """Apply keypoint permutations to a (N+1, M+1) assignment matrix (dustbins stay last)."""
+    r = np.concatenate([perm_rows, [p.shape[0] - 1]])
+    c = np.concatenate([perm_cols, [p.shape[1] - 1]])
+    return p[np.ix_(r, c)]
+
+
+def unpack_bits(words: np.ndarray, nbits: int) -> np.ndarray:
+    w = np.asarray(words, np.uint32)
+    b = (w[..., None] >> np.arange(32, dtype=np.uint32)) & 1
+    return b.reshape(*w.shape[:-1], -1)[..., :nbits].astype(bool)
+
+
+def p_close(p: np.ndarray, ref: np.ndarray, atol: float = 1e-4):
+    """north_star tolerance: |dP| <= 1e-4 on core entries; dustbin row/column entries can be
+    as large as M, so there the bound is relative: 1e-4 * max(1, |P|)."""
+    err = np.abs(p.astype(np.float64) - ref.astype(np.float64))
+    bound = atol * np.maximum(1.0, np.abs(ref.astype(np.float64)))
+    return bool((err <= bound).all()), float((err / bound).max())
+
+
+def bad_tables(num_pairs: int):
+    path = os.path.join(os.path.dirname(GOLDEN), "..", "onnx_image_processing_amd", "data", "bad_tables.npz")
+    t = np.load(path)
+    return t[f"box_{num_pairs}"], t[f"thr_{num_pairs}"]
