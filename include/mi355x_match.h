@@ -1,0 +1,124 @@
+/*
+ * mi355x_match.h -- C ABI of the MI355X-native image-matching hot path.
+ *
+ * The reference (fateshelled/onnx_image_processing) has no FFI: its boundary for this
+ * path is the Python nn.Module.forward() signatures under pytorch_model/{detector,utils,
+ * descriptor,matching}.  Each entry point below is what a binding for one of those
+ * forward()s calls; the reference interface it replaces is cited per function
+ * (paths relative to the reference root).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'd / torch.Tensor.data_ptr() on ROCm);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
+ *     enqueued asynchronously on it, nothing synchronises, nothing allocates;
+ *   - tensors are dense row-major float32 unless stated; images are (n, 1, h, w);
+ *   - return value: 0 = launched; > 0 = hipError_t of the failed launch; < 0 = MI_E_*
+ *     argument error detected on the host before any launch.
+ */
+#ifndef MI355X_MATCH_H
+#define MI355X_MATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *mi_stream_t;
+
+enum {
+  MI_OK = 0,
+  MI_E_NULL = -1,     /* required pointer is NULL */
+  MI_E_SHAPE = -2,    /* non-positive or inconsistent extent */
+  MI_E_PARAM = -3,    /* parameter outside the supported set */
+  MI_E_CAPACITY = -4, /* workspace / capacity too small for the request */
+  MI_E_ALIGN = -5     /* pointer or pitch not aligned as documented */
+};
+
+/* descriptor output modes of mi_sparse_bad (reference descriptor/bad.py:561-567) */
+enum { MI_BAD_RAW = 0, MI_BAD_SOFT = 1, MI_BAD_HARD = 2 };
+/* distance types (reference matching/sinkhorn.py:95-108) */
+enum { MI_DIST_L2 = 0, MI_DIST_L1 = 1 };
+
+int mi_abi_version(void);
+const char *mi_error_string(int code);
+
+/* ---- detector/shi_tomasi.py:66-112  ShiTomasiScore.forward ---------------------------------
+ * score[n,1,h,w] = max(0, (a+c)/2 - sqrt(((a-c)/2)^2 + b^2 + 1e-10)) of the Sobel structure
+ * tensor summed over block_size^2 (replicate padding of image and of the product maps).
+ * block_size: positive odd.  Bit-exact vs the reference for uint8-valued input, block 3. */
+int mi_corner_response(const float *image, int n, int h, int w, int block_size, float *score,
+                       mi_stream_t stream);
+
+/* ---- utils/keypoint_utils.py:12-44  apply_nms_maxpool ---------------------------------------
+ * mask = 1.0f where score >= max over the (2r+1)^2 window (outside image = -inf) - 1e-7. */
+int mi_nms_mask(const float *score, int n, int h, int w, int radius, float *mask, mi_stream_t stream);
+
+/* ---- utils/keypoint_utils.py:71-92 (candidate stage of select_topk_keypoints) ---------------
+ * Emits one 64-bit key per surviving pixel into cand[img * capacity + i], counts in count[img]
+ * (count must be zeroed by the caller, e.g. hipMemsetAsync on the same stream):
+ *     m = score * mask * border ; survive iff m > max(score_threshold, 0)
+ *     key = (float_bits(m) << 32) | (0xFFFFFFFF - (y*w + x))
+ * mi_nms_candidates fuses the NMS of mi_nms_mask (mask never materialised);
+ * mi_select_candidates takes an explicit mask (the reference's two-call form).
+ * capacity >= h*w can never overflow; overflowing keys are dropped and count keeps counting. */
+int mi_nms_candidates(const float *score, int n, int h, int w, int radius, float score_threshold,
+                      int border_margin, uint64_t *cand, uint32_t *count, uint32_t capacity,
+                      mi_stream_t stream);
+int mi_select_candidates(const float *score, const float *mask, int n, int h, int w,
+                         float score_threshold, int border_margin, uint64_t *cand, uint32_t *count,
+                         uint32_t capacity, mi_stream_t stream);
+
+/* ---- utils/keypoint_utils.py:94-115 (top-k stage of select_topk_keypoints) ------------------
+ * For each image: the k largest keys, descending => (score desc, linear index asc).
+ * keypoints[n,k,2] = (y, x) as float, (-1,-1) beyond the candidate count; kscores[n,k].
+ * 1 <= k <= 4096. */
+int mi_topk_keypoints(const uint64_t *cand, const uint32_t *count, uint32_t capacity, int n, int w,
+                      int k, float *keypoints, float *kscores, mi_stream_t stream);
+
+/* ---- descriptor/bad.py:436-576  SparseBAD.forward (non-oriented, sampling_mode="nearest") ---
+ * pair_geom[p] = x1 | x2<<5 | y1<<10 | y2<<15 | r<<20 in the 32x32 patch frame (table rows of
+ * descriptor/bad_params.py), pair_thr[p] the learned threshold.  num_pairs % 64 == 0, <= 1024.
+ * desc (n,k,num_pairs) f32 and/or bits (n,k,num_pairs/32) u32 may be NULL (bits only for HARD).
+ * Box sums are exact (fp64 summed-area table over a replicate-clamped 34x34 window). */
+int mi_sparse_bad(const float *image, int n, int h, int w, const float *keypoints, int k,
+                  const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
+                  float temperature, int normalize, float *desc, uint32_t *bits, mi_stream_t stream);
+
+/* ---- matching/sinkhorn.py:79-110,178  cost matrix -> core log-score matrix --------------------
+ * z[b, i, j] = -cost(desc1[b,i], desc2[b,j]) / epsilon for i < n, j < m; row pitch `pitch` floats
+ * (pitch % 4 == 0, pitch >= m, z 16-byte aligned).  The dustbin row/column of the reference's
+ * augmented matrix (sinkhorn.py:187) is a constant and is not stored: mi_sinkhorn takes it as a
+ * scalar.  epsilon is a double so that fp32(epsilon) and fp32(-unused/epsilon) round exactly as
+ * the reference's Python-float arithmetic does.
+ * _bits: descriptors are packed hard bits (num_bits % 32 == 0, <= 4096); `normalized` selects
+ *     desc = bit/sqrt(popcount) (cost = 2 - 2 dot/sqrt(pa pb)) or desc = bit (cost = Hamming).
+ *     Dot products are exact (v_mfma_i32_32x32x32_i8 on 0/1 bytes).
+ * _f32: arbitrary float descriptors (n,d)/(m,d); L2 via v_mfma_f32_32x32x2_f32, L1 on the VALU. */
+int mi_cost_logscores_bits(const uint32_t *bits1, const uint32_t *bits2, int batch, int n, int m,
+                           int num_bits, int normalized, double epsilon, float *z, int pitch,
+                           mi_stream_t stream);
+int mi_cost_logscores_f32(const float *desc1, const float *desc2, int batch, int n, int m, int d,
+                          int distance, double epsilon, float *z, int pitch, mi_stream_t stream);
+
+/* ---- matching/sinkhorn.py:112-147,187-206  log-space Sinkhorn with dustbins ------------------
+ * z: core log-scores as above.  dustbin_logscore = fp32(-unused_score/epsilon).  u (batch*(n+1))
+ * and v (batch*(m+1)) are workspace and return the final duals.  p (batch, n+1, m+1) dense =
+ * exp(Z + u + v) over the augmented matrix; may be NULL (duals only).  iterations >= 1. */
+int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, float dustbin_logscore,
+                int iterations, float *u, float *v, float *p, mi_stream_t stream);
+
+/* ---- matching/match_extraction.py:72-181  MutualNearestNeighborMatcher.forward --------------
+ * p (batch, n+1, m+1); kpts1 (batch,n,2); kpts2 (batch,m,2).  Workspace: row_best (batch*n) u64,
+ * col_best (batch*m) u64.  Outputs mk1/mk2 (batch,max_matches,2), scores (batch,max_matches),
+ * valid (batch,max_matches) u8, match_ij (batch,max_matches,2) i32 (may be NULL).
+ * n <= 4096.  Ties: first index (argmax), then (score desc, row asc) for the top-max_matches. */
+int mi_mnn_extract(const float *p, int batch, int n, int m, const float *kpts1, const float *kpts2,
+                   int max_matches, float threshold, uint64_t *row_best, uint64_t *col_best,
+                   float *mk1, float *mk2, float *scores, uint8_t *valid, int32_t *match_ij,
+                   mi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355X_MATCH_H */

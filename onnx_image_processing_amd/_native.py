@@ -1,0 +1,85 @@
+"""ctypes binding of lib/libmi355x_match.so (the C ABI in include/mi355x_match.h).
+
+PyTorch is plumbing only: it owns device memory and the HIP stream; every compute call
+goes through the C ABI with raw device pointers.  There is no CPU or eager fallback: if the
+library is missing or a tensor is not on the GPU the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_uint32, c_void_p
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libmi355x_match.so")
+
+# name -> argtypes (return type is int unless listed in _RESTYPE); mirrors include/mi355x_match.h
+SIGNATURES = {
+    "mi_abi_version": [],
+    "mi_error_string": [c_int],
+    "mi_corner_response": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "mi_nms_mask": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "mi_nms_candidates": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_uint32, c_void_p],
+    "mi_select_candidates": [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_uint32, c_void_p],
+    "mi_topk_keypoints": [c_void_p, c_void_p, c_uint32, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "mi_sparse_bad": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
+                      c_void_p, c_void_p, c_void_p],
+    "mi_cost_logscores_bits": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p],
+    "mi_cost_logscores_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p],
+    "mi_sinkhorn": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mi_mnn_extract": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
+                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+}
+_RESTYPE = {"mi_error_string": c_char_p}
+
+MI_BAD_RAW, MI_BAD_SOFT, MI_BAD_HARD = 0, 1, 2
+MI_DIST_L2, MI_DIST_L1 = 0, 1
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP library is not built. Run "
+                "`python -m onnx_image_processing_amd.build` (there is no CPU fallback)."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)            # AttributeError if the ABI and the binding diverge
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPE.get(name, c_int)
+        _lib = lib
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().mi_error_string(code)
+        raise RuntimeError(f"{what} failed ({code}): {msg.decode() if msg else '?'}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dev(t: torch.Tensor, dtype: torch.dtype, what: str) -> int:
+    """Device pointer of a contiguous GPU tensor of the expected dtype."""
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what} must live on the GPU (got device {t.device}); this package has no CPU path"
+        )
+    if t.dtype != dtype:
+        raise RuntimeError(f"{what} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{what} must be contiguous")
+    return t.data_ptr()
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)

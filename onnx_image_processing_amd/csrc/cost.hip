@@ -1,0 +1,253 @@
+// K5: descriptor cost matrix -> augmented Sinkhorn log-score matrix Z.
+// Semantics: reference pytorch_model/matching/sinkhorn.py:95-108 (cost) and :178
+// (Z = -cost/epsilon; the constant dustbin padding of :187 is applied inside K6).
+//
+// bits path  : hard-binarised descriptors stay packed (64 B per 512-bit descriptor); each
+//              32-bit word is expanded to 0/1 bytes in registers and fed to
+//              v_mfma_i32_32x32x32_i8, so dot(a,b) = popcount(a & b) is exact.  The epilogue
+//              applies cost = |a|^2 + |b|^2 - 2 a.b with a = bit/sqrt(pop) (normalised) or
+//              a = bit (Hamming) in fp32 and writes the n x m core of Z.
+// f32 path   : arbitrary float descriptors through v_mfma_f32_32x32x2_f32 (exact fp32 fma
+//              chain, no reduced precision: epsilon = 0.05 multiplies any cost error by 20).
+// l1 path    : |a-b| sums on the VALU from the same LDS tiles.
+#include "common.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// 4 bits -> 4 bytes of 0/1 (bit i -> byte i)
+__device__ __forceinline__ int spread4(uint32_t nib) { return (int)(((nib & 15u) * 0x00204081u) & 0x01010101u); }
+
+__device__ __forceinline__ v4i spread16(uint32_t half) {
+  v4i r;
+  r[0] = spread4(half);
+  r[1] = spread4(half >> 4);
+  r[2] = spread4(half >> 8);
+  r[3] = spread4(half >> 12);
+  return r;
+}
+
+constexpr int CB_T = 128;  // block tile edge (bits path)
+
+__global__ __launch_bounds__(256) void cost_bits_kernel(const uint32_t *__restrict__ bits1,
+                                                        const uint32_t *__restrict__ bits2, int n, int m,
+                                                        int words, int normalized, float eps,
+                                                        float *__restrict__ z, int pitch) {
+  extern __shared__ uint32_t lds_u[];
+  const int wp = words + 1;                          // +1 word: conflict-free column reads
+  uint32_t *sa = lds_u;                              // [128][wp]
+  uint32_t *sb = sa + CB_T * wp;                     // [128][wp]
+  float *inv_a = reinterpret_cast<float *>(sb + CB_T * wp);  // [128] scale of row descriptors
+  float *nrm_a = inv_a + CB_T;                       // [128] squared norms
+  float *inv_b = nrm_a + CB_T;
+  float *nrm_b = inv_b + CB_T;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int j0 = blockIdx.x * CB_T, i0 = blockIdx.y * CB_T, b = blockIdx.z;
+  const uint32_t *a_g = bits1 + (size_t)b * n * words;
+  const uint32_t *b_g = bits2 + (size_t)b * m * words;
+
+  for (int i = t; i < CB_T * words; i += 256) {
+    const int r = i / words, c = i - r * words;
+    sa[r * wp + c] = (i0 + r < n) ? a_g[(size_t)(i0 + r) * words + c] : 0u;
+    sb[r * wp + c] = (j0 + r < m) ? b_g[(size_t)(j0 + r) * words + c] : 0u;
+  }
+  __syncthreads();
+  {
+    const int r = t & 127;
+    const uint32_t *src = (t < 128 ? sa : sb) + r * wp;
+    int pop = 0;
+    for (int c = 0; c < words; ++c) pop += __popc(src[c]);
+    float inv = 1.0f, nrm = (float)pop;
+    if (normalized) {
+      // F.normalize: bit / max(sqrt(pop), 1e-12); squared norm re-formed in fp32 like sinkhorn.py:98
+      inv = pop > 0 ? 1.0f / sqrtf((float)pop) : 0.0f;
+      nrm = (float)pop * (inv * inv);
+    }
+    (t < 128 ? inv_a : inv_b)[r] = inv;
+    (t < 128 ? nrm_a : nrm_b)[r] = nrm;
+  }
+  __syncthreads();
+
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;   // wave's 64x64 sub-tile
+  const int lr = lane & 31, lh = lane >> 5;
+  v16i acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0;
+
+  for (int ks = 0; ks < words; ++ks) {
+    v4i fa[2], fb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      fa[q] = spread16(sa[(wm + q * 32 + lr) * wp + ks] >> (16 * lh));
+      fb[q] = spread16(sb[(wn + q * 32 + lr) * wp + ks] >> (16 * lh));
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+  }
+
+  float *zb = z + (size_t)b * (size_t)n * pitch;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int rl = wm + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int cl = wn + ni * 32 + lr;
+        const int gi = i0 + rl, gj = j0 + cl;
+        if (gi < n && gj < m) {
+          const float dot = (float)acc[mi][ni][e];
+          const float cross = dot * (inv_a[rl] * inv_b[cl]);
+          const float cost = fmaxf((nrm_a[rl] + nrm_b[cl]) - 2.0f * cross, 0.0f);   // sinkhorn.py:101-103
+          zb[(size_t)gi * pitch + gj] = -cost / eps;                                 // sinkhorn.py:178
+        }
+      }
+}
+
+// ------------------------------------------------------------------------------------------
+constexpr int CF_T = 64;   // block tile edge (float paths)
+constexpr int CF_K = 32;   // k chunk
+constexpr int CF_P = CF_K + 1;
+
+template <int DIST>
+__global__ __launch_bounds__(256) void cost_f32_kernel(const float *__restrict__ d1,
+                                                       const float *__restrict__ d2, int n, int m, int d,
+                                                       float eps, float *__restrict__ z, int pitch) {
+  __shared__ float sa[CF_T * CF_P];
+  __shared__ float sb[CF_T * CF_P];
+  __shared__ float nrm_a[CF_T], nrm_b[CF_T];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int j0 = blockIdx.x * CF_T, i0 = blockIdx.y * CF_T, b = blockIdx.z;
+  const float *a_g = d1 + (size_t)b * n * d;
+  const float *b_g = d2 + (size_t)b * m * d;
+
+  const int srow = t >> 2, sk = (t & 3) * 8;          // staging: 8 consecutive k of one row
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  v16f acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+  float l1acc[4][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) l1acc[p][q] = 0.0f;
+  float ssa = 0.0f, ssb = 0.0f;
+
+  for (int k0 = 0; k0 < d; k0 += CF_K) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int kk = k0 + sk + q;
+      const float va = (i0 + srow < n && kk < d) ? a_g[(size_t)(i0 + srow) * d + kk] : 0.0f;
+      const float vb = (j0 + srow < m && kk < d) ? b_g[(size_t)(j0 + srow) * d + kk] : 0.0f;
+      sa[srow * CF_P + sk + q] = va;
+      sb[srow * CF_P + sk + q] = vb;
+      ssa += va * va;
+      ssb += vb * vb;
+    }
+    __syncthreads();
+    if (DIST == MI_DIST_L2) {
+#pragma unroll
+      for (int kk = 0; kk < CF_K; kk += 2) {
+        const float fa = sa[(wm + lr) * CF_P + kk + lh];
+        const float fb = sb[(wn + lr) * CF_P + kk + lh];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+      }
+    } else {
+      const int ti = (t >> 4) * 4, tj = (t & 15) * 4;  // 4x4 outputs per thread
+      for (int kk = 0; kk < CF_K; ++kk) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { av[p] = sa[(ti + p) * CF_P + kk]; bv[p] = sb[(tj + p) * CF_P + kk]; }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) l1acc[p][q] += fabsf(av[p] - bv[q]);
+      }
+    }
+    __syncthreads();
+  }
+
+  float *zb = z + (size_t)b * (size_t)n * pitch;
+  if (DIST == MI_DIST_L2) {
+    // squared norms: 4 staging threads per row hold partial sums
+    ssa += __shfl_xor(ssa, 1, 64); ssa += __shfl_xor(ssa, 2, 64);
+    ssb += __shfl_xor(ssb, 1, 64); ssb += __shfl_xor(ssb, 2, 64);
+    if ((t & 3) == 0) { nrm_a[srow] = ssa; nrm_b[srow] = ssb; }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int rl = wm + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      const int cl = wn + lr;
+      const int gi = i0 + rl, gj = j0 + cl;
+      if (gi < n && gj < m) {
+        const float cost = fmaxf((nrm_a[rl] + nrm_b[cl]) - 2.0f * acc[e], 0.0f);
+        zb[(size_t)gi * pitch + gj] = -cost / eps;
+      }
+    }
+  } else {
+    const int ti = (t >> 4) * 4, tj = (t & 15) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int gi = i0 + ti + p, gj = j0 + tj + q;
+        if (gi < n && gj < m) zb[(size_t)gi * pitch + gj] = -l1acc[p][q] / eps;
+      }
+  }
+}
+
+int check_z(const void *a, const void *b, const void *z, int batch, int n, int m, int pitch, double eps) {
+  if (!a || !b || !z) return MI_E_NULL;
+  if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
+  if (pitch < m || pitch % 4 != 0 || ((uintptr_t)z % 16) != 0) return MI_E_ALIGN;
+  if (!(eps > 0.0)) return MI_E_PARAM;
+  return MI_OK;
+}
+
+}  // namespace
+
+extern "C" int mi_cost_logscores_bits(const uint32_t *bits1, const uint32_t *bits2, int batch, int n, int m,
+                                      int num_bits, int normalized, double epsilon, float *z, int pitch,
+                                      mi_stream_t stream) {
+  int e = check_z(bits1, bits2, z, batch, n, m, pitch, epsilon);
+  if (e) return e;
+  if (num_bits <= 0 || num_bits % 32 != 0 || num_bits > 4096) return MI_E_PARAM;
+  const int words = num_bits / 32;
+  const size_t lds = (size_t)2 * CB_T * (words + 1) * 4 + 4 * CB_T * 4;
+  dim3 grid(ceil_div(m, CB_T), ceil_div(n, CB_T), batch);
+  hipLaunchKernelGGL(cost_bits_kernel, grid, dim3(256), lds, (hipStream_t)stream, bits1, bits2, n, m, words,
+                     normalized, (float)epsilon, z, pitch);
+  return mi_launch_status();
+}
+
+extern "C" int mi_cost_logscores_f32(const float *desc1, const float *desc2, int batch, int n, int m, int d,
+                                     int distance, double epsilon, float *z, int pitch, mi_stream_t stream) {
+  int e = check_z(desc1, desc2, z, batch, n, m, pitch, epsilon);
+  if (e) return e;
+  if (d <= 0) return MI_E_SHAPE;
+  dim3 grid(ceil_div(m, CF_T), ceil_div(n, CF_T), batch);
+  const float eps = (float)epsilon;
+  if (distance == MI_DIST_L2)
+    hipLaunchKernelGGL(cost_f32_kernel<MI_DIST_L2>, grid, dim3(256), 0, (hipStream_t)stream, desc1, desc2, n,
+                       m, d, eps, z, pitch);
+  else if (distance == MI_DIST_L1)
+    hipLaunchKernelGGL(cost_f32_kernel<MI_DIST_L1>, grid, dim3(256), 0, (hipStream_t)stream, desc1, desc2, n,
+                       m, d, eps, z, pitch);
+  else
+    return MI_E_PARAM;
+  return mi_launch_status();
+}

@@ -1,0 +1,162 @@
+// K7: mutual-nearest-neighbour match extraction from the Sinkhorn assignment matrix.
+// Semantics: reference pytorch_model/matching/match_extraction.py:72-181: argmax over rows and
+// columns of P[:n,:m] (first index on ties), mutual check, score >= threshold, the
+// max_matches best by score (build tie policy: lower row index first), gather keypoints,
+// valid = score > 0; non-matches carry score -1 exactly as the reference's top-k over
+// `where(valid, score, -1)` does, and slots beyond n (n < max_matches) are zero-padded.
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int MX_THREADS = 1024;
+constexpr int MX_MAX = 4096;
+
+__device__ __forceinline__ uint64_t best_key(float p, uint32_t idx) {
+  return ((uint64_t)__float_as_uint(p) << 32) | (uint64_t)(0xFFFFFFFFu - idx);   // p >= 0
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t k) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint64_t other = __shfl_xor(k, o, 64);
+    k = other > k ? other : k;
+  }
+  return k;
+}
+
+// one wave per row i < n: best column
+__global__ __launch_bounds__(256) void mnn_row_kernel(const float *__restrict__ p, int n, int m,
+                                                      uint64_t *__restrict__ row_best) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, i = blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  const float *pr = p + ((size_t)b * (n + 1) + i) * (size_t)(m + 1);
+  uint64_t k = 0ull;
+  for (int j = lane; j < m; j += 64) {
+    const uint64_t c = best_key(pr[j], (uint32_t)j);
+    k = c > k ? c : k;
+  }
+  k = wave_max_u64(k);
+  if (lane == 0) row_best[(size_t)b * n + i] = k;
+}
+
+// 64 columns per workgroup, rows split over 4 waves: best row per column j < m
+__global__ __launch_bounds__(256) void mnn_col_kernel(const float *__restrict__ p, int n, int m,
+                                                      uint64_t *__restrict__ col_best) {
+  __shared__ uint64_t red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, j = blockIdx.x * 64 + lane;
+  const float *pb = p + (size_t)b * (n + 1) * (size_t)(m + 1);
+  uint64_t k = 0ull;
+  if (j < m) {
+    for (int i = wave; i < n; i += 4) {
+      const uint64_t c = best_key(pb[(size_t)i * (m + 1) + j], (uint32_t)i);
+      k = c > k ? c : k;
+    }
+  }
+  red[wave][lane] = k;
+  __syncthreads();
+  if (wave == 0 && j < m) {
+    for (int w = 1; w < 4; ++w) k = red[w][lane] > k ? red[w][lane] : k;
+    col_best[(size_t)b * m + j] = k;
+  }
+}
+
+__global__ __launch_bounds__(MX_THREADS) void mnn_select_kernel(
+    int n, int m, const uint64_t *__restrict__ row_best, const uint64_t *__restrict__ col_best,
+    const float *__restrict__ kpts1, const float *__restrict__ kpts2, int max_matches, float threshold,
+    float *__restrict__ mk1, float *__restrict__ mk2, float *__restrict__ scores,
+    uint8_t *__restrict__ valid, int32_t *__restrict__ match_ij) {
+  __shared__ uint64_t keys[MX_MAX];
+  const int t = threadIdx.x, b = blockIdx.x;
+  const uint64_t *rb = row_best + (size_t)b * n;
+  const uint64_t *cb = col_best + (size_t)b * m;
+  int npad = 2;
+  while (npad < n) npad <<= 1;
+  for (int i = t; i < npad; i += MX_THREADS) {
+    uint64_t key = 0ull;
+    if (i < n) {
+      const uint64_t r = rb[i];
+      const uint32_t j = 0xFFFFFFFFu - (uint32_t)(r & 0xFFFFFFFFull);
+      const float val = __uint_as_float((uint32_t)(r >> 32));
+      const uint32_t ib = 0xFFFFFFFFu - (uint32_t)(cb[j] & 0xFFFFFFFFull);
+      const bool ok = (ib == (uint32_t)i) && (val >= threshold);
+      // high word: 0 for non-matches, bits(score)+1 for matches (keeps score 0.0 above them);
+      // low word: inverted row index -> lower row first among equal scores.  +1 so that a real
+      // row never collides with the all-zero padding key.
+      key = ((uint64_t)(ok ? (uint32_t)(r >> 32) + 1u : 0u) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)i);
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  for (int size = 2; size <= npad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = t; i < (npad >> 1); i += MX_THREADS) {
+        const int pos = 2 * i - (i & (stride - 1));
+        const int par = pos + stride;
+        const bool desc = ((pos & size) == 0);
+        const uint64_t a = keys[pos], c = keys[par];
+        if ((a < c) == desc) { keys[pos] = c; keys[par] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  const int cnt = max_matches < n ? max_matches : n;
+  for (int s = t; s < max_matches; s += MX_THREADS) {
+    float sc = 0.0f;
+    uint32_t i = 0;
+    bool matched = false;
+    if (s < cnt) {
+      const uint64_t key = keys[s];
+      i = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
+      const uint32_t hi = (uint32_t)(key >> 32);
+      matched = hi != 0u;
+      sc = matched ? __uint_as_float(hi - 1u) : -1.0f;
+    }
+    const uint32_t j = 0xFFFFFFFFu - (uint32_t)(rb[i] & 0xFFFFFFFFull);
+    const size_t o = (size_t)b * max_matches + s;
+    mk1[o * 2 + 0] = kpts1[((size_t)b * n + i) * 2 + 0];
+    mk1[o * 2 + 1] = kpts1[((size_t)b * n + i) * 2 + 1];
+    mk2[o * 2 + 0] = kpts2[((size_t)b * m + j) * 2 + 0];
+    mk2[o * 2 + 1] = kpts2[((size_t)b * m + j) * 2 + 1];
+    scores[o] = sc;
+    const bool ok = sc > 0.0f;
+    valid[o] = ok ? 1 : 0;
+    if (match_ij) {
+      match_ij[o * 2 + 0] = ok ? (int32_t)i : -1;
+      match_ij[o * 2 + 1] = ok ? (int32_t)j : -1;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mi_mnn_extract(const float *p, int batch, int n, int m, const float *kpts1, const float *kpts2,
+                              int max_matches, float threshold, uint64_t *row_best, uint64_t *col_best,
+                              float *mk1, float *mk2, float *scores, uint8_t *valid, int32_t *match_ij,
+                              mi_stream_t stream) {
+  if (!p || !kpts1 || !kpts2 || !row_best || !col_best || !mk1 || !mk2 || !scores || !valid) return MI_E_NULL;
+  if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
+  if (n > MX_MAX || max_matches <= 0) return MI_E_PARAM;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(mnn_row_kernel, dim3(ceil_div(n, 4), batch), dim3(256), 0, s, p, n, m, row_best);
+  hipLaunchKernelGGL(mnn_col_kernel, dim3(ceil_div(m, 64), batch), dim3(256), 0, s, p, n, m, col_best);
+  hipLaunchKernelGGL(mnn_select_kernel, dim3(batch), dim3(MX_THREADS), 0, s, n, m, row_best, col_best, kpts1,
+                     kpts2, max_matches, threshold, mk1, mk2, scores, valid, match_ij);
+  return mi_launch_status();
+}
+
+extern "C" int mi_abi_version(void) { return 1; }
+
+extern "C" const char *mi_error_string(int code) {
+  switch (code) {
+    case MI_OK: return "ok";
+    case MI_E_NULL: return "required pointer is NULL";
+    case MI_E_SHAPE: return "non-positive or inconsistent extent";
+    case MI_E_PARAM: return "parameter outside the supported set";
+    case MI_E_CAPACITY: return "workspace or capacity too small";
+    case MI_E_ALIGN: return "pointer or pitch not aligned as documented";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}

@@ -1,0 +1,259 @@
+// K6: log-space Sinkhorn with dustbins.
+// Semantics: reference pytorch_model/matching/sinkhorn.py:112-147 (iterations) and :178-206
+// (augmented matrix, marginals, exp).  u, v start at 0; every iteration is
+//     u_i = log mu_i - LSE_j(Z_ij + v_j)   then   v_j = log nu_j - LSE_i(Z_ij + u_i)
+// over the (n+1) x (m+1) augmented matrix whose last row/column/corner are the constant
+// dustbin score.  Those constants are never stored: Z holds only the n x m core (rows are
+// 16-byte aligned, pitch % 4 == 0) and the dustbin terms are added analytically.
+//
+// Both passes are pure streaming reductions over Z (bandwidth-bound: 4 B per element per
+// pass).  Row pass: one wave per row, 16-byte loads, the row lives in registers, max and sum
+// by wave shuffles.  Column pass: one workgroup per strip of columns, rows split over the 4
+// waves, per-lane online (max, sum) carried down the column in chunks of 8 rows so 8 loads
+// are in flight per lane; partials merged through LDS.
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int ROWS_PER_WAVE = 4;
+
+// ---- row pass -----------------------------------------------------------------------------
+// E4 = float4 loads per lane: covers m <= 256 * E4 columns.
+template <int E4>
+__global__ __launch_bounds__(256) void sk_row_kernel(const float *__restrict__ z, int n, int m, int pitch,
+                                                     float dust, const float *__restrict__ v,
+                                                     float *__restrict__ u, float log_m, int v_is_zero) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const float *vb = v + (size_t)b * (m + 1);
+  float vv[E4][4];
+#pragma unroll
+  for (int e = 0; e < E4; ++e)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = e * 256 + lane * 4 + q;
+      vv[e][q] = (j < m) ? (v_is_zero ? 0.0f : vb[j]) : -INFINITY;
+    }
+  const float vd = v_is_zero ? 0.0f : vb[m];
+  const float xd = dust + vd;                       // dustbin column term of every real row
+
+  const int row0 = (blockIdx.x * 4 + wave) * ROWS_PER_WAVE;
+#pragma unroll 1
+  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+    const int i = row0 + rr;
+    if (i > n) break;
+    float x[E4][4];
+    if (i < n) {
+      const float *zr = z + ((size_t)b * n + i) * pitch;
+#pragma unroll
+      for (int e = 0; e < E4; ++e) {
+        const int j = e * 256 + lane * 4;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < m) q = *reinterpret_cast<const float4 *>(zr + j);   // pitch >= round_up(m,4): in bounds
+        // columns >= m (row padding) are masked explicitly: the padding may hold anything
+        x[e][0] = (j + 0 < m) ? q.x + vv[e][0] : -INFINITY;
+        x[e][1] = (j + 1 < m) ? q.y + vv[e][1] : -INFINITY;
+        x[e][2] = (j + 2 < m) ? q.z + vv[e][2] : -INFINITY;
+        x[e][3] = (j + 3 < m) ? q.w + vv[e][3] : -INFINITY;
+      }
+    } else {                                         // dustbin row: Z = dust everywhere
+#pragma unroll
+      for (int e = 0; e < E4; ++e)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[e][q] = dust + vv[e][q];
+    }
+    float mx = xd;
+#pragma unroll
+    for (int e = 0; e < E4; ++e)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mx = fmaxf(mx, x[e][q]);
+    mx = wave_max(mx);
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < E4; ++e)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s += expf(x[e][q] - mx);          // exp(-inf) = 0 for padding lanes
+    s = wave_sum(s) + expf(xd - mx);
+    if (lane == 0) u[(size_t)b * (n + 1) + i] = ((i == n) ? log_m : 0.0f) - (logf(s) + mx);
+  }
+}
+
+// Any m: strided scalar loads, two sweeps (max, then sum).
+__global__ __launch_bounds__(256) void sk_row_generic_kernel(const float *__restrict__ z, int n, int m,
+                                                             int pitch, float dust,
+                                                             const float *__restrict__ v,
+                                                             float *__restrict__ u, float log_m,
+                                                             int v_is_zero) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const float *vb = v + (size_t)b * (m + 1);
+  const float xd = dust + (v_is_zero ? 0.0f : vb[m]);
+  const int row0 = (blockIdx.x * 4 + wave) * ROWS_PER_WAVE;
+  for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+    const int i = row0 + rr;
+    if (i > n) break;
+    const float *zr = z + ((size_t)b * n + (i < n ? i : 0)) * pitch;
+    float mx = xd;
+    for (int j = lane; j < m; j += 64) mx = fmaxf(mx, (i < n ? zr[j] : dust) + (v_is_zero ? 0.0f : vb[j]));
+    mx = wave_max(mx);
+    float s = 0.0f;
+    for (int j = lane; j < m; j += 64) s += expf(((i < n ? zr[j] : dust) + (v_is_zero ? 0.0f : vb[j])) - mx);
+    s = wave_sum(s) + expf(xd - mx);
+    if (lane == 0) u[(size_t)b * (n + 1) + i] = ((i == n) ? log_m : 0.0f) - (logf(s) + mx);
+  }
+}
+
+// ---- column pass --------------------------------------------------------------------------
+// Strip of 64*VEC columns per workgroup; wave w takes rows w, w+4, ... in chunks of CH.
+template <int VEC>
+__global__ __launch_bounds__(256) void sk_col_kernel(const float *__restrict__ z, int n, int m, int pitch,
+                                                     float dust, const float *__restrict__ u,
+                                                     float *__restrict__ v, float log_n) {
+  constexpr int CH = 8;
+  __shared__ float red_m[4][64 * VEC];
+  __shared__ float red_s[4][64 * VEC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 64 * VEC + lane * VEC;          // first column of this lane
+  const float *ub = u + (size_t)b * (n + 1);
+  const float *zb = z + (size_t)b * n * pitch;
+  // the last strip index (gridDim.x - 1) is the dustbin column: handled below
+  const bool dust_col = (blockIdx.x == gridDim.x - 1);
+
+  float mx[VEC], s[VEC];
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) { mx[c] = -INFINITY; s[c] = 0.0f; }
+
+  if (!dust_col) {
+    const bool act = j < m;                                   // m % VEC == 0 guaranteed by the host
+    for (int i0 = wave * CH; i0 < n; i0 += 4 * CH) {
+      float x[CH][VEC];
+#pragma unroll
+      for (int r = 0; r < CH; ++r) {
+        const int i = i0 + r;
+        if (i < n && act) {
+          const float ui = ub[i];
+          const float *p = zb + (size_t)i * pitch + j;
+          if (VEC == 4) {
+            const float4 q = *reinterpret_cast<const float4 *>(p);
+            x[r][0] = q.x + ui; x[r][1 % VEC] = q.y + ui; x[r][2 % VEC] = q.z + ui; x[r][3 % VEC] = q.w + ui;
+          } else if (VEC == 2) {
+            const float2 q = *reinterpret_cast<const float2 *>(p);
+            x[r][0] = q.x + ui; x[r][1 % VEC] = q.y + ui;
+          } else {
+            x[r][0] = p[0] + ui;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) x[r][c] = -INFINITY;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) {
+        float cm = x[0][c];
+#pragma unroll
+        for (int r = 1; r < CH; ++r) cm = fmaxf(cm, x[r][c]);
+        if (cm > mx[c]) { s[c] *= expf(mx[c] - cm); mx[c] = cm; }   // exp(-inf - cm) = 0 on first use
+        if (mx[c] > -INFINITY) {
+#pragma unroll
+          for (int r = 0; r < CH; ++r) s[c] += expf(x[r][c] - mx[c]);
+        }
+      }
+    }
+  } else {
+    // dustbin column: x_i = dust + u_i for i <= n ; lanes stride over rows, reduced below
+    for (int i = threadIdx.x; i <= n; i += 256) {
+      const float x = dust + ub[i];
+      if (x > mx[0]) { s[0] *= expf(mx[0] - x); mx[0] = x; }
+      s[0] += expf(x - mx[0]);
+    }
+  }
+
+  if (dust_col) {
+    // merge all 256 partials: wave shuffle, then LDS across waves
+    float gm = wave_max(mx[0]);
+    float gs = wave_sum(mx[0] > -INFINITY ? s[0] * expf(mx[0] - gm) : 0.0f);
+    if (lane == 0) { red_m[wave][0] = gm; red_s[wave][0] = gs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float fm = red_m[0][0];
+      for (int w = 1; w < 4; ++w) fm = fmaxf(fm, red_m[w][0]);
+      float fs = 0.0f;
+      for (int w = 0; w < 4; ++w) fs += red_s[w][0] * expf(red_m[w][0] - fm);
+      v[(size_t)b * (m + 1) + m] = log_n - (logf(fs) + fm);
+    }
+    return;
+  }
+
+#pragma unroll
+  for (int c = 0; c < VEC; ++c) { red_m[wave][lane * VEC + c] = mx[c]; red_s[wave][lane * VEC + c] = s[c]; }
+  __syncthreads();
+  if (wave == 0 && j < m) {
+    const float xd = dust + ub[n];                           // dustbin row term of every real column
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      float fm = xd;
+      for (int w = 0; w < 4; ++w) fm = fmaxf(fm, red_m[w][lane * VEC + c]);
+      float fs = expf(xd - fm);
+      for (int w = 0; w < 4; ++w) {
+        const float pm = red_m[w][lane * VEC + c];
+        if (pm > -INFINITY) fs += red_s[w][lane * VEC + c] * expf(pm - fm);
+      }
+      v[(size_t)b * (m + 1) + j + c] = 0.0f - (logf(fs) + fm);
+    }
+  }
+}
+
+// ---- P = exp(Z + u + v) over the augmented matrix -------------------------------------------
+__global__ __launch_bounds__(256) void sk_exp_kernel(const float *__restrict__ z, int n, int m, int pitch,
+                                                     float dust, const float *__restrict__ u,
+                                                     const float *__restrict__ v, float *__restrict__ p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 4 + wave;
+  if (i > n) return;
+  const float ui = u[(size_t)b * (n + 1) + i];
+  const float *vb = v + (size_t)b * (m + 1);
+  const float *zr = z + ((size_t)b * n + (i < n ? i : 0)) * pitch;
+  float *pr = p + ((size_t)b * (n + 1) + i) * (size_t)(m + 1);
+  for (int j = lane; j <= m; j += 64) {
+    const float zz = (i < n && j < m) ? zr[j] : dust;
+    pr[j] = expf((zz + ui) + vb[j]);                         // sinkhorn.py:145,206
+  }
+}
+
+}  // namespace
+
+extern "C" int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, float dustbin_logscore,
+                           int iterations, float *u, float *v, float *p, mi_stream_t stream) {
+  if (!z || !u || !v) return MI_E_NULL;
+  if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
+  if (pitch < m || pitch % 4 != 0 || ((uintptr_t)z % 16) != 0) return MI_E_ALIGN;
+  if (iterations <= 0) return MI_E_PARAM;
+  hipStream_t s = (hipStream_t)stream;
+  const float log_m = logf((float)m), log_n = logf((float)n);      // sinkhorn.py:197-198
+  const dim3 rgrid(ceil_div(n + 1, 4 * ROWS_PER_WAVE), batch);
+  const int e4 = ceil_div(m, 256);
+  // widest column vector that divides m (so a lane never straddles the matrix edge)
+  const int vec = (m % 4 == 0) ? 4 : ((m % 2 == 0) ? 2 : 1);
+  const dim3 cgrid(ceil_div(m, 64 * vec) + 1, batch);
+  for (int it = 0; it < iterations; ++it) {
+    const int vz = (it == 0) ? 1 : 0;
+    switch (e4) {
+      case 1: hipLaunchKernelGGL(sk_row_kernel<1>, rgrid, dim3(256), 0, s, z, n, m, pitch, dustbin_logscore, v, u, log_m, vz); break;
+      case 2: hipLaunchKernelGGL(sk_row_kernel<2>, rgrid, dim3(256), 0, s, z, n, m, pitch, dustbin_logscore, v, u, log_m, vz); break;
+      case 3: case 4: hipLaunchKernelGGL(sk_row_kernel<4>, rgrid, dim3(256), 0, s, z, n, m, pitch, dustbin_logscore, v, u, log_m, vz); break;
+      default: hipLaunchKernelGGL(sk_row_generic_kernel, rgrid, dim3(256), 0, s, z, n, m, pitch, dustbin_logscore, v, u, log_m, vz); break;
+    }
+    if (vec == 4) hipLaunchKernelGGL(sk_col_kernel<4>, cgrid, dim3(256), 0, s, z, n, m, pitch, dustbin_logscore, u, v, log_n);
+    else if (vec == 2) hipLaunchKernelGGL(sk_col_kernel<2>, cgrid, dim3(256), 0, s, z, n, m, pitch, dustbin_logscore, u, v, log_n);
+    else hipLaunchKernelGGL(sk_col_kernel<1>, cgrid, dim3(256), 0, s, z, n, m, pitch, dustbin_logscore, u, v, log_n);
+  }
+  if (p) {
+    hipLaunchKernelGGL(sk_exp_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, z, n, m, pitch,
+                       dustbin_logscore, u, v, p);
+  }
+  return mi_launch_status();
+}

@@ -1,0 +1,161 @@
+"""Functional layer over the C ABI: shape checks, output/workspace allocation, launch.
+
+Everything here is asynchronous on torch's current HIP stream.  Outputs are fresh torch
+tensors on the input's device (the reference's ownership convention); workspaces come from
+torch's caching allocator, so a steady-state step performs no hipMalloc.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native as N
+
+F32 = torch.float32
+
+
+def _images(image: torch.Tensor, what: str) -> torch.Tensor:
+    if image.dim() != 4 or image.shape[1] != 1:
+        raise RuntimeError(f"{what} must have shape (N, 1, H, W), got {tuple(image.shape)}")
+    return image.float().contiguous()
+
+
+def corner_response(image: torch.Tensor, block_size: int) -> torch.Tensor:
+    img = _images(image, "image")
+    n, _, h, w = img.shape
+    out = torch.empty_like(img)
+    N.call("mi_corner_response", N.dev(img, F32, "image"), n, h, w, int(block_size), N.dev(out, F32, "score"),
+           N.stream_ptr())
+    return out
+
+
+def _score_maps(scores: torch.Tensor) -> torch.Tensor:
+    if scores.dim() != 3:
+        raise RuntimeError(f"scores must have shape (B, H, W), got {tuple(scores.shape)}")
+    return scores.float().contiguous()
+
+
+def nms_mask(scores: torch.Tensor, radius: int) -> torch.Tensor:
+    s = _score_maps(scores)
+    b, h, w = s.shape
+    mask = torch.empty_like(s)
+    N.call("mi_nms_mask", N.dev(s, F32, "scores"), b, h, w, int(radius), N.dev(mask, F32, "mask"), N.stream_ptr())
+    return mask
+
+
+def _topk_from_candidates(cand, count, capacity, b, h, w, k):
+    if h * w < k:
+        raise RuntimeError(f"selected index k out of range (k={k} > H*W={h * w})")  # torch.topk's failure mode
+    kpts = torch.empty((b, k, 2), dtype=F32, device=cand.device)
+    ksc = torch.empty((b, k), dtype=F32, device=cand.device)
+    N.call("mi_topk_keypoints", cand.data_ptr(), count.data_ptr(), capacity, b, w, int(k), kpts.data_ptr(),
+           ksc.data_ptr(), N.stream_ptr())
+    return kpts, ksc
+
+
+def nms_topk(scores: torch.Tensor, radius: int, k: int, score_threshold: float = 0.0, border_margin: int = 0):
+    """Fused NMS + border + threshold + top-k (the mask is never materialised)."""
+    s = _score_maps(scores)
+    b, h, w = s.shape
+    capacity = h * w
+    cand = torch.empty((b, capacity), dtype=torch.int64, device=s.device)
+    count = torch.zeros((b,), dtype=torch.int32, device=s.device)
+    N.call("mi_nms_candidates", N.dev(s, F32, "scores"), b, h, w, int(radius), float(score_threshold),
+           int(border_margin), cand.data_ptr(), count.data_ptr(), capacity, N.stream_ptr())
+    return _topk_from_candidates(cand, count, capacity, b, h, w, k)
+
+
+def select_topk(scores: torch.Tensor, mask: torch.Tensor, k: int, score_threshold: float = 0.0,
+                border_margin: int = 0):
+    s = _score_maps(scores)
+    mk = _score_maps(mask)
+    if mk.shape != s.shape:
+        raise RuntimeError(f"nms_mask shape {tuple(mk.shape)} != scores shape {tuple(s.shape)}")
+    b, h, w = s.shape
+    capacity = h * w
+    cand = torch.empty((b, capacity), dtype=torch.int64, device=s.device)
+    count = torch.zeros((b,), dtype=torch.int32, device=s.device)
+    N.call("mi_select_candidates", N.dev(s, F32, "scores"), N.dev(mk, F32, "nms_mask"), b, h, w,
+           float(score_threshold), int(border_margin), cand.data_ptr(), count.data_ptr(), capacity, N.stream_ptr())
+    return _topk_from_candidates(cand, count, capacity, b, h, w, k)
+
+
+def sparse_bad(image: torch.Tensor, keypoints: torch.Tensor, pair_geom: torch.Tensor, pair_thr: torch.Tensor,
+               mode: int, temperature: float, normalize: bool, want_desc: bool = True, want_bits: bool = False):
+    img = _images(image, "image")
+    n, _, h, w = img.shape
+    if keypoints.dim() != 3 or keypoints.shape[0] != n or keypoints.shape[2] != 2:
+        raise RuntimeError(f"keypoints must have shape ({n}, K, 2), got {tuple(keypoints.shape)}")
+    kp = keypoints.float().contiguous()
+    k = kp.shape[1]
+    p = pair_geom.numel()
+    desc = torch.empty((n, k, p), dtype=F32, device=img.device) if want_desc else None
+    bits = torch.empty((n, k, p // 32), dtype=torch.int32, device=img.device) if want_bits else None
+    N.call("mi_sparse_bad", N.dev(img, F32, "image"), n, h, w, N.dev(kp, F32, "keypoints"), k,
+           N.dev(pair_geom, torch.int32, "pair_geom"), N.dev(pair_thr, F32, "pair_thr"), p, int(mode),
+           float(temperature), int(bool(normalize)), desc.data_ptr() if want_desc else None,
+           bits.data_ptr() if want_bits else None, N.stream_ptr())
+    return desc, bits
+
+
+def _pitch(m: int) -> int:
+    return (m + 3) // 4 * 4
+
+
+def cost_logscores_bits(bits1: torch.Tensor, bits2: torch.Tensor, normalized: bool, epsilon: float):
+    b, n, words = bits1.shape
+    m = bits2.shape[1]
+    pitch = _pitch(m)
+    z = torch.empty((b, n, pitch), dtype=F32, device=bits1.device)
+    N.call("mi_cost_logscores_bits", N.dev(bits1, torch.int32, "bits1"), N.dev(bits2, torch.int32, "bits2"), b, n, m,
+           words * 32, int(bool(normalized)), float(epsilon), z.data_ptr(), pitch, N.stream_ptr())
+    return z, pitch
+
+
+def cost_logscores_f32(desc1: torch.Tensor, desc2: torch.Tensor, distance: int, epsilon: float):
+    if desc1.dim() != 3 or desc2.dim() != 3 or desc1.shape[0] != desc2.shape[0] or desc1.shape[2] != desc2.shape[2]:
+        raise RuntimeError(f"descriptor shapes do not match: {tuple(desc1.shape)} vs {tuple(desc2.shape)}")
+    d1 = desc1.float().contiguous()
+    d2 = desc2.float().contiguous()
+    b, n, d = d1.shape
+    m = d2.shape[1]
+    pitch = _pitch(m)
+    z = torch.empty((b, n, pitch), dtype=F32, device=d1.device)
+    N.call("mi_cost_logscores_f32", N.dev(d1, F32, "desc1"), N.dev(d2, F32, "desc2"), b, n, m, d, int(distance),
+           float(epsilon), z.data_ptr(), pitch, N.stream_ptr())
+    return z, pitch
+
+
+def sinkhorn(z: torch.Tensor, m: int, pitch: int, dustbin_logscore: float, iterations: int,
+             return_duals: bool = False):
+    b, n, _ = z.shape
+    u = torch.empty((b, n + 1), dtype=F32, device=z.device)
+    v = torch.empty((b, m + 1), dtype=F32, device=z.device)
+    p = torch.empty((b, n + 1, m + 1), dtype=F32, device=z.device)
+    N.call("mi_sinkhorn", N.dev(z, F32, "z"), b, n, m, pitch, float(dustbin_logscore), int(iterations),
+           u.data_ptr(), v.data_ptr(), p.data_ptr(), N.stream_ptr())
+    return (p, u, v) if return_duals else p
+
+
+def mnn_extract(p: torch.Tensor, kpts1: torch.Tensor, kpts2: torch.Tensor, max_matches: int, threshold: float,
+                return_indices: bool = False):
+    if p.dim() != 3:
+        raise RuntimeError(f"P must have shape (B, N+1, M+1), got {tuple(p.shape)}")
+    pp = p.float().contiguous()
+    k1 = kpts1.float().contiguous()
+    k2 = kpts2.float().contiguous()
+    b, n, m = pp.shape[0], k1.shape[1], k2.shape[1]
+    if pp.shape[1] != n + 1 or pp.shape[2] != m + 1:
+        raise RuntimeError(f"P shape {tuple(pp.shape)} does not match keypoints ({n}, {m})")
+    dev = pp.device
+    row_best = torch.empty((b, n), dtype=torch.int64, device=dev)
+    col_best = torch.empty((b, m), dtype=torch.int64, device=dev)
+    mk1 = torch.empty((b, max_matches, 2), dtype=F32, device=dev)
+    mk2 = torch.empty((b, max_matches, 2), dtype=F32, device=dev)
+    sc = torch.empty((b, max_matches), dtype=F32, device=dev)
+    valid = torch.empty((b, max_matches), dtype=torch.uint8, device=dev)
+    ij = torch.empty((b, max_matches, 2), dtype=torch.int32, device=dev)
+    N.call("mi_mnn_extract", N.dev(pp, F32, "P"), b, n, m, N.dev(k1, F32, "keypoints1"), N.dev(k2, F32, "keypoints2"),
+           int(max_matches), float(threshold), row_best.data_ptr(), col_best.data_ptr(), mk1.data_ptr(),
+           mk2.data_ptr(), sc.data_ptr(), valid.data_ptr(), ij.data_ptr(), N.stream_ptr())
+    out = (mk1, mk2, sc, valid.bool())
+    return out + (ij,) if return_indices else out

@@ -1,0 +1,95 @@
+"""SparseBAD -- mirror of reference pytorch_model/descriptor/bad.py:336-576."""
+import torch
+from torch import nn
+
+from ... import _native as N
+from ... import ops
+from .bad_params import _get_bad_learned_params
+
+
+class SparseBAD(nn.Module):
+    """BAD (Box Average Difference) descriptors at keypoints only.
+
+    forward(image (B,1,H,W), keypoints (B,K,2) as (y,x), orientation=None) -> (B,K,num_pairs)
+    float32.  Constructor arguments, validation and buffer names follow bad.py:374-434.  The
+    K4 kernel evaluates every box from an exact summed-area table of a 34x34 window around the
+    keypoint instead of the reference's dense 8-channel box-mean bank, so `box_kernel_bank` and
+    `radius_select` exist only for state_dict() compatibility.
+    """
+
+    def __init__(
+        self,
+        num_pairs: int = 256,
+        binarize: bool = False,
+        soft_binarize: bool = True,
+        temperature: float = 10.0,
+        normalize_descriptors: bool = True,
+        sampling_mode: str = "nearest",
+    ):
+        super().__init__()
+        if num_pairs not in (256, 512):
+            raise ValueError(f"num_pairs must be 256 or 512 to use learned BAD patterns, got {num_pairs}")
+        if sampling_mode not in ("nearest", "bilinear"):
+            raise ValueError(f"sampling_mode must be 'nearest' or 'bilinear', got {sampling_mode}")
+        self.num_pairs = num_pairs
+        self.binarize = binarize
+        self.soft_binarize = soft_binarize
+        self.temperature = temperature
+        self.normalize_descriptors = normalize_descriptors
+        self.sampling_mode = sampling_mode
+
+        box, thr = _get_bad_learned_params(num_pairs)
+        for name, col in (("offset_x1", 0), ("offset_x2", 1), ("offset_y1", 2), ("offset_y2", 3)):
+            self.register_buffer(name, box[:, col] - 16.0)
+        self.register_buffer("radii", box[:, 4].to(torch.int64))
+        self.register_buffer("thresholds", thr)
+        for name in ("offset_y1", "offset_x1", "offset_y2", "offset_x2", "thresholds"):
+            self.register_buffer(name + "_v", getattr(self, name).view(1, 1, -1))
+        self.max_radius = int(self.radii.max().item())
+        sel = torch.zeros(self.max_radius + 1, num_pairs)
+        sel[self.radii, torch.arange(num_pairs)] = 1.0
+        self.register_buffer("radius_select", sel)
+        r = torch.arange(self.max_radius + 1, dtype=torch.float32).view(-1, 1, 1)
+        c = torch.arange(-self.max_radius, self.max_radius + 1, dtype=torch.float32)
+        inside = ((c.abs().view(1, -1, 1) <= r) & (c.abs().view(1, 1, -1) <= r)).float()
+        self.register_buffer("box_kernel_bank", (inside / (2.0 * r + 1.0) ** 2).unsqueeze(1))
+        # packed geometry consumed by mi_sparse_bad: x1 | x2<<5 | y1<<10 | y2<<15 | r<<20
+        b = box.to(torch.int64)
+        geom = b[:, 0] | (b[:, 1] << 5) | (b[:, 2] << 10) | (b[:, 3] << 15) | (b[:, 4] << 20)
+        self.register_buffer("pair_geom", geom.to(torch.int32), persistent=False)
+        self.register_buffer("pair_thr", thr.clone(), persistent=False)
+
+    @property
+    def mode(self) -> int:
+        if not self.binarize:
+            return N.MI_BAD_RAW
+        return N.MI_BAD_SOFT if self.soft_binarize else N.MI_BAD_HARD
+
+    def _check(self, image: torch.Tensor, orientation):
+        if orientation is not None:
+            raise NotImplementedError("oriented SparseBAD (bad.py:487-517) is not built yet in this round")
+        if self.sampling_mode != "nearest":
+            raise NotImplementedError("sampling_mode='bilinear' is not built yet in this round")
+        if self.pair_geom.device != image.device:
+            raise RuntimeError(
+                f"SparseBAD buffers are on {self.pair_geom.device} but the image is on {image.device}; "
+                "move the module with .to(device)"
+            )
+
+    @torch.no_grad()
+    def forward(self, image: torch.Tensor, keypoints: torch.Tensor, orientation: torch.Tensor | None = None):
+        self._check(image, orientation)
+        desc, _ = ops.sparse_bad(image, keypoints, self.pair_geom, self.pair_thr, self.mode, self.temperature,
+                                 self.normalize_descriptors, want_desc=True, want_bits=False)
+        return desc
+
+    @torch.no_grad()
+    def forward_bits(self, image: torch.Tensor, keypoints: torch.Tensor) -> torch.Tensor:
+        """Hard-binarised descriptors as packed bits (B,K,num_pairs/32) int32 -- the form the
+        bit-exact cost kernel consumes.  Only meaningful for binarize=True, soft_binarize=False."""
+        if self.mode != N.MI_BAD_HARD:
+            raise RuntimeError("forward_bits needs binarize=True, soft_binarize=False")
+        self._check(image, None)
+        _, bits = ops.sparse_bad(image, keypoints, self.pair_geom, self.pair_thr, N.MI_BAD_HARD, self.temperature,
+                                 self.normalize_descriptors, want_desc=False, want_bits=True)
+        return bits

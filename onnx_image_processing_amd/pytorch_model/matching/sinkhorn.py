@@ -1,0 +1,60 @@
+"""SinkhornMatcher -- mirror of reference pytorch_model/matching/sinkhorn.py:28-259."""
+import torch
+from torch import nn
+
+from ... import _native as N
+from ... import ops
+
+
+class SinkhornMatcher(nn.Module):
+    """Log-space Sinkhorn assignment with dustbins.
+
+    forward(desc1 (B,N,D), desc2 (B,M,D)) -> P (B,N+1,M+1) float32.  Arguments and validation
+    follow sinkhorn.py:57-77.  K5 builds the n x m log-score core with MFMA, K6 runs the
+    fixed number of row/column log-sum-exp passes; the constant dustbin row/column is applied
+    analytically rather than stored.
+    """
+
+    def __init__(self, iterations: int = 20, epsilon: float = 1.0, unused_score: float = 1.0,
+                 distance_type: str = "l2") -> None:
+        super().__init__()
+        if iterations <= 0:
+            raise ValueError(f"iterations must be positive, got {iterations}")
+        if epsilon <= 0:
+            raise ValueError(f"epsilon must be positive, got {epsilon}")
+        self.iterations = iterations
+        self.epsilon = epsilon
+        self.unused_score = unused_score
+        self.distance_type = distance_type.lower()
+        if self.distance_type not in ("l1", "l2"):
+            raise ValueError(f"distance_type must be 'l1' or 'l2', got {distance_type}")
+
+    @property
+    def dustbin_logscore(self) -> float:
+        return -self.unused_score / self.epsilon            # sinkhorn.py:182 (Python-float arithmetic)
+
+    @torch.no_grad()
+    def forward(self, desc1: torch.Tensor, desc2: torch.Tensor) -> torch.Tensor:
+        dist = N.MI_DIST_L2 if self.distance_type == "l2" else N.MI_DIST_L1
+        z, pitch = ops.cost_logscores_f32(desc1, desc2, dist, self.epsilon)
+        return ops.sinkhorn(z, desc2.shape[1], pitch, self.dustbin_logscore, self.iterations)
+
+    @torch.no_grad()
+    def forward_bits(self, bits1: torch.Tensor, bits2: torch.Tensor, normalized: bool) -> torch.Tensor:
+        """Same result for hard-binarised descriptors given as packed bits (B,N,D/32) int32:
+        the dot products become exact integer popcounts (i8 MFMA).  L2 only."""
+        if self.distance_type != "l2":
+            raise RuntimeError("forward_bits implements the l2 cost only")
+        z, pitch = ops.cost_logscores_bits(bits1, bits2, normalized, self.epsilon)
+        return ops.sinkhorn(z, bits2.shape[1], pitch, self.dustbin_logscore, self.iterations)
+
+
+class SinkhornMatcherWithScores(SinkhornMatcher):
+    """forward -> (P, scores0 (B,N), scores1 (B,M)): row / column maxima of the core of P
+    (sinkhorn.py:228-259)."""
+
+    @torch.no_grad()
+    def forward(self, desc1: torch.Tensor, desc2: torch.Tensor):
+        p = super().forward(desc1, desc2)
+        core = p[:, : desc1.shape[1], : desc2.shape[1]]
+        return p, core.amax(dim=-1), core.amax(dim=-2)

@@ -1,0 +1,309 @@
+"""GPU parity: the HIP path (through the C ABI, via the nn.Module mirrors) against the oracle
+and against the reference-generated golden fixtures.  Run with `-m gpu` on an MI355X.
+
+Bars (north_star): keypoint indices and BAD bit strings bit-exact; Shi-Tomasi scores bit-exact
+for uint8-valued input / block 3; Sinkhorn P within 1e-4 (relative on the dustbin row/column).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import bad_tables, cfg_of, load_golden, p_close, permute_p, tie_canonical_perm, unpack_bits
+from onnx_image_processing_amd.synth import synth_batch, synth_image
+from oracle import numpy_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def gpu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from onnx_image_processing_amd import _native
+    from onnx_image_processing_amd.pytorch_model.descriptor.bad import SparseBAD
+    from onnx_image_processing_amd.pytorch_model.detector import ShiTomasiScore
+    from onnx_image_processing_amd.pytorch_model.feature_detection import (
+        MatchExtractionWrapper, ShiTomasiSparseBADSinkhornMatcher)
+    from onnx_image_processing_amd.pytorch_model.matching import SinkhornMatcher, SinkhornMatcherWithScores
+    from onnx_image_processing_amd.pytorch_model.matching.match_extraction import MutualNearestNeighborMatcher
+    from onnx_image_processing_amd.pytorch_model.utils import apply_nms_maxpool, select_topk_keypoints
+    from onnx_image_processing_amd.pytorch_model.utils.keypoint_utils import detect_keypoints
+    _native.load()     # fail loudly if the HIP library is missing
+    return dict(locals())
+
+
+# ------------------------------------------------------------------ K1
+@pytest.mark.parametrize("shape,bs", [((2, 480, 640), 3), ((3, 96, 128), 3), ((1, 37, 64), 3), ((2, 61, 83), 3),
+                                      ((1, 8, 8), 3), ((1, 200, 136), 3)])
+def test_corner_bitexact_uint8_bs3(mods, shape, bs):
+    n, h, w = shape
+    img = np.stack([synth_image(500 + i, h, w) for i in range(n)])[:, None].astype(np.float32)
+    got = mods["ShiTomasiScore"](bs)(gpu(img)).cpu().numpy()
+    assert np.array_equal(got, O.shi_tomasi_score(img, bs))
+
+
+def test_corner_c1_golden(mods):
+    g = load_golden("c1_shi_tomasi")
+    img = synth_image(int(g["seed"]))[None, None].astype(np.float32)
+    got = mods["ShiTomasiScore"](3)(gpu(img)).cpu().numpy()
+    ref, root = O.shi_tomasi_score(img, 3, return_sqrt_term=True)
+    assert np.array_equal(got, ref)
+    diff = np.abs(got[0, 0].astype(np.float64) - g["score3"])       # reference run: MKL sqrt is 1 ulp off on <1 %
+    assert np.all(diff <= np.spacing(root[0, 0]) + np.spacing(ref[0, 0])) and (diff > 0).mean() < 0.02
+
+
+@pytest.mark.parametrize("bs,shape", [(5, (2, 96, 128)), (7, (1, 64, 128)), (5, (1, 61, 83)), (9, (1, 40, 52))])
+def test_corner_other_blocks(mods, bs, shape):
+    n, h, w = shape
+    img = np.stack([synth_image(600 + i, h, w) for i in range(n)])[:, None].astype(np.float32)
+    got = mods["ShiTomasiScore"](bs)(gpu(img)).cpu().numpy()
+    ref = O.shi_tomasi_score(img, bs)
+    # sums may exceed 2^24 for bs >= 5: order-dependent rounding, relative to the trace scale
+    assert np.abs(got - ref).max() <= 2e-6 * max(float(ref.max()), 1.0) + 1.0
+
+
+def test_corner_float_image_tolerance(mods):
+    g = load_golden("c1_shi_tomasi")
+    for bs, key in ((3, "float_score3"), (7, "float_score7")):
+        got = mods["ShiTomasiScore"](bs)(gpu(g["float_img"])).cpu().numpy()
+        assert np.abs(got - g[key]).max() <= 4e-6 * float(g[key].max()) + 1.0
+
+
+# ------------------------------------------------------------------ K2 / K3
+def test_nms_mask_golden_and_oracle(mods):
+    g = load_golden("nms_topk")
+    s = g["plateau_scores"]
+    for r in (1, 2, 3, 5):
+        m = mods["apply_nms_maxpool"](gpu(s), r).cpu().numpy()
+        assert np.array_equal(np.packbits(m.astype(bool)), g[f"mask_r{r}"])
+    img = synth_image(77, 200, 264)[None, None].astype(np.float32)
+    sc = O.shi_tomasi_score(img, 3)[:, 0]
+    for r in (0, 3, 5, 9):
+        assert np.array_equal(mods["apply_nms_maxpool"](gpu(sc), r).cpu().numpy(), O.nms_mask(sc, r))
+
+
+def test_topk_golden_tie_free(mods):
+    g = load_golden("nms_topk")
+    s = gpu(g["uniq_scores"])
+    for i in range(4):
+        r, k, thr, margin = g[f"t{i}_args"]
+        mask = mods["apply_nms_maxpool"](s, int(r))
+        kp, sc = mods["select_topk_keypoints"](s, mask, int(k), float(thr), int(margin))
+        kp2, sc2 = mods["detect_keypoints"](s, int(r), int(k), float(thr), int(margin))
+        assert torch.equal(kp, kp2) and torch.equal(sc, sc2)                     # fused == two-call form
+        kp, sc = kp.cpu().numpy(), sc.cpu().numpy()
+        assert np.array_equal(sc, g[f"t{i}_scores"])
+        valid = sc > 0
+        assert np.array_equal(kp[valid], g[f"t{i}_kpts"][valid]) and np.all(kp[~valid] == -1)
+
+
+def test_topk_plateaus_vs_oracle(mods):
+    """Massive exact ties: every pixel of a flat-ish map is a candidate (> 4096 -> radix-select path)."""
+    g = load_golden("nms_topk")
+    s = g["plateau_scores"]
+    big = np.tile(s, (1, 4, 4))[:, :150, :200].copy()                           # 30000 px, 12 distinct values
+    for arr, r, k in ((s, 2, 200), (big, 1, 512), (big, 0, 4096), (big + 1.0, 0, 100)):
+        mask = O.nms_mask(arr, r)
+        kp_ref, sc_ref, _ = O.select_topk_keypoints(arr, mask, k, 0.0, 0)
+        kp, sc = mods["detect_keypoints"](gpu(arr), r, k, 0.0, 0)
+        assert np.array_equal(kp.cpu().numpy(), kp_ref) and np.array_equal(sc.cpu().numpy(), sc_ref)
+
+
+def test_topk_errors_and_empty(mods):
+    s = torch.zeros(1, 16, 16, device=DEV)
+    kp, sc = mods["detect_keypoints"](s, 2, 10, 0.0, 0)
+    assert torch.all(kp == -1) and torch.all(sc == 0)
+    with pytest.raises(RuntimeError):
+        mods["detect_keypoints"](s, 2, 300, 0.0, 0)                              # k > H*W, as torch.topk
+
+
+# ------------------------------------------------------------------ K4
+@pytest.mark.parametrize("num_pairs", [256, 512])
+def test_sparse_bad_modes_vs_oracle(mods, num_pairs):
+    box, thr = bad_tables(num_pairs)
+    a, _ = synth_batch(900, 2, 120, 160)
+    rng = np.random.default_rng(3)
+    kp = np.stack([rng.integers(0, 120, (2, 90)), rng.integers(0, 160, (2, 90))], -1).astype(np.float32)
+    kp[0, 5] = (-1, -1)                                                          # invalid keypoint
+    kp[1, :4] = [(0, 0), (119, 159), (0, 159), (119, 0)]                         # corners: clamped boxes
+    for kw in (dict(binarize=False, normalize_descriptors=False), dict(binarize=False),
+               dict(binarize=True, soft_binarize=True, temperature=4.0),
+               dict(binarize=True, soft_binarize=False), dict(binarize=True, soft_binarize=False, normalize_descriptors=False)):
+        mod = mods["SparseBAD"](num_pairs=num_pairs, **kw).to(DEV)
+        got = mod(gpu(a), gpu(kp)).cpu().numpy()
+        ref, aux = O.sparse_bad(a, kp, box, thr, return_aux=True, **kw)
+        if kw.get("binarize") and not kw.get("soft_binarize", True):
+            assert np.array_equal(got, ref)                                      # bit-exact incl. fp32 normalisation
+            bits = mod.forward_bits(gpu(a), gpu(kp)).cpu().numpy().view(np.uint32)
+            assert np.array_equal(bits, O.pack_bits(aux["bits"]))
+        else:
+            np.testing.assert_allclose(got, ref, rtol=0, atol=3e-5 if kw.get("normalize_descriptors", True) else 2e-4)
+        assert np.all(got[0, 5] == 0)
+
+
+# ------------------------------------------------------------------ K5 / K6
+def test_sinkhorn_unit_golden(mods):
+    g = load_golden("sinkhorn_unit")
+    for i in range(4):
+        kw = cfg_of(g, f"s{i}_cfg")
+        p = mods["SinkhornMatcher"](**kw)(gpu(g["d1"]), gpu(g["d2"])).cpu().numpy()
+        ok, worst = p_close(p, g[f"s{i}_P"], atol=3e-5)
+        assert ok, (i, kw, worst)
+
+
+@pytest.mark.parametrize("n,m,d", [(512, 512, 512), (130, 67, 256), (1, 1, 32), (300, 513, 64), (1024, 1024, 512)])
+def test_sinkhorn_bits_vs_float_vs_oracle(mods, n, m, d):
+    rng = np.random.default_rng(n + m)
+    b1 = rng.random((2, n, d)) < 0.4
+    b2 = rng.random((2, m, d)) < 0.4
+    b2[:, : min(n, m) // 2] = b1[:, : min(n, m) // 2]                            # true matches
+    b1[0, 0] = False                                                             # an all-zero (invalid) descriptor
+    for normalized, eps, unused in ((True, 0.05, 1.0), (False, 16.0, 60.0)):
+        def desc(bits):
+            f = bits.astype(np.float32)
+            if normalized:
+                nrm = np.sqrt(f.sum(-1, keepdims=True, dtype=np.float32))
+                f = f / np.maximum(nrm, np.float32(1e-12))
+            return f
+        d1, d2 = desc(b1), desc(b2)
+        ref = O.sinkhorn_match(d1.astype(np.float64), d2.astype(np.float64), 20, eps, unused, dtype=np.float64)
+        mt = mods["SinkhornMatcher"](iterations=20, epsilon=eps, unused_score=unused)
+        pb = mt.forward_bits(gpu(O.pack_bits(b1).view(np.int32)), gpu(O.pack_bits(b2).view(np.int32)), normalized)
+        pf = mt(gpu(d1), gpu(d2))
+        for name, p in (("bits", pb), ("f32", pf)):
+            ok, worst = p_close(p.cpu().numpy(), ref)
+            assert ok, (name, normalized, worst)
+
+
+def test_sinkhorn_with_scores(mods):
+    g = load_golden("sinkhorn_unit")
+    p, s0, s1 = mods["SinkhornMatcherWithScores"](iterations=5, epsilon=0.1, unused_score=0.7)(gpu(g["d1"]), gpu(g["d2"]))
+    assert torch.equal(s0, p[:, :40, :56].amax(-1)) and torch.equal(s1, p[:, :40, :56].amax(-2))
+
+
+# ------------------------------------------------------------------ K7
+def test_mnn_vs_oracle(mods):
+    rng = np.random.default_rng(5)
+    for n, m, mx, thr in ((512, 512, 100, 0.1), (40, 56, 100, 0.01), (300, 77, 64, 0.0)):
+        p = rng.random((2, n + 1, m + 1)).astype(np.float32) ** 8
+        p[0, 3] = p[0, 4]                                                         # duplicate rows -> argmax ties
+        k1 = rng.integers(0, 400, (2, n, 2)).astype(np.float32)
+        k2 = rng.integers(0, 400, (2, m, 2)).astype(np.float32)
+        ref = O.mnn_extract(p, k1, k2, mx, thr)
+        got = mods["MutualNearestNeighborMatcher"](mx, thr)(gpu(p), gpu(k1), gpu(k2))
+        for a, b in zip(got, ref[:4]):
+            assert np.array_equal(a.cpu().numpy(), b)
+
+
+# ------------------------------------------------------------------ composite
+def _images(g):
+    a, b = synth_batch(int(g["seed"]), 1, int(g["h"]), int(g["w"]), noise=int(g["noise"]))
+    if int(g["blank"][0]) >= 0:
+        y0, y1, x0, x1 = [int(v) for v in g["blank"]]
+        b[:, :, y0:y1, x0:x1] = 77.0
+    return a, b
+
+
+PIPELINES = ["c2_pair_480x640_k512", "c2_pair_noise_seed1001", "small_default_120x160_k64",
+             "small_hamming_96x128_k48", "small_soft_l1_96x128_k32", "ragged_120x160_k96"]
+
+
+@pytest.mark.parametrize("name", PIPELINES)
+def test_pipeline_vs_oracle_and_golden(mods, name):
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    a, b = _images(g)
+    model = mods["ShiTomasiSparseBADSinkhornMatcher"](max_keypoints=int(g["k"]), **cfg).to(DEV)
+    k1, k2, p = [t.cpu().numpy() for t in model(gpu(a), gpu(b))]
+    # --- vs the oracle on the same inputs: keypoints bit-exact, P within tolerance
+    box, thr = bad_tables(cfg.get("num_pairs", 256))
+    kw = {k: v for k, v in cfg.items() if k not in ("num_pairs", "sampling_mode")}
+    o1, o2, op, aux = O.match_pair(a, b, box, thr, int(g["k"]), return_aux=True, **kw)
+    assert np.array_equal(k1, o1) and np.array_equal(k2, o2)
+    ok, worst = p_close(p, op)
+    assert ok, f"P vs oracle: worst ratio {worst:.3g}"
+    # --- vs the reference's own output (tie groups canonicalised)
+    w = int(g["w"])
+    perms = [tie_canonical_perm(g["kpts" + t][0], g["kscores" + t][0], w) for t in "12"]
+    assert np.array_equal(k1[0], g["kpts1"][0][perms[0]]) and np.array_equal(k2[0], g["kpts2"][0][perms[1]])
+    if "P" in g.files:
+        ok, worst = p_close(p[0], permute_p(g["P"][0], perms[0], perms[1]))
+        assert ok, f"P vs reference: worst ratio {worst:.3g}"
+    if "mk1" in g.files:
+        mcfg = cfg_of(g, "mnn_cfg")
+        wrap = mods["MatchExtractionWrapper"](model, max_matches=mcfg["max_matches"], match_threshold=mcfg["threshold"])
+        mk1, mk2, sc, valid = [t.cpu().numpy() for t in wrap(gpu(a), gpu(b))]
+        assert np.array_equal(valid, g["mvalid"])
+        gm = {(tuple(x), tuple(y)) for x, y, v in zip(g["mk1"][0], g["mk2"][0], g["mvalid"][0]) if v}
+        hm = {(tuple(x), tuple(y)) for x, y, v in zip(mk1[0], mk2[0], valid[0]) if v}
+        assert gm == hm                                                           # match-set parity
+
+
+def test_pipeline_bits_bitexact_full_size(mods):
+    """BAD bit strings of the north-star pair: bit-exact vs the oracle, and vs the reference except
+    where the reference's own fp32 box means put a response within 5e-4 of its threshold."""
+    g = load_golden("c2_pair_480x640_k512")
+    cfg = cfg_of(g)
+    a, b = _images(g)
+    model = mods["ShiTomasiSparseBADSinkhornMatcher"](max_keypoints=512, **cfg).to(DEV)
+    box, thr = bad_tables(512)
+    for tag, im in (("1", a), ("2", b)):
+        s = model.corner_detector(gpu(im)).squeeze(1)
+        kp, _ = mods["detect_keypoints"](s, 5, 512, 0.0, 7)
+        bits = model.descriptor.forward_bits(gpu(im), kp).cpu().numpy().view(np.uint32)
+        _, aux = O.sparse_bad(im, kp.cpu().numpy(), box, thr, binarize=True, soft_binarize=False, return_aux=True)
+        assert np.array_equal(bits, O.pack_bits(aux["bits"]))
+        perm = tie_canonical_perm(g["kpts" + tag][0], g["kscores" + tag][0], 640)
+        diff = np.argwhere(unpack_bits(g["bits" + tag][0][perm], 512) != unpack_bits(bits[0], 512))
+        assert len(diff) <= 4
+        for kk, pp in diff:
+            assert abs(aux["centered"][0, kk, pp]) < 5e-4
+
+
+def test_batch_consistency_and_determinism(mods):
+    """A batch equals its pairs run one by one; two runs are bit-identical (atomics only decide
+    the append order of candidates, never the result)."""
+    a, b = synth_batch(3000, 3, 120, 160)
+    cfg = dict(num_pairs=512, binarize=True, soft_binarize=False, epsilon=0.05, nms_radius=5)
+    model = mods["ShiTomasiSparseBADSinkhornMatcher"](max_keypoints=128, **cfg).to(DEV)
+    out1 = model(gpu(a), gpu(b))
+    out2 = model(gpu(a), gpu(b))
+    for x, y in zip(out1, out2):
+        assert torch.equal(x, y)
+    for i in range(3):
+        single = model(gpu(a[i:i + 1]), gpu(b[i:i + 1]))
+        for x, y in zip(out1, single):
+            assert torch.equal(x[i:i + 1], y)
+
+
+def test_full_size_batch_properties(mods):
+    """BASELINE full size (640x480, K=512), batch of 8: size-independent properties of the output."""
+    a, b = synth_batch(4000, 8, 480, 640)
+    model = mods["ShiTomasiSparseBADSinkhornMatcher"](
+        max_keypoints=512, num_pairs=512, binarize=True, soft_binarize=False, epsilon=0.05, nms_radius=5).to(DEV)
+    k1, k2, p = model(gpu(a), gpu(b))
+    assert p.shape == (8, 513, 513) and torch.isfinite(p).all()
+    # after the final column normalisation column sums are exact marginals; row sums nearly
+    np.testing.assert_allclose(p[:, :, :512].sum(1).cpu().numpy(), 1.0, atol=2e-4)
+    np.testing.assert_allclose(p[:, :, 512].sum(1).cpu().numpy(), 512.0, rtol=2e-4)
+    # 20 iterations at epsilon 0.05 have not converged: row sums are only close to 1 (reference too)
+    np.testing.assert_allclose(p[:, :512].sum(2).cpu().numpy(), 1.0, atol=0.15)
+    # keypoints: inside the border, sorted by score, distinct
+    kk = k1.cpu().numpy()
+    assert kk[..., 0].min() >= 7 and kk[..., 0].max() < 473 and kk[..., 1].min() >= 7 and kk[..., 1].max() < 633
+    for i in range(8):
+        assert len({tuple(x) for x in kk[i]}) == 512
+    # image 2 is image 1 shifted by (3,5): mutual matches must recover that shift
+    mk1, mk2, sc, valid = mods["MutualNearestNeighborMatcher"](100, 0.1)(p, k1, k2)
+    d = (mk2 - mk1)[valid]
+    frac = ((d[:, 0] == 3) & (d[:, 1] == 5)).float().mean().item()
+    assert valid.float().mean().item() > 0.9 and frac > 0.95
+
+
+def test_cpu_tensor_is_refused(mods):
+    with pytest.raises(RuntimeError):
+        mods["ShiTomasiScore"](3)(torch.zeros(1, 1, 16, 16))
