@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: image-pairs/sec (640x480, K=512) -- BASELINE.json's metric.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs-per-gpu B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the whole path (Shi-Tomasi -> NMS/top-k -> sparse BAD -> cost ->
+Sinkhorn -> mutual-NN match extraction) over a batch of B synthetic pairs per GPU that is
+already resident in HBM, followed (N > 1) by the RCCL gather of the match records to rank 0.
+Configuration = BASELINE.json configs[1] hyper-parameters (the export-CLI values, SURVEY.md
+§2.2) with K=512; pairs are independent, so ranks hold different pairs (weak scaling).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+H, W, K, NUM_PAIRS = 480, 640, 512, 512
+CFG = dict(block_size=3, num_pairs=NUM_PAIRS, binarize=True, soft_binarize=False, sinkhorn_iterations=20,
+           epsilon=0.05, unused_score=1.0, distance_type="l2", nms_radius=5, score_threshold=0.0,
+           normalize_descriptors=True, sampling_mode="nearest")
+MNN = dict(max_matches=100, threshold=0.1)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def cpu_baseline(pairs: int) -> dict:
+    """The oracle (numpy port of the reference algorithm) on this host's cores, same workload."""
+    from oracle import numpy_oracle as O
+    from onnx_image_processing_amd.synth import synth_batch
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    t = np.load(os.path.join(ROOT, "onnx_image_processing_amd", "data", "bad_tables.npz"))
+    kw = {k: v for k, v in CFG.items() if k not in ("num_pairs", "sampling_mode")}
+    a, b = synth_batch(1000, pairs, H, W)
+    O.match_pair(a[:1], b[:1], t["box_512"], t["thr_512"], K, **kw)          # warm-up
+    t0 = time.perf_counter()
+    for i in range(pairs):
+        k1, k2, p = O.match_pair(a[i:i + 1], b[i:i + 1], t["box_512"], t["thr_512"], K, **kw)
+        O.mnn_extract(p, k1, k2, **MNN)
+    dt = time.perf_counter() - t0
+    return {"value": pairs / dt, "unit": "image-pairs/sec", "cores": int(threads), "kind": "port",
+            "sample": f"{pairs} pairs 640x480 K=512 (seeds 1000..{999 + pairs}), oracle/numpy_oracle.py, one pair "
+                      f"at a time; BLAS matmul uses {threads} threads, the rest is single-threaded numpy"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs-per-gpu", type=int, default=256)
+    ap.add_argument("--cpu-pairs", type=int, default=24, help="oracle sample size for cpu_baseline (0 = skip)")
+    args = ap.parse_args()
+
+    from onnx_image_processing_amd import _native, distributed as D
+    from onnx_image_processing_amd.pytorch_model.feature_detection import ShiTomasiSparseBADSinkhornMatcher
+    from onnx_image_processing_amd.pytorch_model.matching.match_extraction import MutualNearestNeighborMatcher
+    from onnx_image_processing_amd.synth import synth_batch
+
+    rank, world, local = D.init()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    _native.load()
+
+    B = args.pairs_per_gpu
+    begin, _ = D.shard_range(B * world, rank, world)            # this rank's pairs in the global order
+    a, b = synth_batch(1000 + begin, B, H, W)
+    img1, img2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)   # resident in HBM before timing
+    del a, b
+    model = ShiTomasiSparseBADSinkhornMatcher(max_keypoints=K, **CFG).to(dev)
+    extract = MutualNearestNeighborMatcher(**MNN)
+
+    def step():
+        k1, k2, p = model(img1, img2)
+        rec = D.pack_records(*extract(p, k1, k2))
+        return D.gather_records(rec, dst=0)
+
+    for _ in range(args.warmup):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _native.enable_timing(True)                                  # HIP events around every C-ABI call
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed_ms = (time.perf_counter() - t0) * 1e3
+    per_call = _native.timings_ms()
+    _native.enable_timing(False)
+    elapsed_ms = D.barrier_max_ms(elapsed_ms, dev)
+
+    if rank == 0:
+        ms_per_step = elapsed_ms / args.steps
+        pairs_per_step = B * world
+        kernels = {k: {"ms_per_step": float(np.sum(v)) / args.steps, "calls_per_step": len(v) / args.steps}
+                   for k, v in per_call.items()}
+        # K1 corner response: 8 algorithmic bytes per pixel (4 read + 4 written), one launch covers
+        # both images of every pair of this rank
+        k1_bytes = 8.0 * 2 * B * H * W
+        k1_ms = float(np.mean(per_call["mi_corner_response"]))
+        achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
+        nvalid = float(out[..., 5].sum().item()) / pairs_per_step
+        line = {
+            "metric": "image-pairs/sec (640x480, K=512)",
+            "value": pairs_per_step / (ms_per_step * 1e-3),
+            "unit": "image-pairs/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "Shi-Tomasi(3) + NMS(r=5)/top-k + sparse BAD(512, hard) + Sinkhorn(20, eps 0.05) "
+                                   "+ MNN(100, 0.1), 640x480 gray pairs, K=512 (BASELINE configs[1])",
+                       "pairs_per_gpu_per_step": B, "global_pairs_per_step": pairs_per_step,
+                       "height": H, "width": W, "max_keypoints": K, "parallelism": f"pair-sharded x{world}",
+                       "mean_valid_matches_per_pair": nvalid},
+            "roofline": {"kernel": "corner_tile_kernel<3,8> (mi_corner_response)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "bytes_per_launch": k1_bytes, "ms_per_launch": k1_ms},
+            "kernels": kernels,
+        }
+        if world == 1 and args.cpu_pairs > 0:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -81,5 +81,30 @@ def dev(t: torch.Tensor, dtype: torch.dtype, what: str) -> int:
     return t.data_ptr()
 
 
+_timers: dict | None = None
+
+
+def enable_timing(on: bool) -> None:
+    """Bracket every C-ABI call with HIP events on the launch stream (bench.py's per-kernel
+    clock).  Off by default: no events, no overhead."""
+    global _timers
+    _timers = {} if on else None
+
+
+def timings_ms() -> dict:
+    """name -> list of elapsed milliseconds, one per call (synchronises)."""
+    torch.cuda.synchronize()
+    return {k: [s.elapsed_time(e) for s, e in v] for k, v in (_timers or {}).items()}
+
+
 def call(name: str, *args) -> None:
-    check(getattr(load(), name)(*args), name)
+    fn = getattr(load(), name)
+    if _timers is None:
+        check(fn(*args), name)
+        return
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()                     # torch's current stream == the stream passed to the ABI
+    rc = fn(*args)
+    end.record()
+    check(rc, name)
+    _timers.setdefault(name, []).append((start, end))
