@@ -115,9 +115,9 @@ def main() -> None:
         pairs_per_step = B * world
         kernels = {k: {"ms_per_step": float(np.sum(v)) / args.steps, "calls_per_step": len(v) / args.steps}
                    for k, v in per_call.items()}
-        # K1 corner response: 8 algorithmic bytes per pixel (4 read + 4 written), one launch covers
-        # both images of every pair of this rank
-        k1_bytes = 8.0 * 2 * B * H * W
+        # K1 corner response: 8 algorithmic bytes per pixel (4 read + 4 written); one launch covers
+        # one image of every pair of this rank, two launches per step
+        k1_bytes = 8.0 * B * H * W
         k1_ms = float(np.mean(per_call["mi_corner_response"]))
         achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
         nvalid = float(out[..., 5].sum().item()) / pairs_per_step

@@ -18,6 +18,7 @@
 #ifndef MI355X_MATCH_H
 #define MI355X_MATCH_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -104,9 +105,15 @@ int mi_cost_logscores_f32(const float *desc1, const float *desc2, int batch, int
 /* ---- matching/sinkhorn.py:112-147,187-206  log-space Sinkhorn with dustbins ------------------
  * z: core log-scores as above.  dustbin_logscore = fp32(-unused_score/epsilon).  u (batch*(n+1))
  * and v (batch*(m+1)) are workspace and return the final duals.  p (batch, n+1, m+1) dense =
- * exp(Z + u + v) over the augmented matrix; may be NULL (duals only).  iterations >= 1. */
+ * exp(Z + u + v) over the augmented matrix; may be NULL (duals only).  iterations >= 1.
+ * workspace: mi_sinkhorn_workspace_bytes(batch, n, m) bytes, 8-byte aligned, enables the fused
+ * iteration that reads Z once per iteration (per-band column partials); with workspace == NULL
+ * (or m > 1024, for which the query returns 0) the two-pass form runs -- same results up to
+ * fp32 summation order. */
+size_t mi_sinkhorn_workspace_bytes(int batch, int n, int m);
 int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, float dustbin_logscore,
-                int iterations, float *u, float *v, float *p, mi_stream_t stream);
+                int iterations, float *u, float *v, float *p, void *workspace, size_t workspace_bytes,
+                mi_stream_t stream);
 
 /* ---- matching/match_extraction.py:72-181  MutualNearestNeighborMatcher.forward --------------
  * p (batch, n+1, m+1); kpts1 (batch,n,2); kpts2 (batch,m,2).  Workspace: row_best (batch*n) u64,

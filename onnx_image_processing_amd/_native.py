@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_uint32, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_uint32, c_void_p
 
 import torch
 
@@ -28,11 +28,13 @@ SIGNATURES = {
                       c_void_p, c_void_p, c_void_p],
     "mi_cost_logscores_bits": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p],
     "mi_cost_logscores_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p],
-    "mi_sinkhorn": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mi_sinkhorn_workspace_bytes": [c_int, c_int, c_int],
+    "mi_sinkhorn": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                    c_size_t, c_void_p],
     "mi_mnn_extract": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
 }
-_RESTYPE = {"mi_error_string": c_char_p}
+_RESTYPE = {"mi_error_string": c_char_p, "mi_sinkhorn_workspace_bytes": c_size_t}
 
 MI_BAD_RAW, MI_BAD_SOFT, MI_BAD_HARD = 0, 1, 2
 MI_DIST_L2, MI_DIST_L1 = 0, 1

@@ -54,41 +54,54 @@ __global__ __launch_bounds__(64) void sparse_bad_kernel(const float *__restrict_
   const float kx = fminf(fmaxf(kx_raw, 0.0f), (float)(w - 1));
   const int oy = (int)floorf(ky) - WOFF, ox = (int)floorf(kx) - WOFF;
 
-  // ---- stage the replicate-extended window as doubles at sat[r+1][c+1]
+  // ---- summed-area table of the replicate-extended window, sat[r+1][c+1] = sum of rows<=r, cols<=c
+  // Lane c < 34 owns window column c: its 34 row loads are all issued before any use (34 loads in
+  // flight per lane, each wave-instruction one 136-byte row segment), the column prefix runs in
+  // registers, then lane r < 34 takes row r for the horizontal prefix (stride 35 doubles between
+  // lanes: conflict-free for ds_read_b64).
+  const int groups = num_pairs / 64;
+  uint32_t qg[8];
+  float tg[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    qg[g] = (g < groups) ? geom[g * 64 + lane] : 0u;
+    tg[g] = (g < groups) ? thr[g * 64 + lane] : 0.0f;
+  }
   for (int i = lane; i < SP; i += 64) { sat[i] = 0.0; sat[i * SP] = 0.0; }
-  for (int i = lane; i < WIN * WIN; i += 64) {
-    const int r = i / WIN, c = i - r * WIN;
-    const int gy = clampi(oy + r, 0, h - 1), gx = clampi(ox + c, 0, w - 1);
-    sat[(r + 1) * SP + (c + 1)] = (double)im[(size_t)gy * w + gx];
+  if (lane < WIN) {
+    const int gx = clampi(ox + lane, 0, w - 1);
+    float px[WIN];
+#pragma unroll
+    for (int r = 0; r < WIN; ++r) px[r] = im[(size_t)clampi(oy + r, 0, h - 1) * w + gx];
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < WIN; ++r) {
+      acc += (double)px[r];
+      sat[(r + 1) * SP + (lane + 1)] = acc;
+    }
   }
   __syncthreads();
-  // ---- inclusive prefix along rows (lane = row), then along columns (lane = column)
   if (lane < WIN) {
     double *row = sat + (lane + 1) * SP + 1;
+    double v[WIN];
+#pragma unroll
+    for (int c = 0; c < WIN; ++c) v[c] = row[c];
     double acc = 0.0;
 #pragma unroll
-    for (int c = 0; c < WIN; ++c) { acc += row[c]; row[c] = acc; }
-  }
-  __syncthreads();
-  if (lane < WIN) {
-    double *col = sat + SP + (lane + 1);
-    double acc = 0.0;
-#pragma unroll
-    for (int r = 0; r < WIN; ++r) { acc += col[r * SP]; col[r * SP] = acc; }
+    for (int c = 0; c < WIN; ++c) { acc += v[c]; row[c] = acc; }
   }
   __syncthreads();
 
   const size_t drow = ((size_t)img * k + kp) * (size_t)num_pairs;
   const int words = num_pairs / 32;
   uint32_t *brow = bits ? bits + ((size_t)img * k + kp) * words : nullptr;
-  const int groups = num_pairs / 64;
   int pop = 0;
   float sumsq = 0.0f;
 
-#pragma unroll 1
-  for (int g = 0; g < groups; ++g) {
+  // one group = 64 pairs (one per lane).  Geometry/threshold words of the first 8 groups were
+  // fetched before the SAT was built (their latency hides behind it).
+  auto eval_group = [&](int g, uint32_t q, float thr_p) {
     const int p = g * 64 + lane;
-    const uint32_t q = geom[p];
     const int x1 = (int)(q & 31u) - 16, x2 = (int)((q >> 5) & 31u) - 16;
     const int y1 = (int)((q >> 10) & 31u) - 16, y2 = (int)((q >> 15) & 31u) - 16;
     const int r = (int)((q >> 20) & 15u);
@@ -105,7 +118,7 @@ __global__ __launch_bounds__(64) void sparse_bad_kernel(const float *__restrict_
     const double s1 = (sat[b1 * SP + r1] - sat[a1 * SP + r1]) - (sat[b1 * SP + l1] - sat[a1 * SP + l1]);
     const double s2 = (sat[b2 * SP + r2] - sat[a2 * SP + r2]) - (sat[b2 * SP + l2] - sat[a2 * SP + l2]);
     const double area = (double)((2 * r + 1) * (2 * r + 1));
-    const double t = (double)thr[p];
+    const double t = (double)thr_p;
     if (mode == MI_BAD_HARD) {
       // bit = (mean1 - mean2 - t <= 0)  <=>  s1 - s2 <= t * area   (t*area exact in fp64)
       const bool bit = valid && ((s1 - s2) <= t * area);                // bad.py:567,570
@@ -115,7 +128,7 @@ __global__ __launch_bounds__(64) void sparse_bad_kernel(const float *__restrict_
         brow[2 * g] = (uint32_t)word;
         brow[2 * g + 1] = (uint32_t)(word >> 32);
       }
-      vals[p] = bit ? 1.0f : 0.0f;
+      if (desc) vals[p] = bit ? 1.0f : 0.0f;
     } else {
       const float c = (float)((s1 - s2) / area - t);                    // bad.py:559
       float v = c;
@@ -124,7 +137,12 @@ __global__ __launch_bounds__(64) void sparse_bad_kernel(const float *__restrict_
       sumsq += v * v;
       vals[p] = v;
     }
-  }
+  };
+#pragma unroll
+  for (int g = 0; g < 8; ++g)
+    if (g < groups) eval_group(g, qg[g], tg[g]);
+#pragma unroll 1
+  for (int g = 8; g < groups; ++g) eval_group(g, geom[g * 64 + lane], thr[g * 64 + lane]);
 
   if (!desc) return;
   float inv = 1.0f;

@@ -50,22 +50,36 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(const float *__restric
   const float *im = image + (size_t)img * h * w;
 
   // ---- stage the clamped tile: every float4 chunk is wholly inside or wholly outside (w % 4 == 0)
-  for (int i = t; i < LH * LW4; i += 256) {
-    const int r = i / LW4, c = i - r * LW4;
-    const int gy = clampi(y0 - HL + r, 0, h - 1);
-    const int gx = x0 - LPAD + 4 * c;
-    const float *row = im + (size_t)gy * w;
-    float4 v;
-    if (gx < 0) {
-      const float e = row[0];
-      v = make_float4(e, e, e, e);
-    } else if (gx >= w) {
-      const float e = row[w - 1];
-      v = make_float4(e, e, e, e);
-    } else {
-      v = *reinterpret_cast<const float4 *>(row + gx);
+  // All of a thread's 16-byte loads are issued before the first LDS store, so ~10 loads per lane
+  // are in flight instead of one dependent HBM round trip per chunk.
+  {
+    constexpr int NCH = (LH * LW4 + 255) / 256;
+    float4 v[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int i = t + q * 256;
+      const int r = i / LW4, c = i - r * LW4;
+      const int gy = clampi(y0 - HL + r, 0, h - 1);
+      const int gx = x0 - LPAD + 4 * c;
+      const float *row = im + (size_t)gy * w;
+      v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < LH * LW4) {
+        if (gx < 0) {
+          const float e = row[0];
+          v[q] = make_float4(e, e, e, e);
+        } else if (gx >= w) {
+          const float e = row[w - 1];
+          v[q] = make_float4(e, e, e, e);
+        } else {
+          v[q] = *reinterpret_cast<const float4 *>(row + gx);
+        }
+      }
     }
-    tile[r][c] = v;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int i = t + q * 256;
+      if (i < LH * LW4) (&tile[0][0])[i] = v[q];
+    }
   }
   __syncthreads();
 

@@ -116,6 +116,187 @@ __global__ __launch_bounds__(256) void select_kernel(const float *__restrict__ s
   }
 }
 
+// ---- fast path: w % 4 == 0, radius 1..8 -----------------------------------------------------
+// Same tile (128x32), but every stage moves float4: staging issues all of a thread's 16-byte
+// global loads before the first LDS store (loads in flight, not one dependent round trip per
+// element), the row pass forms 4 adjacent window maxima from 12/20 registers sharing the common
+// core of the four windows, the column pass does the same down 4+2R rows, and survivors of a
+// whole wave (16 pixels per lane) are appended with ONE atomic.
+__device__ __forceinline__ float4 max4(float4 a, float4 b) {
+  return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+
+template <int MODE, int R>
+__global__ __launch_bounds__(256) void nms_fast_kernel(const float *__restrict__ score, int h, int w,
+                                                       int tiles_x, int tiles_y, float *__restrict__ mask,
+                                                       float thr_eff, int margin,
+                                                       uint64_t *__restrict__ cand, uint32_t *__restrict__ count,
+                                                       uint32_t capacity) {
+  constexpr int PC = (R + 3) / 4;              // padding chunks each side
+  constexpr int AW4 = NT_W / 4 + 2 * PC;       // staged row, in float4
+  constexpr int LH = NT_H + 2 * R;             // staged rows
+  constexpr int NCH = (LH * AW4 + 255) / 256;  // staging chunks per thread
+  constexpr int NV = 4 * (1 + 2 * PC);         // floats a thread reads per row in the row pass
+  constexpr int B0 = 4 * PC;                   // index of output column 0 inside those floats
+  __shared__ float4 pa[LH][AW4];               // scores (+halo), -inf outside the image
+  __shared__ float4 pb[LH][NT_W / 4];          // horizontal window maxima
+
+  const int t = threadIdx.x;
+  int bid = blockIdx.x;
+  const int tx_tile = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty_tile = bid % tiles_y;
+  const int img = bid / tiles_y;
+  const int x0 = tx_tile * NT_W, y0 = ty_tile * NT_H;
+  const float *sc = score + (size_t)img * h * w;
+  const float ninf = -INFINITY;
+
+  {
+    float4 v[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int i = t + q * 256;
+      const int rr = i / AW4, cc = i - rr * AW4;
+      const int gy = y0 - R + rr, gx = x0 - 4 * PC + 4 * cc;
+      v[q] = make_float4(ninf, ninf, ninf, ninf);
+      if (i < LH * AW4 && gy >= 0 && gy < h && gx >= 0 && gx < w)
+        v[q] = *reinterpret_cast<const float4 *>(sc + (size_t)gy * w + gx);
+    }
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int i = t + q * 256;
+      if (i < LH * AW4) (&pa[0][0])[i] = v[q];
+    }
+  }
+  __syncthreads();
+
+  // row pass: LH rows x 32 column groups
+#pragma unroll 1
+  for (int i = t; i < LH * (NT_W / 4); i += 256) {
+    const int rr = i >> 5, cg = i & 31;
+    float v[NV];
+#pragma unroll
+    for (int c = 0; c < NV / 4; ++c) {
+      const float4 q = pa[rr][cg + c];
+      v[4 * c] = q.x; v[4 * c + 1] = q.y; v[4 * c + 2] = q.z; v[4 * c + 3] = q.w;
+    }
+    // windows [B0+o-R, B0+o+R], o = 0..3; for R >= 2 they share the core [B0+3-R, B0+R]
+    float o[4];
+    if constexpr (R >= 2) {
+      float core = v[B0 + 3 - R];
+#pragma unroll
+      for (int c = B0 + 4 - R; c <= B0 + R; ++c) core = fmaxf(core, v[c]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float m = core;
+#pragma unroll
+        for (int c = B0 + k - R; c < B0 + 3 - R; ++c) m = fmaxf(m, v[c]);
+#pragma unroll
+        for (int c = B0 + R + 1; c <= B0 + k + R; ++c) m = fmaxf(m, v[c]);
+        o[k] = m;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = fmaxf(fmaxf(v[B0 + k - 1], v[B0 + k]), v[B0 + k + 1]);
+    }
+    pb[rr][cg] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  __syncthreads();
+
+  // column pass: thread = 4 columns x 4 rows
+  const int tx = t & 31, ty = t >> 5;
+  float4 rows[4 + 2 * R];
+#pragma unroll
+  for (int q = 0; q < 4 + 2 * R; ++q) rows[q] = pb[ty * 4 + q][tx];
+  float4 core = rows[3];                       // rows [3, 2R] are common to the 4 windows (R >= 2)
+  if constexpr (R >= 2) {
+#pragma unroll
+    for (int q = 4; q <= 2 * R; ++q) core = max4(core, rows[q]);
+  }
+  const int gx = x0 + 4 * tx;
+  uint32_t nkeep = 0;
+  float kval[16];
+  uint32_t kidx[16];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float4 m;
+    if constexpr (R >= 2) {
+      m = core;
+#pragma unroll
+      for (int q = k; q < 3; ++q) m = max4(m, rows[q]);
+#pragma unroll
+      for (int q = 2 * R + 1; q <= k + 2 * R; ++q) m = max4(m, rows[q]);
+    } else {
+      m = max4(max4(rows[k], rows[k + 1]), rows[k + 2]);
+    }
+    const int ly = ty * 4 + k, gy = y0 + ly;
+    const float4 s = pa[ly + R][tx + PC];
+    const bool in_img = (gx < w) && (gy < h);
+    const float sv[4] = {s.x, s.y, s.z, s.w};
+    const float mv[4] = {m.x, m.y, m.z, m.w};
+    float outv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool is_max = sv[c] >= (mv[c] - 1e-7f);                      // keypoint_utils.py:43
+      outv[c] = is_max ? 1.0f : 0.0f;
+      if (MODE == 1) {
+        const int x = gx + c;
+        const bool in_border = (margin <= 0) || (gy >= margin && gy < h - margin && x >= margin && x < w - margin);
+        const bool keep = in_img && is_max && in_border && (sv[c] > thr_eff);
+        kval[k * 4 + c] = sv[c];
+        kidx[k * 4 + c] = keep ? (uint32_t)(gy * w + x) : 0xFFFFFFFFu;
+        nkeep += keep ? 1u : 0u;
+      }
+    }
+    if (MODE == 0 && in_img)
+      *reinterpret_cast<float4 *>(mask + ((size_t)img * h + gy) * w + gx) = make_float4(outv[0], outv[1], outv[2], outv[3]);
+  }
+  if (MODE == 1) {
+    // wave-level compaction: exclusive prefix of per-lane counts, one atomic per wave
+    const int lane = t & 63;
+    uint32_t incl = nkeep;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    if (total == 0u) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(count + img, total);
+    base = __shfl(base, 0, 64);
+    uint32_t slot = base + incl - nkeep;
+    uint64_t *dst = cand + (size_t)img * capacity;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      if (kidx[q] != 0xFFFFFFFFu) {
+        if (slot < capacity) dst[slot] = ((uint64_t)__float_as_uint(kval[q]) << 32) | (uint64_t)(0xFFFFFFFFu - kidx[q]);
+        ++slot;
+      }
+    }
+  }
+}
+
+template <int MODE>
+bool launch_fast(const float *score, int n, int h, int w, int radius, float *mask, float thr_eff, int margin,
+                 uint64_t *cand, uint32_t *count, uint32_t capacity, hipStream_t s) {
+  if (w % 4 != 0 || radius < 1 || radius > 8 || ((uintptr_t)score % 16) != 0) return false;
+  if (MODE == 0 && ((uintptr_t)mask % 16) != 0) return false;
+  const int tiles_x = ceil_div(w, NT_W), tiles_y = ceil_div(h, NT_H);
+  const dim3 grid((unsigned)(n * tiles_x * tiles_y));
+#define MI_NMS_CASE(RR)                                                                                      \
+  case RR:                                                                                                   \
+    hipLaunchKernelGGL((nms_fast_kernel<MODE, RR>), grid, dim3(256), 0, s, score, h, w, tiles_x, tiles_y,   \
+                       mask, thr_eff, margin, cand, count, capacity);                                        \
+    break;
+  switch (radius) {
+    MI_NMS_CASE(1) MI_NMS_CASE(2) MI_NMS_CASE(3) MI_NMS_CASE(4)
+    MI_NMS_CASE(5) MI_NMS_CASE(6) MI_NMS_CASE(7) MI_NMS_CASE(8)
+  }
+#undef MI_NMS_CASE
+  return true;
+}
+
 template <typename K>
 int allow_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return MI_OK;
@@ -138,6 +319,8 @@ extern "C" int mi_nms_mask(const float *score, int n, int h, int w, int radius, 
   int e = check_common(score, mask, n, h, w);
   if (e) return e;
   if (radius < 0 || radius > 24) return MI_E_PARAM;
+  if (launch_fast<0>(score, n, h, w, radius, mask, 0.f, 0, nullptr, nullptr, 0u, (hipStream_t)stream))
+    return mi_launch_status();
   const int tiles_x = ceil_div(w, NT_W), tiles_y = ceil_div(h, NT_H);
   const size_t lds = ((size_t)(NT_H + 2 * radius) * (NT_W + 2 * radius) + (size_t)(NT_H + 2 * radius) * NT_W) * 4;
   if ((e = allow_lds(nms_kernel<0>, lds)) != MI_OK) return e;
@@ -158,6 +341,9 @@ extern "C" int mi_nms_candidates(const float *score, int n, int h, int w, int ra
   const int tiles_x = ceil_div(w, NT_W), tiles_y = ceil_div(h, NT_H);
   const size_t lds = ((size_t)(NT_H + 2 * radius) * (NT_W + 2 * radius) + (size_t)(NT_H + 2 * radius) * NT_W) * 4;
   const float thr_eff = score_threshold > 0.f ? score_threshold : 0.f;
+  if (launch_fast<1>(score, n, h, w, radius, nullptr, thr_eff, border_margin, cand, count, capacity,
+                     (hipStream_t)stream))
+    return mi_launch_status();
   if ((e = allow_lds(nms_kernel<1>, lds)) != MI_OK) return e;
   hipLaunchKernelGGL(nms_kernel<1>, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), lds,
                      (hipStream_t)stream, score, h, w, radius, tiles_x, tiles_y, nullptr, thr_eff,

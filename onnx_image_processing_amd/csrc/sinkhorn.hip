@@ -224,16 +224,209 @@ __global__ __launch_bounds__(256) void sk_exp_kernel(const float *__restrict__ z
   }
 }
 
+// ---- fused iteration: Z is read ONCE per iteration ----------------------------------------------
+// A workgroup owns a band of 4*RW rows.  Each wave keeps RW whole rows of Z in registers
+// (RW * E4 float4 per lane, all loads issued up front), computes u for them (row pass), and
+// -- with u fresh in registers -- the band's contribution to every column's log-sum-exp:
+// a (max, sum) pair per column, merged over the 4 waves in LDS and written as one float2 per
+// column.  A tiny second kernel merges the bands' partials into v.  Per iteration Z moves
+// 4 B/element once instead of twice; partials are 8 B per column per band (~6 % extra).
+// Band index nb = number of row bands carries the dustbin ROW (x = dust + u_n, computed
+// without Z); column index m of every partial carries the dustbin COLUMN (x = dust + u_i).
+template <int E4, int RW>
+__global__ __launch_bounds__(256) void sk_band_kernel(const float *__restrict__ z, int n, int m, int pitch,
+                                                      float dust, const float *__restrict__ v,
+                                                      float *__restrict__ u, float2 *__restrict__ part,
+                                                      float log_m, int v_is_zero) {
+  constexpr int BAND = 4 * RW;
+  __shared__ float red_m[4][256 * E4 + 1];
+  __shared__ float red_s[4][256 * E4 + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, band = blockIdx.x, nb = gridDim.x - 1;
+  const float *vb = v + (size_t)b * (m + 1);
+  float2 *pb = part + ((size_t)b * (nb + 1) + band) * (size_t)(m + 1);
+  const float vd = v_is_zero ? 0.0f : vb[m];
+
+  if (band == nb) {
+    // dustbin row: u_n = log m - LSE_j(dust + v_j), then its term for every column
+    float mx = dust + vd;
+    for (int j = threadIdx.x; j < m; j += 256) mx = fmaxf(mx, dust + (v_is_zero ? 0.0f : vb[j]));
+    mx = wave_max(mx);
+    if (lane == 0) red_m[wave][0] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_m[0][0], red_m[1][0]), fmaxf(red_m[2][0], red_m[3][0]));
+    float s = 0.0f;
+    for (int j = threadIdx.x; j < m; j += 256) s += expf((dust + (v_is_zero ? 0.0f : vb[j])) - mx);
+    s = wave_sum(s);
+    if (lane == 0) red_s[wave][0] = s;
+    __syncthreads();
+    s = ((red_s[0][0] + red_s[1][0]) + (red_s[2][0] + red_s[3][0])) + expf((dust + vd) - mx);
+    const float un = log_m - (logf(s) + mx);
+    if (threadIdx.x == 0) u[(size_t)b * (n + 1) + n] = un;
+    for (int j = threadIdx.x; j <= m; j += 256) pb[j] = make_float2(dust + un, 1.0f);
+    return;
+  }
+
+  float vv[E4][4];
+#pragma unroll
+  for (int e = 0; e < E4; ++e)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = e * 256 + lane * 4 + q;
+      vv[e][q] = (j < m && !v_is_zero) ? vb[j] : 0.0f;
+    }
+  const float xd = dust + vd;
+  const int row0 = band * BAND + wave * RW;
+
+  float zr[RW][E4][4];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int i = row0 + r;
+    const float *src = z + ((size_t)b * n + (i < n ? i : 0)) * pitch;
+#pragma unroll
+    for (int e = 0; e < E4; ++e) {
+      const int j = e * 256 + lane * 4;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < n && j < m) q = *reinterpret_cast<const float4 *>(src + j);
+      // outside the matrix (row padding, rows past n): -inf, i.e. no contribution anywhere
+      zr[r][e][0] = (i < n && j + 0 < m) ? q.x : -INFINITY;
+      zr[r][e][1] = (i < n && j + 1 < m) ? q.y : -INFINITY;
+      zr[r][e][2] = (i < n && j + 2 < m) ? q.z : -INFINITY;
+      zr[r][e][3] = (i < n && j + 3 < m) ? q.w : -INFINITY;
+    }
+  }
+
+  // row pass (sinkhorn.py:139): u_i = log mu_i - LSE_j(Z_ij + v_j), dustbin column included
+  float ur[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    float mx = xd;
+#pragma unroll
+    for (int e = 0; e < E4; ++e)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mx = fmaxf(mx, zr[r][e][q] + vv[e][q]);
+    mx = wave_max(mx);
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < E4; ++e)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s += expf((zr[r][e][q] + vv[e][q]) - mx);
+    s = wave_sum(s) + expf(xd - mx);
+    ur[r] = 0.0f - (logf(s) + mx);
+    if (lane == 0 && row0 + r < n) u[(size_t)b * (n + 1) + row0 + r] = ur[r];
+  }
+
+  // column partials over this wave's RW rows (sinkhorn.py:141: Z_ij + u_i)
+#pragma unroll
+  for (int e = 0; e < E4; ++e)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float cm = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < RW; ++r) cm = fmaxf(cm, zr[r][e][q] + ur[r]);
+      float cs = 0.0f;
+      if (cm > -INFINITY) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) cs += expf((zr[r][e][q] + ur[r]) - cm);
+      }
+      red_m[wave][e * 256 + lane * 4 + q] = cm;
+      red_s[wave][e * 256 + lane * 4 + q] = cs;
+    }
+  {
+    // dustbin column: x_i = dust + u_i over this wave's valid rows (uniform across lanes)
+    float cm = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+      if (row0 + r < n) cm = fmaxf(cm, dust + ur[r]);
+    float cs = 0.0f;
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+      if (row0 + r < n) cs += expf((dust + ur[r]) - cm);
+    if (lane == 0) { red_m[wave][256 * E4] = cm; red_s[wave][256 * E4] = cs; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c <= 256 * E4; c += 256) {
+    const int j = (c == 256 * E4) ? m : c;
+    if (c < 256 * E4 && j >= m) continue;
+    float fm = fmaxf(fmaxf(red_m[0][c], red_m[1][c]), fmaxf(red_m[2][c], red_m[3][c]));
+    float fs = 0.0f;
+    if (fm > -INFINITY) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (red_m[w][c] > -INFINITY) fs += red_s[w][c] * expf(red_m[w][c] - fm);
+    }
+    pb[j] = make_float2(fm, fs);
+  }
+}
+
+// v_j = log nu_j - LSE over all bands' partials (including the dustbin-row band)
+__global__ __launch_bounds__(256) void sk_vcombine_kernel(const float2 *__restrict__ part, int m, int nparts,
+                                                          float *__restrict__ v, float log_n) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j > m) return;
+  const float2 *p = part + (size_t)b * nparts * (size_t)(m + 1) + j;
+  float mx = -INFINITY;
+  for (int k = 0; k < nparts; ++k) mx = fmaxf(mx, p[(size_t)k * (m + 1)].x);
+  float s = 0.0f;
+  for (int k = 0; k < nparts; ++k) {
+    const float2 q = p[(size_t)k * (m + 1)];
+    if (q.x > -INFINITY) s += q.y * expf(q.x - mx);
+  }
+  v[(size_t)b * (m + 1) + j] = ((j == m) ? log_n : 0.0f) - (logf(s) + mx);
+}
+
+template <int E4, int RW>
+void launch_fused(const float *z, int batch, int n, int m, int pitch, float dust, int iterations, float *u,
+                  float *v, float2 *part, float log_m, float log_n, hipStream_t s) {
+  const int nb = ceil_div(n, 4 * RW);
+  for (int it = 0; it < iterations; ++it) {
+    hipLaunchKernelGGL((sk_band_kernel<E4, RW>), dim3(nb + 1, batch), dim3(256), 0, s, z, n, m, pitch, dust, v,
+                       u, part, log_m, it == 0 ? 1 : 0);
+    hipLaunchKernelGGL(sk_vcombine_kernel, dim3(ceil_div(m + 1, 256), batch), dim3(256), 0, s, part, m, nb + 1,
+                       v, log_n);
+  }
+}
+
+int fused_rows_per_band(int m) {
+  const int e4 = ceil_div(m, 256);
+  if (e4 <= 2) return 32;
+  if (e4 <= 4) return 16;
+  return 0;  // not supported by the fused kernels
+}
+
 }  // namespace
 
+extern "C" size_t mi_sinkhorn_workspace_bytes(int batch, int n, int m) {
+  const int band = fused_rows_per_band(m);
+  if (batch <= 0 || n <= 0 || m <= 0 || band == 0) return 0;
+  return (size_t)batch * (size_t)(ceil_div(n, band) + 1) * (size_t)(m + 1) * sizeof(float2);
+}
+
 extern "C" int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, float dustbin_logscore,
-                           int iterations, float *u, float *v, float *p, mi_stream_t stream) {
+                           int iterations, float *u, float *v, float *p, void *workspace,
+                           size_t workspace_bytes, mi_stream_t stream) {
   if (!z || !u || !v) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
   if (pitch < m || pitch % 4 != 0 || ((uintptr_t)z % 16) != 0) return MI_E_ALIGN;
   if (iterations <= 0) return MI_E_PARAM;
   hipStream_t s = (hipStream_t)stream;
   const float log_m = logf((float)m), log_n = logf((float)n);      // sinkhorn.py:197-198
+  const size_t need = mi_sinkhorn_workspace_bytes(batch, n, m);
+  if (need > 0 && workspace && ((uintptr_t)workspace % 8) == 0) {
+    if (workspace_bytes < need) return MI_E_CAPACITY;
+    float2 *part = reinterpret_cast<float2 *>(workspace);
+    const int e4 = ceil_div(m, 256);
+    if (e4 == 1) launch_fused<1, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, log_m, log_n, s);
+    else if (e4 == 2) launch_fused<2, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, log_m, log_n, s);
+    else launch_fused<4, 4>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, log_m, log_n, s);
+    if (p) {
+      hipLaunchKernelGGL(sk_exp_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, z, n, m, pitch,
+                         dustbin_logscore, u, v, p);
+    }
+    return mi_launch_status();
+  }
+  // two-pass form (no workspace, or m > 1024)
   const dim3 rgrid(ceil_div(n + 1, 4 * ROWS_PER_WAVE), batch);
   const int e4 = ceil_div(m, 256);
   // widest column vector that divides m (so a lane never straddles the matrix edge)

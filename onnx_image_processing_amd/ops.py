@@ -126,13 +126,16 @@ def cost_logscores_f32(desc1: torch.Tensor, desc2: torch.Tensor, distance: int, 
 
 
 def sinkhorn(z: torch.Tensor, m: int, pitch: int, dustbin_logscore: float, iterations: int,
-             return_duals: bool = False):
+             return_duals: bool = False, use_workspace: bool = True):
     b, n, _ = z.shape
     u = torch.empty((b, n + 1), dtype=F32, device=z.device)
     v = torch.empty((b, m + 1), dtype=F32, device=z.device)
     p = torch.empty((b, n + 1, m + 1), dtype=F32, device=z.device)
+    wbytes = int(N.load().mi_sinkhorn_workspace_bytes(b, n, m))
+    work = torch.empty((max(wbytes, 8) // 8,), dtype=torch.int64, device=z.device) if use_workspace else None
     N.call("mi_sinkhorn", N.dev(z, F32, "z"), b, n, m, pitch, float(dustbin_logscore), int(iterations),
-           u.data_ptr(), v.data_ptr(), p.data_ptr(), N.stream_ptr())
+           u.data_ptr(), v.data_ptr(), p.data_ptr(), work.data_ptr() if work is not None else None,
+           wbytes if work is not None else 0, N.stream_ptr())
     return (p, u, v) if return_duals else p
 
 

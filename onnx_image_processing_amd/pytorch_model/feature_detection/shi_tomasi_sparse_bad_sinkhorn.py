@@ -66,16 +66,17 @@ class ShiTomasiSparseBADSinkhornMatcher(nn.Module):
     def forward(self, image1: torch.Tensor, image2: torch.Tensor):
         if image1.shape != image2.shape:
             raise RuntimeError(f"image shapes differ: {tuple(image1.shape)} vs {tuple(image2.shape)}")
-        b = image1.shape[0]
-        both = torch.cat([image1.float(), image2.float()], dim=0)            # (2B,1,H,W): one launch per stage
-        scores = self.corner_detector(both).squeeze(1)
-        kpts, _ = detect_keypoints(scores, self.nms_radius, self.max_keypoints, self.score_threshold,
-                                   self.border_margin)
         packed = self.descriptor.mode == N.MI_BAD_HARD and self.matcher.distance_type == "l2"
+        kpts, descs = [], []
+        for image in (image1, image2):                                       # no concatenation: images stay in place
+            scores = self.corner_detector(image).squeeze(1)
+            kp, _ = detect_keypoints(scores, self.nms_radius, self.max_keypoints, self.score_threshold,
+                                     self.border_margin)
+            del scores
+            kpts.append(kp)
+            descs.append(self.descriptor.forward_bits(image, kp) if packed else self.descriptor(image, kp))
         if packed:
-            bits = self.descriptor.forward_bits(both, kpts)
-            probs = self.matcher.forward_bits(bits[:b], bits[b:], self.descriptor.normalize_descriptors)
+            probs = self.matcher.forward_bits(descs[0], descs[1], self.descriptor.normalize_descriptors)
         else:
-            desc = self.descriptor(both, kpts)
-            probs = self.matcher(desc[:b], desc[b:])
-        return kpts[:b], kpts[b:], probs
+            probs = self.matcher(descs[0], descs[1])
+        return kpts[0], kpts[1], probs

@@ -179,6 +179,26 @@ def test_sinkhorn_bits_vs_float_vs_oracle(mods, n, m, d):
             assert ok, (name, normalized, worst)
 
 
+@pytest.mark.parametrize("n,m", [(512, 512), (97, 301), (5, 3), (700, 1000), (64, 1500)])
+def test_sinkhorn_fused_equals_two_pass(mods, n, m):
+    """The band-fused iteration (Z read once) and the two-pass form agree to fp32 rounding, and both
+    match the fp64 oracle; m > 1024 exercises the generic two-pass kernels."""
+    from onnx_image_processing_amd import ops
+    rng = np.random.default_rng(n * 7 + m)
+    cost = (rng.random((2, n, m)) * 2.0).astype(np.float32)
+    eps, unused = 0.05, 1.0
+    pitch = (m + 3) // 4 * 4
+    z = np.full((2, n, pitch), np.nan, np.float32)               # poison the row padding
+    z[:, :, :m] = -cost / np.float32(eps)
+    ref = O.sinkhorn_from_cost(cost.astype(np.float64), 20, eps, unused, dtype=np.float64)
+    pa = ops.sinkhorn(gpu(z), m, pitch, -unused / eps, 20, use_workspace=True).cpu().numpy()
+    pb = ops.sinkhorn(gpu(z), m, pitch, -unused / eps, 20, use_workspace=False).cpu().numpy()
+    for name, p in (("fused", pa), ("two-pass", pb)):
+        ok, worst = p_close(p, ref)
+        assert ok, (name, worst)
+    assert np.abs(pa - pb).max() <= 2e-5 * max(1.0, float(np.abs(pb).max()))
+
+
 def test_sinkhorn_with_scores(mods):
     g = load_golden("sinkhorn_unit")
     p, s0, s1 = mods["SinkhornMatcherWithScores"](iterations=5, epsilon=0.1, unused_score=0.7)(gpu(g["d1"]), gpu(g["d2"]))

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark through the C ABI (development tool, GPU box only).
+
+    python tools/kbench.py [corner nms topk bad cost sinkhorn mnn] [--images 256] [--iters 20]
+
+Prints average milliseconds per call (HIP events on the launch stream) and the achieved
+algorithmic GB/s where a byte count is defined.
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from onnx_image_processing_amd import _native as N, ops  # noqa: E402
+from onnx_image_processing_amd.pytorch_model.descriptor.bad import SparseBAD  # noqa: E402
+from onnx_image_processing_amd.synth import synth_batch  # noqa: E402
+
+H, W, K = 480, 640, 512
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="*", default=["corner", "nms", "topk", "bad", "cost", "sinkhorn", "mnn"])
+    ap.add_argument("--images", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--radius", type=int, default=5)
+    args = ap.parse_args()
+    dev = "cuda:0"
+    n = args.images
+    a, _ = synth_batch(1000, 8, H, W)
+    img = torch.from_numpy(a).to(dev).repeat((n + 7) // 8, 1, 1, 1)[:n].contiguous()
+    px = n * H * W
+    res = {}
+    score = ops.corner_response(img, 3)
+    if "corner" in args.which:
+        ms = timeit(lambda: ops.corner_response(img, 3), args.iters)
+        res["corner"] = (ms, 8.0 * px / ms / 1e6)
+    sc = score.squeeze(1)
+    if "nms" in args.which:
+        cand = torch.empty((n, H * W), dtype=torch.int64, device=dev)
+        count = torch.zeros((n,), dtype=torch.int32, device=dev)
+
+        def f():
+            count.zero_()
+            N.call("mi_nms_candidates", sc.data_ptr(), n, H, W, args.radius, 0.0, 7, cand.data_ptr(), count.data_ptr(),
+                   H * W, N.stream_ptr())
+        ms = timeit(f, args.iters)
+        res["nms_candidates"] = (ms, 4.0 * px / ms / 1e6)
+        ms = timeit(lambda: ops.nms_mask(sc, args.radius), args.iters)
+        res["nms_mask"] = (ms, 8.0 * px / ms / 1e6)
+        print("candidates per image:", float(count.float().mean()))
+    kp, _ = ops.nms_topk(sc, args.radius, K, 0.0, 7)
+    if "topk" in args.which:
+        cand = torch.empty((n, H * W), dtype=torch.int64, device=dev)
+        count = torch.zeros((n,), dtype=torch.int32, device=dev)
+        N.call("mi_nms_candidates", sc.data_ptr(), n, H, W, args.radius, 0.0, 7, cand.data_ptr(), count.data_ptr(),
+               H * W, N.stream_ptr())
+        ms = timeit(lambda: ops._topk_from_candidates(cand, count, H * W, n, H, W, K), args.iters)
+        res["topk"] = (ms, 0.0)
+    bad = SparseBAD(512, binarize=True, soft_binarize=False).to(dev)
+    if "bad" in args.which:
+        ms = timeit(lambda: bad.forward_bits(img, kp), args.iters)
+        res["bad_bits"] = (ms, 0.0)
+        ms = timeit(lambda: bad(img, kp), args.iters)
+        res["bad_f32"] = (ms, 4.0 * n * K * 512 / ms / 1e6)
+    bits = bad.forward_bits(img, kp)
+    b2 = torch.roll(bits, 1, 0)
+    if "cost" in args.which:
+        ms = timeit(lambda: ops.cost_logscores_bits(bits, b2, True, 0.05), args.iters)
+        res["cost_bits"] = (ms, 4.0 * n * K * K / ms / 1e6)
+        d = bad(img[:32], kp[:32])
+        ms = timeit(lambda: ops.cost_logscores_f32(d, torch.roll(d, 1, 0), 0, 0.05), args.iters)
+        res["cost_f32(32 pairs)"] = (ms, 2.0 * 32 * K * K * 512 / ms / 1e9)
+    z, pitch = ops.cost_logscores_bits(bits, b2, True, 0.05)
+    if "sinkhorn" in args.which:
+        ms = timeit(lambda: ops.sinkhorn(z, K, pitch, -20.0, 20), args.iters)
+        res["sinkhorn_fused(20 it)"] = (ms, (21.0 * 4 * n * K * K + 4.0 * n * (K + 1) ** 2) / ms / 1e6)
+        ms = timeit(lambda: ops.sinkhorn(z, K, pitch, -20.0, 20, use_workspace=False), args.iters)
+        res["sinkhorn_2pass(20 it)"] = (ms, (41.0 * 4 * n * K * K + 4.0 * n * (K + 1) ** 2) / ms / 1e6)
+    p = ops.sinkhorn(z, K, pitch, -20.0, 20)
+    if "mnn" in args.which:
+        ms = timeit(lambda: ops.mnn_extract(p, kp, torch.roll(kp, 1, 0), 100, 0.1), args.iters)
+        res["mnn"] = (ms, 2 * 4.0 * n * (K + 1) ** 2 / ms / 1e6)
+    for k, (ms, gbs) in res.items():
+        print(f"{k:26s} {ms:8.3f} ms   {gbs:9.1f} GB/s (or GFLOP/s)")
+
+
+if __name__ == "__main__":
+    main()
