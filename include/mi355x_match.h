@@ -56,26 +56,28 @@ int mi_corner_response(const float *image, int n, int h, int w, int block_size, 
 int mi_nms_mask(const float *score, int n, int h, int w, int radius, float *mask, mi_stream_t stream);
 
 /* ---- utils/keypoint_utils.py:71-92 (candidate stage of select_topk_keypoints) ---------------
- * Emits one 64-bit key per surviving pixel into cand[img * capacity + i], counts in count[img]
- * (count must be zeroed by the caller, e.g. hipMemsetAsync on the same stream):
+ * Emits one 64-bit key per surviving pixel:
  *     m = score * mask * border ; survive iff m > max(score_threshold, 0)
  *     key = (float_bits(m) << 32) | (0xFFFFFFFF - (y*w + x))
+ * The candidate buffer is segmented: mi_candidate_layout(h, w) gives S segments (one per
+ * 128x32 image tile) of C slots each; cand is uint64[n][S][C], count is uint32[n][S].  Every
+ * count entry is written (no pre-zeroing), a segment holds at most its tile's pixels (cannot
+ * overflow), and no global atomics are used; the order inside a segment is unspecified.
  * mi_nms_candidates fuses the NMS of mi_nms_mask (mask never materialised);
- * mi_select_candidates takes an explicit mask (the reference's two-call form).
- * capacity >= h*w can never overflow; overflowing keys are dropped and count keeps counting. */
+ * mi_select_candidates takes an explicit mask (the reference's two-call form). */
+int mi_candidate_layout(int h, int w, int *segments, int *segment_capacity);
 int mi_nms_candidates(const float *score, int n, int h, int w, int radius, float score_threshold,
-                      int border_margin, uint64_t *cand, uint32_t *count, uint32_t capacity,
-                      mi_stream_t stream);
+                      int border_margin, uint64_t *cand, uint32_t *count, mi_stream_t stream);
 int mi_select_candidates(const float *score, const float *mask, int n, int h, int w,
                          float score_threshold, int border_margin, uint64_t *cand, uint32_t *count,
-                         uint32_t capacity, mi_stream_t stream);
+                         mi_stream_t stream);
 
 /* ---- utils/keypoint_utils.py:94-115 (top-k stage of select_topk_keypoints) ------------------
- * For each image: the k largest keys, descending => (score desc, linear index asc).
- * keypoints[n,k,2] = (y, x) as float, (-1,-1) beyond the candidate count; kscores[n,k].
- * 1 <= k <= 4096. */
-int mi_topk_keypoints(const uint64_t *cand, const uint32_t *count, uint32_t capacity, int n, int w,
-                      int k, float *keypoints, float *kscores, mi_stream_t stream);
+ * For each image: the k largest keys over all its segments, descending => (score desc, linear
+ * index asc).  keypoints[n,k,2] = (y, x) as float, (-1,-1) beyond the candidate count;
+ * kscores[n,k].  1 <= k <= 4096. */
+int mi_topk_keypoints(const uint64_t *cand, const uint32_t *count, int segments, int segment_capacity,
+                      int n, int w, int k, float *keypoints, float *kscores, mi_stream_t stream);
 
 /* ---- descriptor/bad.py:436-576  SparseBAD.forward (non-oriented, sampling_mode="nearest") ---
  * pair_geom[p] = x1 | x2<<5 | y1<<10 | y2<<15 | r<<20 in the 32x32 patch frame (table rows of

@@ -21,9 +21,10 @@ SIGNATURES = {
     "mi_error_string": [c_int],
     "mi_corner_response": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mi_nms_mask": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
-    "mi_nms_candidates": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_uint32, c_void_p],
-    "mi_select_candidates": [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_uint32, c_void_p],
-    "mi_topk_keypoints": [c_void_p, c_void_p, c_uint32, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "mi_candidate_layout": [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
+    "mi_nms_candidates": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p],
+    "mi_select_candidates": [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p],
+    "mi_topk_keypoints": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mi_sparse_bad": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
                       c_void_p, c_void_p, c_void_p],
     "mi_cost_logscores_bits": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p],

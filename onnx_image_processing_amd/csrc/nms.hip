@@ -2,12 +2,13 @@
 // Semantics: reference pytorch_model/utils/keypoint_utils.py:12-44 (mask) and :71-92 (masking,
 // border, threshold).  HBM traffic: 4 B/pixel read; candidates are ~1 % of pixels.
 //
-// One 256-thread workgroup owns a 128x32 tile: the score tile (+r halo, -inf outside the
+// One 256-thread workgroup owns a 128x32 tile.  The score tile (+r halo, -inf outside the
 // image) is staged in LDS, a separable max (row pass into a second LDS plane, column pass in
 // registers) gives the (2r+1)^2 window maximum.  Survivors are packed into 64-bit keys
-// (score bits high, inverted linear index low) and appended to the per-image candidate list
-// with one atomic per wave (ballot + prefix popcount), so the later top-k sort has a total
-// order that does not depend on the append order.
+// (score bits high, inverted linear index low) and written to the tile's OWN segment of the
+// candidate buffer (4096 slots = every pixel of the tile, so it cannot overflow) with the
+// count in count[img][tile]: no global atomics, no pre-zeroed counters, and the later top-k
+// sort has a total order, so the result does not depend on the order inside a segment.
 #include "common.h"
 
 #include <math.h>
@@ -15,28 +16,52 @@
 namespace {
 
 constexpr int NT_W = 128, NT_H = 32;
+constexpr int SEG_CAP = NT_W * NT_H;  // slots per tile segment
 
-__device__ __forceinline__ void emit_candidate(bool keep, float m, uint32_t lin, uint64_t *cand,
-                                               uint32_t *count, uint32_t capacity) {
-  const unsigned long long ballot = __ballot(keep);
-  if (ballot == 0ull) return;
-  const int lane = threadIdx.x & 63;
-  uint32_t base = 0;
-  if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(ballot));
-  base = __shfl(base, 0, 64);
-  if (keep) {
-    const uint32_t slot = base + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
-    if (slot < capacity)
-      cand[slot] = ((uint64_t)__float_as_uint(m) << 32) | (uint64_t)(0xFFFFFFFFu - lin);
+__device__ __forceinline__ uint64_t make_key(float m, uint32_t lin) {
+  return ((uint64_t)__float_as_uint(m) << 32) | (uint64_t)(0xFFFFFFFFu - lin);
+}
+
+// Workgroup-wide compaction of up to 16 survivors per thread into one segment.
+// kidx[q] == 0xFFFFFFFF marks "not a survivor".  Must be called by all 256 threads.
+__device__ __forceinline__ void compact_tile(uint32_t nkeep, const float (&kval)[16], const uint32_t (&kidx)[16],
+                                             uint64_t *__restrict__ seg, uint32_t *__restrict__ seg_count) {
+  __shared__ uint32_t wave_total[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = nkeep;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  if (lane == 63) wave_total[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const uint32_t c = wave_total[w];
+    base += (w < wave) ? c : 0u;
+    total += c;
+  }
+  if (threadIdx.x == 0) *seg_count = total;
+  uint32_t slot = base + incl - nkeep;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    if (kidx[q] != 0xFFFFFFFFu) seg[slot++] = make_key(kval[q], kidx[q]);
   }
 }
 
+__device__ __forceinline__ bool in_border(int gy, int gx, int h, int w, int margin) {
+  return (margin <= 0) || (gy >= margin && gy < h - margin && gx >= margin && gx < w - margin);
+}
+
+// ---- generic path: any width, radius up to 24 (dynamic LDS) ---------------------------------
 // MODE 0: write the float mask.  MODE 1: border + threshold + compaction (mask not stored).
 template <int MODE>
 __global__ __launch_bounds__(256) void nms_kernel(const float *__restrict__ score, int h, int w, int r,
                                                   int tiles_x, int tiles_y, float *__restrict__ mask,
                                                   float thr_eff, int margin, uint64_t *__restrict__ cand,
-                                                  uint32_t *__restrict__ count, uint32_t capacity) {
+                                                  uint32_t *__restrict__ count) {
   extern __shared__ float lds[];
   const int sw = NT_W + 2 * r;       // staged width
   const int sh = NT_H + 2 * r;       // staged height
@@ -44,6 +69,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float *__restrict__ scor
   float *rmax = lds + sh * sw;       // [sh][NT_W] horizontal window maxima
 
   const int t = threadIdx.x;
+  const int seg_id = blockIdx.x;
   int bid = blockIdx.x;
   const int tx_tile = bid % tiles_x;
   bid /= tiles_x;
@@ -70,6 +96,10 @@ __global__ __launch_bounds__(256) void nms_kernel(const float *__restrict__ scor
   const int cx = t & (NT_W - 1);     // column inside the tile
   const int half = t >> 7;           // rows [half*16, half*16+16)
   const int gx = x0 + cx;
+  uint32_t nkeep = 0;
+  float kval[16];
+  uint32_t kidx[16];
+#pragma unroll
   for (int k = 0; k < NT_H / 2; ++k) {
     const int ly = half * (NT_H / 2) + k;
     const int gy = y0 + ly;
@@ -85,43 +115,55 @@ __global__ __launch_bounds__(256) void nms_kernel(const float *__restrict__ scor
     if (MODE == 0) {
       if (inside) mask[((size_t)img * h + gy) * w + gx] = is_max ? 1.0f : 0.0f;
     } else {
-      const bool in_border = (margin <= 0) || (gy >= margin && gy < h - margin && gx >= margin && gx < w - margin);
-      const bool keep = is_max && in_border && (s > thr_eff);
-      emit_candidate(keep, s, (uint32_t)(gy * w + gx), cand + (size_t)img * capacity, count + img, capacity);
+      const bool keep = is_max && in_border(gy, gx, h, w, margin) && (s > thr_eff);
+      kval[k] = s;
+      kidx[k] = keep ? (uint32_t)(gy * w + gx) : 0xFFFFFFFFu;
+      nkeep += keep ? 1u : 0u;
     }
   }
+  if (MODE == 1) compact_tile(nkeep, kval, kidx, cand + (size_t)seg_id * SEG_CAP, count + seg_id);
 }
 
-// Explicit-mask form (the reference's separate select_topk_keypoints call): elementwise.
+// Explicit-mask form (the reference's separate select_topk_keypoints call), same tiling.
 __global__ __launch_bounds__(256) void select_kernel(const float *__restrict__ score,
                                                      const float *__restrict__ mask, int h, int w,
-                                                     float thr, float thr_eff, int margin,
-                                                     uint64_t *__restrict__ cand, uint32_t *__restrict__ count,
-                                                     uint32_t capacity) {
-  const int img = blockIdx.y;
-  const int hw = h * w;
-  for (int base = blockIdx.x * 256; base < hw; base += gridDim.x * 256) {
-    const int i = base + threadIdx.x;
+                                                     int tiles_x, int tiles_y, float thr, int margin,
+                                                     uint64_t *__restrict__ cand, uint32_t *__restrict__ count) {
+  const int t = threadIdx.x;
+  const int seg_id = blockIdx.x;
+  int bid = blockIdx.x;
+  const int tx_tile = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty_tile = bid % tiles_y;
+  const int img = bid / tiles_y;
+  const int gx = tx_tile * NT_W + (t & (NT_W - 1));
+  const int half = t >> 7;
+  uint32_t nkeep = 0;
+  float kval[16];
+  uint32_t kidx[16];
+#pragma unroll
+  for (int k = 0; k < NT_H / 2; ++k) {
+    const int gy = ty_tile * NT_H + half * (NT_H / 2) + k;
     bool keep = false;
     float m = 0.f;
-    if (i < hw) {
-      const int gy = i / w, gx = i - gy * w;
-      const float border =
-          (margin <= 0 || (gy >= margin && gy < h - margin && gx >= margin && gx < w - margin)) ? 1.0f : 0.0f;
-      m = score[(size_t)img * hw + i] * mask[(size_t)img * hw + i];
-      if (margin > 0) m = m * border;
-      keep = (m > thr) && (m > thr_eff);                        // keypoint_utils.py:88-92 then "> 0" at :108
+    if (gx < w && gy < h) {
+      const size_t i = ((size_t)img * h + gy) * w + gx;
+      m = score[i] * mask[i];
+      if (margin > 0) m = m * (in_border(gy, gx, h, w, margin) ? 1.0f : 0.0f);
+      keep = (m > thr) && (m > 0.0f);                          // keypoint_utils.py:88-92, then "> 0" at :108
     }
-    emit_candidate(keep, m, (uint32_t)i, cand + (size_t)img * capacity, count + img, capacity);
+    kval[k] = m;
+    kidx[k] = keep ? (uint32_t)(gy * w + gx) : 0xFFFFFFFFu;
+    nkeep += keep ? 1u : 0u;
   }
+  compact_tile(nkeep, kval, kidx, cand + (size_t)seg_id * SEG_CAP, count + seg_id);
 }
 
 // ---- fast path: w % 4 == 0, radius 1..8 -----------------------------------------------------
-// Same tile (128x32), but every stage moves float4: staging issues all of a thread's 16-byte
-// global loads before the first LDS store (loads in flight, not one dependent round trip per
-// element), the row pass forms 4 adjacent window maxima from 12/20 registers sharing the common
-// core of the four windows, the column pass does the same down 4+2R rows, and survivors of a
-// whole wave (16 pixels per lane) are appended with ONE atomic.
+// Same tile, but every stage moves float4: staging issues all of a thread's 16-byte global
+// loads before the first LDS store (loads in flight, not one dependent round trip per element),
+// the row pass forms 4 adjacent window maxima from 12/20 registers sharing the common core of the
+// four windows, the column pass does the same down 4+2R rows.
 __device__ __forceinline__ float4 max4(float4 a, float4 b) {
   return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
 }
@@ -130,18 +172,19 @@ template <int MODE, int R>
 __global__ __launch_bounds__(256) void nms_fast_kernel(const float *__restrict__ score, int h, int w,
                                                        int tiles_x, int tiles_y, float *__restrict__ mask,
                                                        float thr_eff, int margin,
-                                                       uint64_t *__restrict__ cand, uint32_t *__restrict__ count,
-                                                       uint32_t capacity) {
+                                                       uint64_t *__restrict__ cand, uint32_t *__restrict__ count) {
   constexpr int PC = (R + 3) / 4;              // padding chunks each side
   constexpr int AW4 = NT_W / 4 + 2 * PC;       // staged row, in float4
   constexpr int LH = NT_H + 2 * R;             // staged rows
   constexpr int NCH = (LH * AW4 + 255) / 256;  // staging chunks per thread
+  constexpr int NRP = (LH * (NT_W / 4) + 255) / 256;  // row-pass items per thread
   constexpr int NV = 4 * (1 + 2 * PC);         // floats a thread reads per row in the row pass
   constexpr int B0 = 4 * PC;                   // index of output column 0 inside those floats
   __shared__ float4 pa[LH][AW4];               // scores (+halo), -inf outside the image
   __shared__ float4 pb[LH][NT_W / 4];          // horizontal window maxima
 
   const int t = threadIdx.x;
+  const int seg_id = blockIdx.x;
   int bid = blockIdx.x;
   const int tx_tile = bid % tiles_x;
   bid /= tiles_x;
@@ -171,8 +214,10 @@ __global__ __launch_bounds__(256) void nms_fast_kernel(const float *__restrict__
   __syncthreads();
 
   // row pass: LH rows x 32 column groups
-#pragma unroll 1
-  for (int i = t; i < LH * (NT_W / 4); i += 256) {
+#pragma unroll
+  for (int it = 0; it < NRP; ++it) {
+    const int i = t + it * 256;
+    if (i >= LH * (NT_W / 4)) break;
     const int rr = i >> 5, cg = i & 31;
     float v[NV];
 #pragma unroll
@@ -240,46 +285,21 @@ __global__ __launch_bounds__(256) void nms_fast_kernel(const float *__restrict__
       const bool is_max = sv[c] >= (mv[c] - 1e-7f);                      // keypoint_utils.py:43
       outv[c] = is_max ? 1.0f : 0.0f;
       if (MODE == 1) {
-        const int x = gx + c;
-        const bool in_border = (margin <= 0) || (gy >= margin && gy < h - margin && x >= margin && x < w - margin);
-        const bool keep = in_img && is_max && in_border && (sv[c] > thr_eff);
+        const bool keep = in_img && is_max && in_border(gy, gx + c, h, w, margin) && (sv[c] > thr_eff);
         kval[k * 4 + c] = sv[c];
-        kidx[k * 4 + c] = keep ? (uint32_t)(gy * w + x) : 0xFFFFFFFFu;
+        kidx[k * 4 + c] = keep ? (uint32_t)(gy * w + gx + c) : 0xFFFFFFFFu;
         nkeep += keep ? 1u : 0u;
       }
     }
     if (MODE == 0 && in_img)
       *reinterpret_cast<float4 *>(mask + ((size_t)img * h + gy) * w + gx) = make_float4(outv[0], outv[1], outv[2], outv[3]);
   }
-  if (MODE == 1) {
-    // wave-level compaction: exclusive prefix of per-lane counts, one atomic per wave
-    const int lane = t & 63;
-    uint32_t incl = nkeep;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += up;
-    }
-    const uint32_t total = __shfl(incl, 63, 64);
-    if (total == 0u) return;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(count + img, total);
-    base = __shfl(base, 0, 64);
-    uint32_t slot = base + incl - nkeep;
-    uint64_t *dst = cand + (size_t)img * capacity;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      if (kidx[q] != 0xFFFFFFFFu) {
-        if (slot < capacity) dst[slot] = ((uint64_t)__float_as_uint(kval[q]) << 32) | (uint64_t)(0xFFFFFFFFu - kidx[q]);
-        ++slot;
-      }
-    }
-  }
+  if (MODE == 1) compact_tile(nkeep, kval, kidx, cand + (size_t)seg_id * SEG_CAP, count + seg_id);
 }
 
 template <int MODE>
 bool launch_fast(const float *score, int n, int h, int w, int radius, float *mask, float thr_eff, int margin,
-                 uint64_t *cand, uint32_t *count, uint32_t capacity, hipStream_t s) {
+                 uint64_t *cand, uint32_t *count, hipStream_t s) {
   if (w % 4 != 0 || radius < 1 || radius > 8 || ((uintptr_t)score % 16) != 0) return false;
   if (MODE == 0 && ((uintptr_t)mask % 16) != 0) return false;
   const int tiles_x = ceil_div(w, NT_W), tiles_y = ceil_div(h, NT_H);
@@ -287,7 +307,7 @@ bool launch_fast(const float *score, int n, int h, int w, int radius, float *mas
 #define MI_NMS_CASE(RR)                                                                                      \
   case RR:                                                                                                   \
     hipLaunchKernelGGL((nms_fast_kernel<MODE, RR>), grid, dim3(256), 0, s, score, h, w, tiles_x, tiles_y,   \
-                       mask, thr_eff, margin, cand, count, capacity);                                        \
+                       mask, thr_eff, margin, cand, count);                                                  \
     break;
   switch (radius) {
     MI_NMS_CASE(1) MI_NMS_CASE(2) MI_NMS_CASE(3) MI_NMS_CASE(4)
@@ -309,57 +329,64 @@ int allow_lds(K kernel, size_t bytes) {
 int check_common(const void *a, const void *b, int n, int h, int w) {
   if (!a || !b) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0 || (long long)h * w > 0x7fffffffLL) return MI_E_SHAPE;
+  if ((long long)n * ceil_div(w, NT_W) * ceil_div(h, NT_H) > 0x7fffffffLL) return MI_E_SHAPE;
   return MI_OK;
 }
 
+size_t generic_lds(int radius) {
+  return ((size_t)(NT_H + 2 * radius) * (NT_W + 2 * radius) + (size_t)(NT_H + 2 * radius) * NT_W) * 4;
+}
+
 }  // namespace
+
+extern "C" int mi_candidate_layout(int h, int w, int *segments, int *segment_capacity) {
+  if (h <= 0 || w <= 0 || !segments || !segment_capacity) return MI_E_SHAPE;
+  *segments = ceil_div(w, NT_W) * ceil_div(h, NT_H);
+  *segment_capacity = SEG_CAP;
+  return MI_OK;
+}
 
 extern "C" int mi_nms_mask(const float *score, int n, int h, int w, int radius, float *mask,
                            mi_stream_t stream) {
   int e = check_common(score, mask, n, h, w);
   if (e) return e;
   if (radius < 0 || radius > 24) return MI_E_PARAM;
-  if (launch_fast<0>(score, n, h, w, radius, mask, 0.f, 0, nullptr, nullptr, 0u, (hipStream_t)stream))
+  if (launch_fast<0>(score, n, h, w, radius, mask, 0.f, 0, nullptr, nullptr, (hipStream_t)stream))
     return mi_launch_status();
   const int tiles_x = ceil_div(w, NT_W), tiles_y = ceil_div(h, NT_H);
-  const size_t lds = ((size_t)(NT_H + 2 * radius) * (NT_W + 2 * radius) + (size_t)(NT_H + 2 * radius) * NT_W) * 4;
+  const size_t lds = generic_lds(radius);
   if ((e = allow_lds(nms_kernel<0>, lds)) != MI_OK) return e;
   hipLaunchKernelGGL(nms_kernel<0>, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), lds,
-                     (hipStream_t)stream, score, h, w, radius, tiles_x, tiles_y, mask, 0.f, 0, nullptr,
-                     nullptr, 0u);
+                     (hipStream_t)stream, score, h, w, radius, tiles_x, tiles_y, mask, 0.f, 0, nullptr, nullptr);
   return mi_launch_status();
 }
 
 extern "C" int mi_nms_candidates(const float *score, int n, int h, int w, int radius, float score_threshold,
-                                 int border_margin, uint64_t *cand, uint32_t *count, uint32_t capacity,
-                                 mi_stream_t stream) {
+                                 int border_margin, uint64_t *cand, uint32_t *count, mi_stream_t stream) {
   int e = check_common(score, cand, n, h, w);
   if (e) return e;
   if (!count) return MI_E_NULL;
   if (radius < 0 || radius > 24) return MI_E_PARAM;
-  if (capacity == 0) return MI_E_CAPACITY;
-  const int tiles_x = ceil_div(w, NT_W), tiles_y = ceil_div(h, NT_H);
-  const size_t lds = ((size_t)(NT_H + 2 * radius) * (NT_W + 2 * radius) + (size_t)(NT_H + 2 * radius) * NT_W) * 4;
   const float thr_eff = score_threshold > 0.f ? score_threshold : 0.f;
-  if (launch_fast<1>(score, n, h, w, radius, nullptr, thr_eff, border_margin, cand, count, capacity,
-                     (hipStream_t)stream))
+  if (launch_fast<1>(score, n, h, w, radius, nullptr, thr_eff, border_margin, cand, count, (hipStream_t)stream))
     return mi_launch_status();
+  const int tiles_x = ceil_div(w, NT_W), tiles_y = ceil_div(h, NT_H);
+  const size_t lds = generic_lds(radius);
   if ((e = allow_lds(nms_kernel<1>, lds)) != MI_OK) return e;
   hipLaunchKernelGGL(nms_kernel<1>, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), lds,
-                     (hipStream_t)stream, score, h, w, radius, tiles_x, tiles_y, nullptr, thr_eff,
-                     border_margin, cand, count, capacity);
+                     (hipStream_t)stream, score, h, w, radius, tiles_x, tiles_y, nullptr, thr_eff, border_margin,
+                     cand, count);
   return mi_launch_status();
 }
 
 extern "C" int mi_select_candidates(const float *score, const float *mask, int n, int h, int w,
                                     float score_threshold, int border_margin, uint64_t *cand,
-                                    uint32_t *count, uint32_t capacity, mi_stream_t stream) {
+                                    uint32_t *count, mi_stream_t stream) {
   int e = check_common(score, mask, n, h, w);
   if (e) return e;
   if (!cand || !count) return MI_E_NULL;
-  if (capacity == 0) return MI_E_CAPACITY;
-  const int gx = ceil_div(h * w, 256) < 1024 ? ceil_div(h * w, 256) : 1024;
-  hipLaunchKernelGGL(select_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, score, mask, h, w,
-                     score_threshold, 0.f, border_margin, cand, count, capacity);
+  const int tiles_x = ceil_div(w, NT_W), tiles_y = ceil_div(h, NT_H);
+  hipLaunchKernelGGL(select_kernel, dim3((unsigned)(n * tiles_x * tiles_y)), dim3(256), 0, (hipStream_t)stream,
+                     score, mask, h, w, tiles_x, tiles_y, score_threshold, border_margin, cand, count);
   return mi_launch_status();
 }

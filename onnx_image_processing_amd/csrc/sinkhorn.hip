@@ -19,6 +19,12 @@ namespace {
 
 constexpr int ROWS_PER_WAVE = 4;
 
+// exp(d) for d <= 0 in the O(n*m) inner sums: one multiply + v_exp_f32 (2^x, <= 1 ulp) instead
+// of the ~15-instruction libm expf.  The argument's rounding error (|d| * log2e * 2^-24, at most
+// ~4e-6 for |d| <= 60) bounds the term's relative error; terms that far below the row maximum
+// do not move the sum.  Merges of partials, log() and the final P = exp(...) use libm.
+__device__ __forceinline__ float sk_exp(float d) { return __builtin_amdgcn_exp2f(d * 1.4426950408889634f); }
+
 // ---- row pass -----------------------------------------------------------------------------
 // E4 = float4 loads per lane: covers m <= 256 * E4 columns.
 template <int E4>
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256) void sk_row_kernel(const float *__restrict__ z
 #pragma unroll
     for (int e = 0; e < E4; ++e)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) s += expf(x[e][q] - mx);          // exp(-inf) = 0 for padding lanes
+      for (int q = 0; q < 4; ++q) s += sk_exp(x[e][q] - mx);        // exp(-inf) = 0 for padding lanes
     s = wave_sum(s) + expf(xd - mx);
     if (lane == 0) u[(size_t)b * (n + 1) + i] = ((i == n) ? log_m : 0.0f) - (logf(s) + mx);
   }
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(256) void sk_col_kernel(const float *__restrict__ z
         if (cm > mx[c]) { s[c] *= expf(mx[c] - cm); mx[c] = cm; }   // exp(-inf - cm) = 0 on first use
         if (mx[c] > -INFINITY) {
 #pragma unroll
-          for (int r = 0; r < CH; ++r) s[c] += expf(x[r][c] - mx[c]);
+          for (int r = 0; r < CH; ++r) s[c] += sk_exp(x[r][c] - mx[c]);
         }
       }
     }
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(256) void sk_band_kernel(const float *__restrict__ 
 #pragma unroll
     for (int e = 0; e < E4; ++e)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) s += expf((zr[r][e][q] + vv[e][q]) - mx);
+      for (int q = 0; q < 4; ++q) s += sk_exp((zr[r][e][q] + vv[e][q]) - mx);
     s = wave_sum(s) + expf(xd - mx);
     ur[r] = 0.0f - (logf(s) + mx);
     if (lane == 0 && row0 + r < n) u[(size_t)b * (n + 1) + row0 + r] = ur[r];
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(256) void sk_band_kernel(const float *__restrict__ 
       float cs = 0.0f;
       if (cm > -INFINITY) {
 #pragma unroll
-        for (int r = 0; r < RW; ++r) cs += expf((zr[r][e][q] + ur[r]) - cm);
+        for (int r = 0; r < RW; ++r) cs += sk_exp((zr[r][e][q] + ur[r]) - cm);
       }
       red_m[wave][e * 256 + lane * 4 + q] = cm;
       red_s[wave][e * 256 + lane * 4 + q] = cs;

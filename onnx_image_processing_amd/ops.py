@@ -42,12 +42,27 @@ def nms_mask(scores: torch.Tensor, radius: int) -> torch.Tensor:
     return mask
 
 
-def _topk_from_candidates(cand, count, capacity, b, h, w, k):
+def candidate_layout(h: int, w: int) -> tuple[int, int]:
+    """(segments per image, slots per segment) of the K2 candidate buffer."""
+    import ctypes
+    seg, cap = ctypes.c_int(0), ctypes.c_int(0)
+    N.check(N.load().mi_candidate_layout(int(h), int(w), ctypes.byref(seg), ctypes.byref(cap)), "mi_candidate_layout")
+    return seg.value, cap.value
+
+
+def _candidate_buffers(b: int, h: int, w: int, device):
+    seg, cap = candidate_layout(h, w)
+    cand = torch.empty((b, seg, cap), dtype=torch.int64, device=device)
+    count = torch.empty((b, seg), dtype=torch.int32, device=device)      # fully written by K2
+    return cand, count, seg, cap
+
+
+def _topk_from_candidates(cand, count, seg, cap, b, h, w, k):
     if h * w < k:
         raise RuntimeError(f"selected index k out of range (k={k} > H*W={h * w})")  # torch.topk's failure mode
     kpts = torch.empty((b, k, 2), dtype=F32, device=cand.device)
     ksc = torch.empty((b, k), dtype=F32, device=cand.device)
-    N.call("mi_topk_keypoints", cand.data_ptr(), count.data_ptr(), capacity, b, w, int(k), kpts.data_ptr(),
+    N.call("mi_topk_keypoints", cand.data_ptr(), count.data_ptr(), seg, cap, b, w, int(k), kpts.data_ptr(),
            ksc.data_ptr(), N.stream_ptr())
     return kpts, ksc
 
@@ -56,12 +71,10 @@ def nms_topk(scores: torch.Tensor, radius: int, k: int, score_threshold: float =
     """Fused NMS + border + threshold + top-k (the mask is never materialised)."""
     s = _score_maps(scores)
     b, h, w = s.shape
-    capacity = h * w
-    cand = torch.empty((b, capacity), dtype=torch.int64, device=s.device)
-    count = torch.zeros((b,), dtype=torch.int32, device=s.device)
+    cand, count, seg, cap = _candidate_buffers(b, h, w, s.device)
     N.call("mi_nms_candidates", N.dev(s, F32, "scores"), b, h, w, int(radius), float(score_threshold),
-           int(border_margin), cand.data_ptr(), count.data_ptr(), capacity, N.stream_ptr())
-    return _topk_from_candidates(cand, count, capacity, b, h, w, k)
+           int(border_margin), cand.data_ptr(), count.data_ptr(), N.stream_ptr())
+    return _topk_from_candidates(cand, count, seg, cap, b, h, w, k)
 
 
 def select_topk(scores: torch.Tensor, mask: torch.Tensor, k: int, score_threshold: float = 0.0,
@@ -71,12 +84,10 @@ def select_topk(scores: torch.Tensor, mask: torch.Tensor, k: int, score_threshol
     if mk.shape != s.shape:
         raise RuntimeError(f"nms_mask shape {tuple(mk.shape)} != scores shape {tuple(s.shape)}")
     b, h, w = s.shape
-    capacity = h * w
-    cand = torch.empty((b, capacity), dtype=torch.int64, device=s.device)
-    count = torch.zeros((b,), dtype=torch.int32, device=s.device)
+    cand, count, seg, cap = _candidate_buffers(b, h, w, s.device)
     N.call("mi_select_candidates", N.dev(s, F32, "scores"), N.dev(mk, F32, "nms_mask"), b, h, w,
-           float(score_threshold), int(border_margin), cand.data_ptr(), count.data_ptr(), capacity, N.stream_ptr())
-    return _topk_from_candidates(cand, count, capacity, b, h, w, k)
+           float(score_threshold), int(border_margin), cand.data_ptr(), count.data_ptr(), N.stream_ptr())
+    return _topk_from_candidates(cand, count, seg, cap, b, h, w, k)
 
 
 def sparse_bad(image: torch.Tensor, keypoints: torch.Tensor, pair_geom: torch.Tensor, pair_thr: torch.Tensor,

@@ -55,25 +55,22 @@ def main():
         res["corner"] = (ms, 8.0 * px / ms / 1e6)
     sc = score.squeeze(1)
     if "nms" in args.which:
-        cand = torch.empty((n, H * W), dtype=torch.int64, device=dev)
-        count = torch.zeros((n,), dtype=torch.int32, device=dev)
+        cand, count, seg, cap = ops._candidate_buffers(n, H, W, dev)
 
         def f():
-            count.zero_()
             N.call("mi_nms_candidates", sc.data_ptr(), n, H, W, args.radius, 0.0, 7, cand.data_ptr(), count.data_ptr(),
-                   H * W, N.stream_ptr())
+                   N.stream_ptr())
         ms = timeit(f, args.iters)
         res["nms_candidates"] = (ms, 4.0 * px / ms / 1e6)
         ms = timeit(lambda: ops.nms_mask(sc, args.radius), args.iters)
         res["nms_mask"] = (ms, 8.0 * px / ms / 1e6)
-        print("candidates per image:", float(count.float().mean()))
+        print("candidates per image:", float(count.float().sum(1).mean()))
     kp, _ = ops.nms_topk(sc, args.radius, K, 0.0, 7)
     if "topk" in args.which:
-        cand = torch.empty((n, H * W), dtype=torch.int64, device=dev)
-        count = torch.zeros((n,), dtype=torch.int32, device=dev)
+        cand, count, seg, cap = ops._candidate_buffers(n, H, W, dev)
         N.call("mi_nms_candidates", sc.data_ptr(), n, H, W, args.radius, 0.0, 7, cand.data_ptr(), count.data_ptr(),
-               H * W, N.stream_ptr())
-        ms = timeit(lambda: ops._topk_from_candidates(cand, count, H * W, n, H, W, K), args.iters)
+               N.stream_ptr())
+        ms = timeit(lambda: ops._topk_from_candidates(cand, count, seg, cap, n, H, W, K), args.iters)
         res["topk"] = (ms, 0.0)
     bad = SparseBAD(512, binarize=True, soft_binarize=False).to(dev)
     if "bad" in args.which:
@@ -99,6 +96,25 @@ def main():
     if "mnn" in args.which:
         ms = timeit(lambda: ops.mnn_extract(p, kp, torch.roll(kp, 1, 0), 100, 0.1), args.iters)
         res["mnn"] = (ms, 2 * 4.0 * n * (K + 1) ** 2 / ms / 1e6)
+    if "acc" in args.which:
+        # accuracy margin of the Sinkhorn path vs the fp64 oracle (bound: 1e-4 * max(1, |P|))
+        from oracle import numpy_oracle as O
+        rng = np.random.default_rng(1)
+        b1 = rng.random((2, 512, 512)) < 0.4
+        b2 = rng.random((2, 512, 512)) < 0.4
+        b2[:, :256] = b1[:, :256]
+
+        def desc(bb):
+            f = bb.astype(np.float32)
+            return f / np.maximum(np.sqrt(f.sum(-1, keepdims=True, dtype=np.float32)), np.float32(1e-12))
+        ref = O.sinkhorn_match(desc(b1).astype(np.float64), desc(b2).astype(np.float64), 20, 0.05, 1.0, dtype=np.float64)
+        tb1 = torch.from_numpy(O.pack_bits(b1).view(np.int32)).to(dev)
+        tb2 = torch.from_numpy(O.pack_bits(b2).view(np.int32)).to(dev)
+        zz, pp = ops.cost_logscores_bits(tb1, tb2, True, 0.05)
+        for name, ws in (("fused", True), ("two-pass", False)):
+            got = ops.sinkhorn(zz, 512, pp, -20.0, 20, use_workspace=ws).cpu().numpy().astype(np.float64)
+            ratio = np.abs(got - ref) / (1e-4 * np.maximum(1.0, np.abs(ref)))
+            print(f"accuracy {name}: worst |dP|/bound = {ratio.max():.4f}, max |dP| core = {np.abs(got - ref)[:, :512, :512].max():.3e}")
     for k, (ms, gbs) in res.items():
         print(f"{k:26s} {ms:8.3f} ms   {gbs:9.1f} GB/s (or GFLOP/s)")
 
