@@ -43,6 +43,10 @@ enum { MI_DIST_L2 = 0, MI_DIST_L1 = 1 };
 
 int mi_abi_version(void);
 const char *mi_error_string(int code);
+/* Development/test hook: choose between equivalent kernel implementations (results are
+ * identical).  key 1: corner response, 0 = streaming LDS-DMA kernel (default), 1 = register-
+ * staged tile kernel. */
+int mi_debug_set(int key, int value);
 
 /* ---- detector/shi_tomasi.py:66-112  ShiTomasiScore.forward ---------------------------------
  * score[n,1,h,w] = max(0, (a+c)/2 - sqrt(((a-c)/2)^2 + b^2 + 1e-10)) of the Sobel structure
@@ -83,10 +87,18 @@ int mi_topk_keypoints(const uint64_t *cand, const uint32_t *count, int segments,
  * pair_geom[p] = x1 | x2<<5 | y1<<10 | y2<<15 | r<<20 in the 32x32 patch frame (table rows of
  * descriptor/bad_params.py), pair_thr[p] the learned threshold.  num_pairs % 64 == 0, <= 1024.
  * desc (n,k,num_pairs) f32 and/or bits (n,k,num_pairs/32) u32 may be NULL (bits only for HARD).
- * Box sums are exact (fp64 summed-area table over a replicate-clamped 34x34 window). */
+ * Box sums are exact (fp64 summed-area table over a replicate-clamped 34x34 window).
+ * plan (optional, may be NULL): device buffer of mi_bad_plan_bytes(num_pairs) bytes, 16-byte
+ * aligned, filled once per pair table by mi_bad_plan_build.  With a plan, HARD-mode keypoints
+ * that are integer-valued, at least 15 px from the border and sit on an integer-valued (uint8)
+ * patch take an int32 fast path with precomputed table corners; results are identical. */
+size_t mi_bad_plan_bytes(int num_pairs);
+int mi_bad_plan_build(const uint32_t *pair_geom, const float *pair_thr, int num_pairs, void *plan,
+                      mi_stream_t stream);
 int mi_sparse_bad(const float *image, int n, int h, int w, const float *keypoints, int k,
                   const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
-                  float temperature, int normalize, float *desc, uint32_t *bits, mi_stream_t stream);
+                  float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
+                  mi_stream_t stream);
 
 /* ---- matching/sinkhorn.py:79-110,178  cost matrix -> core log-score matrix --------------------
  * z[b, i, j] = -cost(desc1[b,i], desc2[b,j]) / epsilon for i < n, j < m; row pitch `pitch` floats

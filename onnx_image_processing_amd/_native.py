@@ -19,14 +19,17 @@ LIB_PATH = os.path.join(_PKG, "lib", "libmi355x_match.so")
 SIGNATURES = {
     "mi_abi_version": [],
     "mi_error_string": [c_int],
+    "mi_debug_set": [c_int, c_int],
     "mi_corner_response": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mi_nms_mask": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mi_candidate_layout": [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
     "mi_nms_candidates": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p],
     "mi_select_candidates": [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p],
     "mi_topk_keypoints": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "mi_bad_plan_bytes": [c_int],
+    "mi_bad_plan_build": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "mi_sparse_bad": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
-                      c_void_p, c_void_p, c_void_p],
+                      c_void_p, c_void_p, c_void_p, c_void_p],
     "mi_cost_logscores_bits": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p],
     "mi_cost_logscores_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p],
     "mi_sinkhorn_workspace_bytes": [c_int, c_int, c_int],
@@ -35,7 +38,7 @@ SIGNATURES = {
     "mi_mnn_extract": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
 }
-_RESTYPE = {"mi_error_string": c_char_p, "mi_sinkhorn_workspace_bytes": c_size_t}
+_RESTYPE = {"mi_error_string": c_char_p, "mi_sinkhorn_workspace_bytes": c_size_t, "mi_bad_plan_bytes": c_size_t}
 
 MI_BAD_RAW, MI_BAD_SOFT, MI_BAD_HARD = 0, 1, 2
 MI_DIST_L2, MI_DIST_L1 = 0, 1

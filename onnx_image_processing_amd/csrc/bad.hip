@@ -23,6 +23,17 @@ namespace {
 constexpr int WIN = 34;          // window edge
 constexpr int WOFF = 16;         // window origin = floor(k) - WOFF
 constexpr int SP = WIN + 1;      // SAT edge (leading zero row/column)
+constexpr int FW = 33;           // fast-path SAT edge (32x32 window + leading zero row/column)
+
+// Device-resident plan for the fast path, built once per pair table by mi_bad_plan_build:
+// header, then uint4 offs[P] (eight 16-bit BYTE offsets into the int32 33x33 table: box 1
+// corners (b,r) (a,r) (b,l) (a,l) in x,y; box 2 in z,w; low half first), then int tint[P] =
+// floor(thr * area).
+struct BadPlan {
+  int geometry_ok;   // every box of the table stays inside the 32x32 patch
+  int num_pairs;
+  int pad[2];
+};
 
 // ATen grid_sampler semantics used by bad.py:518-556 (align_corners=True, padding "border",
 // mode "nearest"): normalise with fp32(2/(size-1+1e-8)), un-normalise, clip, round half even.
@@ -40,8 +51,11 @@ __global__ __launch_bounds__(64) void sparse_bad_kernel(const float *__restrict_
                                                         int mode, float temperature, int normalize,
                                                         float scale_y, float scale_x,
                                                         float *__restrict__ desc,
-                                                        uint32_t *__restrict__ bits) {
+                                                        uint32_t *__restrict__ bits,
+                                                        const BadPlan *__restrict__ plan) {
   __shared__ double sat[SP * SP];
+  const uint4 *plan_offs = reinterpret_cast<const uint4 *>(plan + 1);
+  const int *plan_tint = reinterpret_cast<const int *>(plan_offs + num_pairs);
   __shared__ float vals[1024];               // un-normalised descriptor row (num_pairs <= 1024)
   const int lane = threadIdx.x;
   const int kp = blockIdx.x;                 // keypoint index within the image
@@ -53,6 +67,91 @@ __global__ __launch_bounds__(64) void sparse_bad_kernel(const float *__restrict_
   const float ky = fminf(fmaxf(ky_raw, 0.0f), (float)(h - 1));         // bad.py:464-465
   const float kx = fminf(fmaxf(kx_raw, 0.0f), (float)(w - 1));
   const int oy = (int)floorf(ky) - WOFF, ox = (int)floorf(kx) - WOFF;
+
+  // ---- fast path (hard bits): integer keypoint whose 512 box centres need no clamping, over an
+  // integer-valued (uint8) patch.  Then every box lies in the 32x32 window [k-16, k+15], its four
+  // summed-area-table corners are the same for every keypoint (precomputed byte offsets in
+  // `plan`), sums are exact int32 and the sign test is D <= floor(thr * area).  All 64 lanes
+  // build the table: lane = (half, column) holds 16 rows of its column, then lane = (half, row).
+  if (plan != nullptr && mode == MI_BAD_HARD && plan->geometry_ok) {
+    const bool interior = valid && ky == floorf(ky) && kx == floorf(kx) && ky >= 15.0f &&
+                          ky <= (float)(h - 15) && kx >= 15.0f && kx <= (float)(w - 15);
+    if (interior) {                                  // wave-uniform: one keypoint per wave
+      int *isat = reinterpret_cast<int *>(sat);      // [33][33], aliases the fp64 table
+      const int half = lane >> 5, c = lane & 31;
+      const int gx = clampi(ox + c, 0, w - 1);
+      float px[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) px[r] = im[(size_t)clampi(oy + 16 * half + r, 0, h - 1) * w + gx];
+      bool integral = true;
+      int col[16];
+      int acc = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int v = (int)px[r];
+        integral = integral && ((float)v == px[r]) && (v >= 0) && (v <= 255);
+        acc += v;
+        col[r] = acc;
+      }
+      if (__all(integral)) {
+        const int upper = __shfl(acc, c, 64);        // column total of rows 0..15 (held by half 0)
+        if (lane < 33) { isat[lane] = 0; isat[lane * 33] = 0; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) isat[(16 * half + r + 1) * 33 + c + 1] = col[r] + (half ? upper : 0);
+        __syncthreads();
+        {
+          int *row = isat + (c + 1) * 33 + 16 * half + 1;   // lane = (half, row c): 16 entries of row c
+          int v[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) v[q] = row[q];
+          int racc = 0;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) { racc += v[q]; v[q] = racc; }
+          const int left = __shfl(racc, c, 64);      // total of columns 0..15 of this row
+#pragma unroll
+          for (int q = 0; q < 16; ++q) row[q] = v[q] + (half ? left : 0);
+        }
+        __syncthreads();
+        const int groups_f = num_pairs / 64;
+        const int words_f = num_pairs / 32;
+        uint32_t *brow_f = bits ? bits + ((size_t)img * k + kp) * words_f : nullptr;
+        const char *sbase = reinterpret_cast<const char *>(isat);
+        unsigned long long wordv[16];
+        int pop_f = 0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          wordv[g] = 0ull;
+          if (g < groups_f) {
+            const uint4 o = plan_offs[g * 64 + lane];
+            const int tint = plan_tint[g * 64 + lane];
+            auto at = [&](uint32_t byte_off) { return *reinterpret_cast<const int *>(sbase + byte_off); };
+            const int s1 = (at(o.x & 0xFFFFu) - at(o.x >> 16)) - (at(o.y & 0xFFFFu) - at(o.y >> 16));
+            const int s2 = (at(o.z & 0xFFFFu) - at(o.z >> 16)) - (at(o.w & 0xFFFFu) - at(o.w >> 16));
+            const unsigned long long word = __ballot((s1 - s2) <= tint);
+            wordv[g] = word;
+            pop_f += (int)__popcll(word);
+            if (brow_f && lane == 0) {
+              brow_f[2 * g] = (uint32_t)word;
+              brow_f[2 * g + 1] = (uint32_t)(word >> 32);
+            }
+          }
+        }
+        if (desc) {
+          const float inv = normalize ? fmaxf(sqrtf((float)pop_f), 1e-12f) : 1.0f;
+          const size_t drow_f = ((size_t)img * k + kp) * (size_t)num_pairs;
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            if (g < groups_f) {
+              const float v = ((wordv[g] >> lane) & 1ull) ? 1.0f : 0.0f;
+              desc[drow_f + g * 64 + lane] = normalize ? v / inv : v;
+            }
+          }
+        }
+        return;
+      }
+      __syncthreads();   // not integral: fall through to the general path (window reloaded below)
+    }
+  }
 
   // ---- summed-area table of the replicate-extended window, sat[r+1][c+1] = sum of rows<=r, cols<=c
   // Lane c < 34 owns window column c: its 34 row loads are all issued before any use (34 loads in
@@ -157,11 +256,55 @@ __global__ __launch_bounds__(64) void sparse_bad_kernel(const float *__restrict_
   }
 }
 
+__global__ __launch_bounds__(64) void bad_plan_kernel(const uint32_t *__restrict__ geom,
+                                                      const float *__restrict__ thr, int num_pairs,
+                                                      BadPlan *__restrict__ plan) {
+  uint4 *offs = reinterpret_cast<uint4 *>(plan + 1);
+  int *tint = reinterpret_cast<int *>(offs + num_pairs);
+  bool ok = true;
+  for (int p = threadIdx.x; p < num_pairs; p += 64) {
+    const uint32_t q = geom[p];
+    const int x1 = (int)(q & 31u), x2 = (int)((q >> 5) & 31u);
+    const int y1 = (int)((q >> 10) & 31u), y2 = (int)((q >> 15) & 31u);
+    const int r = (int)((q >> 20) & 15u);
+    ok = ok && x1 - r >= 0 && x2 - r >= 0 && y1 - r >= 0 && y2 - r >= 0 && x1 + r <= 31 && x2 + r <= 31 &&
+         y1 + r <= 31 && y2 + r <= 31;
+    auto off = [](int row, int col) { return (uint32_t)((row * FW + col) * 4); };
+    uint4 o;
+    o.x = off(y1 + r + 1, x1 + r + 1) | (off(y1 - r, x1 + r + 1) << 16);
+    o.y = off(y1 + r + 1, x1 - r) | (off(y1 - r, x1 - r) << 16);
+    o.z = off(y2 + r + 1, x2 + r + 1) | (off(y2 - r, x2 + r + 1) << 16);
+    o.w = off(y2 + r + 1, x2 - r) | (off(y2 - r, x2 - r) << 16);
+    offs[p] = o;
+    tint[p] = (int)floor((double)thr[p] * (double)((2 * r + 1) * (2 * r + 1)));
+  }
+  const bool all_ok = __all(ok);
+  if (threadIdx.x == 0) {
+    plan->geometry_ok = all_ok ? 1 : 0;
+    plan->num_pairs = num_pairs;
+  }
+}
+
 }  // namespace
+
+extern "C" size_t mi_bad_plan_bytes(int num_pairs) {
+  if (num_pairs <= 0) return 0;
+  return sizeof(BadPlan) + (size_t)num_pairs * (sizeof(uint4) + sizeof(int));
+}
+
+extern "C" int mi_bad_plan_build(const uint32_t *pair_geom, const float *pair_thr, int num_pairs, void *plan,
+                                 mi_stream_t stream) {
+  if (!pair_geom || !pair_thr || !plan) return MI_E_NULL;
+  if (num_pairs <= 0 || num_pairs % 64 != 0 || num_pairs > 1024) return MI_E_PARAM;
+  if (((uintptr_t)plan % 16) != 0) return MI_E_ALIGN;
+  hipLaunchKernelGGL(bad_plan_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pair_geom, pair_thr, num_pairs,
+                     reinterpret_cast<BadPlan *>(plan));
+  return mi_launch_status();
+}
 
 extern "C" int mi_sparse_bad(const float *image, int n, int h, int w, const float *keypoints, int k,
                              const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
-                             float temperature, int normalize, float *desc, uint32_t *bits,
+                             float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
                              mi_stream_t stream) {
   if (!image || !keypoints || !pair_geom || !pair_thr) return MI_E_NULL;
   if (!desc && !bits) return MI_E_NULL;
@@ -175,6 +318,6 @@ extern "C" int mi_sparse_bad(const float *image, int n, int h, int w, const floa
   const float scale_x = (float)(2.0 / ((double)(w - 1) + 1e-8));
   hipLaunchKernelGGL(sparse_bad_kernel, dim3(k, n), dim3(64), 0, (hipStream_t)stream, image, h, w, keypoints,
                      k, pair_geom, pair_thr, num_pairs, mode, temperature, normalize, scale_y, scale_x, desc,
-                     bits);
+                     bits, reinterpret_cast<const BadPlan *>(plan));
   return mi_launch_status();
 }

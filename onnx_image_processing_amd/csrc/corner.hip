@@ -19,13 +19,209 @@ constexpr int TW = 128;  // tile width: 32 threads x 4 pixels
 constexpr int LPAD = 4;  // LDS padding each side, one float4 (>= 1 + block/2 for block <= 7)
 constexpr int LW4 = (TW + 2 * LPAD) / 4;
 
+// Correctly rounded fp32 sqrt for normal, finite x (here x >= 1e-10): v_sqrt_f32 is within 1 ulp,
+// so the answer is one of {s-1ulp, s, s+1ulp}; two exact-sign fma residuals pick it.  This is
+// the compiler's own IEEE sqrt expansion without its denormal pre-scaling and class checks.
+__device__ __forceinline__ float sqrt_rn(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float lo = __uint_as_float(__float_as_uint(s) - 1u);
+  const float hi = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rl = __builtin_fmaf(-lo, s, x);
+  const float rh = __builtin_fmaf(-hi, s, x);
+  float r = (rl <= 0.0f) ? lo : s;
+  r = (rh > 0.0f) ? hi : r;
+  return r;
+}
+
 __device__ __forceinline__ float lambda_min(float a, float c, float b) {
   // shi_tomasi.py:102-110, one rounding per op
   float half_trace = (a + c) * 0.5f;
   float half_diff = (a - c) * 0.5f;
   float disc = half_diff * half_diff + b * b;
-  float root = sqrtf(disc + 1e-10f);
+  float root = sqrt_rn(disc + 1e-10f);
   return fmaxf(half_trace - root, 0.0f);
+}
+
+// Per-thread stencil on a staged tile (shared by the tile and the streaming kernels).
+// `tile` is the row-major [LH][LW4] float4 image of the clamped image region whose first row is
+// y0 - HL and first column x0 - LPAD.
+template <int BS, int R>
+__device__ __forceinline__ void corner_compute(const float4 *__restrict__ tile, float *__restrict__ score,
+                                               int img, int h, int w, int x0, int y0, int t) {
+  constexpr int HP = BS / 2;       // halo of the product maps
+  constexpr int HL = HP + 1;       // halo of the image
+  constexpr int TH = 8 * R;        // tile height
+  constexpr int NG = 4 + 2 * HP;   // gradient columns per thread
+  constexpr int NP = R + 2 * HP;   // product rows per thread
+  const int tx = t & 31, ty = t >> 5;
+  const int x = x0 + 4 * tx;
+  const int ybase = y0 + ty * R;
+  if (x >= w || ybase >= h) return;
+  // image-border handling only exists on border tiles (workgroup-uniform branches)
+  const bool tile_left = (x0 == 0), tile_right = (x0 + TW >= w);
+  const bool tile_top = (y0 == 0), tile_bottom = (y0 + TH + HP > h);
+  const bool left_edge = (x == 0);
+  const bool right_edge = (x + 4 >= w);
+  const bool top_edge = (ybase == 0);
+
+  constexpr int NC = NG + 2;   // image columns feeding the NG gradient columns
+  constexpr int C0 = 3 - HP;   // window index of the first of them
+  float win[3][12];            // rolling image rows, columns x-4 .. x+7
+  float cprev[NC];             // row(ir-2) + row(ir-1): half of the vertical 1-2-1
+  float hs[NP][3][4];          // horizontally summed products per product row (xx, yy, xy)
+  float vq[3][4];              // hs[r+1] + hs[r+2], shared by output rows r and r+1 (BS == 3)
+
+#pragma unroll
+  for (int ir = 0; ir < R + 2 * HL; ++ir) {
+    // image row (ybase - HL + ir) lives in LDS row ty*R + ir
+    {
+      const float4 *src = &tile[(ty * R + ir) * LW4 + tx];
+      const float4 a = src[0], b = src[1], c = src[2];
+      float *d = win[ir % 3];
+      d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
+      d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+      d[8] = c.x; d[9] = c.y; d[10] = c.z; d[11] = c.w;
+      // replicate padding of the IMAGE in x: chunks left/right of the image take the edge pixel
+      // (the register-staged kernel already stored them that way; LDS-DMA cannot splat)
+      if (tile_left) {
+        if (left_edge) { d[0] = d[4]; d[1] = d[4]; d[2] = d[4]; d[3] = d[4]; }
+      }
+      if (tile_right) {
+        if (right_edge) { d[8] = d[7]; d[9] = d[7]; d[10] = d[7]; d[11] = d[7]; }
+      }
+    }
+    if (ir < 1) continue;
+    const float *mid = win[(ir - 1) % 3], *bot = win[ir % 3];
+    // vertical 1-2-1 as (top+mid) + (mid+bot): each pair sum is formed once and used twice
+    float cnew[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) cnew[k] = mid[C0 + k] + bot[C0 + k];
+    if (ir < 2) {
+#pragma unroll
+      for (int k = 0; k < NC; ++k) cprev[k] = cnew[k];
+      continue;
+    }
+    const int pr = ir - 2;                 // product row index, global row ybase - HP + pr
+    const float *top = win[(ir - 2) % 3];
+    const int gy = ybase - HP + pr;
+
+    float sm[NC], df[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      sm[k] = cprev[k] + cnew[k];
+      df[k] = bot[C0 + k] - top[C0 + k];
+      cprev[k] = cnew[k];
+    }
+    // horizontal taps: gx = sm[j+2]-sm[j];  gy = df[j] + 2 df[j+1] + df[j+2] = e[j] + e[j+1]
+    float e[NC - 1];
+#pragma unroll
+    for (int k = 0; k < NC - 1; ++k) e[k] = df[k] + df[k + 1];
+    float gx_[NG], gy_[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      gx_[j] = sm[j + 2] - sm[j];
+      gy_[j] = e[j] + e[j + 1];
+    }
+    // replicate padding of the PRODUCT maps == gradients taken at the clamped column
+    if (tile_left) {
+      if (left_edge) {
+#pragma unroll
+        for (int j = 0; j < HP; ++j) { gx_[j] = gx_[HP]; gy_[j] = gy_[HP]; }
+      }
+    }
+    if (tile_right) {
+      if (right_edge) {
+#pragma unroll
+        for (int j = 0; j < HP; ++j) { gx_[4 + HP + j] = gx_[3 + HP]; gy_[4 + HP + j] = gy_[3 + HP]; }
+      }
+    }
+    float pxx[NG], pyy[NG], pxy[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      pxx[j] = gx_[j] * gx_[j];
+      pyy[j] = gy_[j] * gy_[j];
+      pxy[j] = gx_[j] * gy_[j];
+    }
+    if constexpr (BS == 3) {
+      // 4 sliding 3-sums out of 6 values with 7 adds: pair sums s01 s23 s45
+      const float *pp[3] = {pxx, pyy, pxy};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float *p = pp[q];
+        const float s01 = p[0] + p[1], s23 = p[2] + p[3], s45 = p[4] + p[5];
+        hs[pr][q][0] = s01 + p[2];
+        hs[pr][q][1] = p[1] + s23;
+        hs[pr][q][2] = s23 + p[4];
+        hs[pr][q][3] = p[3] + s45;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float a = pxx[i], c = pyy[i], b = pxy[i];
+#pragma unroll
+        for (int dx = 1; dx < BS; ++dx) { a += pxx[i + dx]; c += pyy[i + dx]; b += pxy[i + dx]; }
+        hs[pr][0][i] = a; hs[pr][1][i] = c; hs[pr][2][i] = b;
+      }
+    }
+    // rows below the image repeat the last in-image product row
+    if (tile_bottom) {
+      if (pr > 0 && gy > h - 1) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) hs[pr][q][i] = hs[pr - 1][q][i];
+      }
+    }
+    // rows above the image repeat product row 0 of the image (= local row HP)
+    if (pr == HP) {
+      if (tile_top) {
+        if (top_edge) {
+#pragma unroll
+          for (int r = 0; r < HP; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) hs[r][q][i] = hs[HP][q][i];
+        }
+      }
+    }
+    if (pr < 2 * HP) continue;
+    const int orow = pr - 2 * HP;          // output row ybase + orow
+    float acc[3][4];
+    if constexpr (BS == 3) {
+      // out(r) = hs[r] + (hs[r+1] + hs[r+2]);  out(r+1) = (hs[r+1] + hs[r+2]) + hs[r+3]
+      if ((orow & 1) == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            vq[q][i] = hs[orow + 1][q][i] + hs[orow + 2][q][i];
+            acc[q][i] = hs[orow][q][i] + vq[q][i];
+          }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[q][i] = vq[q][i] + hs[orow + 2][q][i];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float sacc = hs[orow][q][i];
+#pragma unroll
+          for (int dy = 1; dy < BS; ++dy) sacc += hs[orow + dy][q][i];
+          acc[q][i] = sacc;
+        }
+    }
+    if (ybase + orow >= h) continue;
+    float out[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = lambda_min(acc[0][i], acc[1][i], acc[2][i]);
+    float *dst = score + ((size_t)img * h + (ybase + orow)) * w + x;
+    *reinterpret_cast<float4 *>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+  }
 }
 
 template <int BS, int R>
@@ -41,7 +237,7 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(const float *__restric
   __shared__ float4 tile[LH][LW4];
 
   const int t = threadIdx.x;
-  int bid = blockIdx.x;
+  int bid = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);   // neighbouring tiles share an XCD's L2
   const int tx_tile = bid % tiles_x;
   bid /= tiles_x;
   const int ty_tile = bid % tiles_y;
@@ -82,100 +278,77 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(const float *__restric
     }
   }
   __syncthreads();
+  corner_compute<BS, R>(&tile[0][0], score, img, h, w, x0, y0, t);
+}
 
-  const int tx = t & 31, ty = t >> 5;
-  const int x = x0 + 4 * tx;
-  const int ybase = y0 + ty * R;
-  if (x >= w || ybase >= h) return;
-  const bool left_edge = (x == 0);
-  const bool right_edge = (x + 4 >= w);
-  const bool top_edge = (ybase == 0);
+// Streaming form: persistent workgroups, two LDS buffers, the next tile arrives by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no wave stalled on the load) while the current
+// tile is being computed.  Each wave issues NCH 1-KiB DMA pieces per tile; the LDS image is the
+// same linear [LH][LW4] float4 array (chunk i of the tile at byte 16*i), so lane l of piece q
+// lands exactly where the register-staged kernel would have stored chunk q*256 + t.
+//   loop:  s_waitcnt vmcnt(R): THIS tile's DMA has landed (the previous tile's R stores, issued
+//          later, may still be in flight); barrier; issue DMA(next tile -> other buffer); compute
+// Row clamping is done by the DMA source address itself; chunks left/right of the image are
+// fetched from a clamped (valid) address and replaced by the edge pixel in registers
+// (corner_compute), so no LDS access ever has to wait for an in-flight DMA.
+template <int BS, int R>
+__global__ __launch_bounds__(256) void corner_stream_kernel(const float *__restrict__ image,
+                                                            float *__restrict__ score, int h, int w,
+                                                            int tiles_x, int tiles_y, int total_tiles) {
+  constexpr int HP = BS / 2, HL = HP + 1, TH = 8 * R, LH = TH + 2 * HL;
+  constexpr int NCH = (LH * LW4 + 255) / 256;   // DMA pieces per wave per tile
+  constexpr int BUF = NCH * 256;                // float4 slots per buffer (tail slots are scratch)
+  __shared__ float4 lds[2 * BUF];
 
-  float win[3][12];       // rolling image rows, columns x-4 .. x+7
-  float hs[NP][3][4];     // horizontally summed products per product row (xx, yy, xy)
+  const int t = threadIdx.x;
+  const int wave_base = t & ~63;
 
+  auto decode = [&](int v, int &img, int &x0, int &y0) {
+    int id = (int)xcd_contiguous_id((unsigned)v, (unsigned)total_tiles);
+    const int tx_tile = id % tiles_x;
+    id /= tiles_x;
+    const int ty_tile = id % tiles_y;
+    img = id / tiles_y;
+    x0 = tx_tile * TW;
+    y0 = ty_tile * TH;
+  };
+  auto issue = [&](int v, int buf) {
+    int img, x0, y0;
+    decode(v, img, x0, y0);
+    const float *im = image + (size_t)img * h * w;
 #pragma unroll
-  for (int ir = 0; ir < R + 2 * HL; ++ir) {
-    // image row (ybase - HL + ir) lives in LDS row ty*R + ir
-    {
-      const float4 *src = &tile[ty * R + ir][tx];
-      const float4 a = src[0], b = src[1], c = src[2];
-      float *d = win[ir % 3];
-      d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
-      d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
-      d[8] = c.x; d[9] = c.y; d[10] = c.z; d[11] = c.w;
+    for (int q = 0; q < NCH; ++q) {
+      int i = t + q * 256;
+      if (i >= LH * LW4) i = 0;                                   // scratch slots: any valid source
+      const int r = i / LW4, c = i - r * LW4;
+      const int gy = clampi(y0 - HL + r, 0, h - 1);
+      const int gx = clampi(x0 - LPAD + 4 * c, 0, w - 4);
+      __builtin_amdgcn_global_load_lds(im + (size_t)gy * w + gx,
+                                       (__attribute__((address_space(3))) void *)&lds[buf * BUF + q * 256 + wave_base],
+                                       16, 0, 0);
     }
-    if (ir < 2) continue;
-    const int pr = ir - 2;                 // product row index, global row ybase - HP + pr
-    const float *top = win[(ir - 2) % 3], *mid = win[(ir - 1) % 3], *bot = win[ir % 3];
-    const int gy = ybase - HP + pr;
+  };
 
-    // separable Sobel: vertical 1-2-1 / difference per column, then the horizontal taps
-    float sm[NG + 2], df[NG + 2];
-#pragma unroll
-    for (int k = 0; k < NG + 2; ++k) {
-      const int q = 3 - HP + k;            // window column of gradient column k-1
-      sm[k] = (top[q] + bot[q]) + 2.0f * mid[q];
-      df[k] = bot[q] - top[q];
-    }
-    float gx_[NG], gy_[NG];
-#pragma unroll
-    for (int j = 0; j < NG; ++j) {
-      gx_[j] = sm[j + 2] - sm[j];
-      gy_[j] = (df[j] + df[j + 2]) + 2.0f * df[j + 1];
-    }
-    // replicate padding of the PRODUCT maps == gradients taken at the clamped column
-    if (left_edge) {
-#pragma unroll
-      for (int j = 0; j < HP; ++j) { gx_[j] = gx_[HP]; gy_[j] = gy_[HP]; }
-    }
-    if (right_edge) {
-#pragma unroll
-      for (int j = 0; j < HP; ++j) { gx_[4 + HP + j] = gx_[3 + HP]; gy_[4 + HP + j] = gy_[3 + HP]; }
-    }
-    float pxx[NG], pyy[NG], pxy[NG];
-#pragma unroll
-    for (int j = 0; j < NG; ++j) {
-      pxx[j] = gx_[j] * gx_[j];
-      pyy[j] = gy_[j] * gy_[j];
-      pxy[j] = gx_[j] * gy_[j];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float a = pxx[i], c = pyy[i], b = pxy[i];
-#pragma unroll
-      for (int dx = 1; dx < BS; ++dx) { a += pxx[i + dx]; c += pyy[i + dx]; b += pxy[i + dx]; }
-      hs[pr][0][i] = a; hs[pr][1][i] = c; hs[pr][2][i] = b;
-    }
-    // rows below the image repeat the last in-image product row
-    if (pr > 0 && gy > h - 1) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) hs[pr][q][i] = hs[pr - 1][q][i];
-    }
-    if (pr < 2 * HP) continue;
-    const int orow = pr - 2 * HP;          // output row ybase + orow
-    if (ybase + orow >= h) continue;
-    float out[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float acc[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        float s = 0.0f;
-#pragma unroll
-        for (int dy = 0; dy < BS; ++dy) {
-          const int r = orow + dy;         // product row; rows above the image repeat row `HP`
-          const float v = (top_edge && r < HP) ? hs[HP][q][i] : hs[r][q][i];
-          s = (dy == 0) ? v : s + v;
-        }
-        acc[q] = s;
-      }
-      out[i] = lambda_min(acc[0], acc[1], acc[2]);
-    }
-    float *dst = score + ((size_t)img * h + (ybase + orow)) * w + x;
-    *reinterpret_cast<float4 *>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+  int v = blockIdx.x;
+  if (v >= total_tiles) return;
+  issue(v, 0);
+  bool prev_full = false;                         // previous tile issued exactly R stores per lane
+  for (int it = 0; v < total_tiles; v += gridDim.x, ++it) {
+    const int cur = it & 1;
+    const int nxt = v + (int)gridDim.x;
+    // This tile's DMA pieces were issued BEFORE the previous tile's R stores, and vmcnt retires
+    // in issue order: leaving R operations outstanding waits for the DMA but not for the stores.
+    if (prev_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // One barrier per tile: every wave's pieces have landed, and every wave has finished
+    // computing the previous tile, whose buffer the next DMA is about to overwrite.
+    __builtin_amdgcn_s_barrier();
+    if (nxt < total_tiles) issue(nxt, cur ^ 1);
+    int img, x0, y0;
+    decode(v, img, x0, y0);
+    prev_full = (x0 + TW <= w) && (y0 + TH <= h);  // workgroup-uniform
+    const float4 *tile = &lds[cur * BUF];
+    corner_compute<BS, R>(tile, score, img, h, w, x0, y0, t);
   }
 }
 
@@ -223,7 +396,34 @@ int launch_tile(const float *image, int n, int h, int w, float *score, hipStream
   return mi_launch_status();
 }
 
+// Persistent grid: 2 workgroups per CU (2 x 80 KiB of LDS) on the 256 CUs of an MI355X.
+template <int BS, int R>
+int launch_stream(const float *image, int n, int h, int w, float *score, hipStream_t s) {
+  const int tiles_x = ceil_div(w, TW), tiles_y = ceil_div(h, 8 * R);
+  const long long total = (long long)n * tiles_x * tiles_y;
+  if (total > 0x7fffffffLL) return MI_E_SHAPE;
+  // persistent grid: as many workgroups per CU as two LDS buffers allow, on 256 CUs
+  constexpr int LH = 8 * R + 2 * (BS / 2 + 1);
+  constexpr int LDS_BYTES = 2 * ((LH * LW4 + 255) / 256) * 256 * 16;
+  constexpr int PER_CU = (160 * 1024) / LDS_BYTES;
+  const int resident = 256 * (PER_CU > 8 ? 8 : PER_CU);
+  const int grid = total < resident ? (int)total : resident;
+  hipLaunchKernelGGL((corner_stream_kernel<BS, R>), dim3(grid), dim3(256), 0, s, image, score, h, w, tiles_x,
+                     tiles_y, (int)total);
+  return mi_launch_status();
+}
+
+int g_corner_impl = 0;   // 0 = streaming (LDS-DMA) kernel, 1 = register-staged tile kernel
+int g_corner_rows = 8;   // rows per thread of the streaming kernel (tile height = 8 * rows)
+
 }  // namespace
+
+// Development/test hook: select between equivalent kernel implementations (results identical).
+extern "C" int mi_debug_set(int key, int value) {
+  if (key == 1) { g_corner_impl = value; return MI_OK; }
+  if (key == 2 && (value == 4 || value == 5 || value == 8)) { g_corner_rows = value; return MI_OK; }
+  return MI_E_PARAM;
+}
 
 extern "C" int mi_corner_response(const float *image, int n, int h, int w, int block_size, float *score,
                                   mi_stream_t stream) {
@@ -233,6 +433,11 @@ extern "C" int mi_corner_response(const float *image, int n, int h, int w, int b
   hipStream_t s = (hipStream_t)stream;
   const bool aligned = (w % 4 == 0) && (((uintptr_t)image | (uintptr_t)score) % 16 == 0);
   if (aligned && h >= 4 && w >= 8) {
+    if (block_size == 3 && g_corner_impl == 0) {
+      if (g_corner_rows == 4) return launch_stream<3, 4>(image, n, h, w, score, s);
+      if (g_corner_rows == 5) return launch_stream<3, 5>(image, n, h, w, score, s);
+      return launch_stream<3, 8>(image, n, h, w, score, s);
+    }
     if (block_size == 3) return launch_tile<3, 8>(image, n, h, w, score, s);
     if (block_size == 5) return launch_tile<5, 8>(image, n, h, w, score, s);
     if (block_size == 7) return launch_tile<7, 8>(image, n, h, w, score, s);

@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256) void nms_fast_kernel(const float *__restrict__
   __shared__ float4 pb[LH][NT_W / 4];          // horizontal window maxima
 
   const int t = threadIdx.x;
-  const int seg_id = blockIdx.x;
-  int bid = blockIdx.x;
+  const int seg_id = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);   // neighbouring tiles share an XCD's L2
+  int bid = seg_id;
   const int tx_tile = bid % tiles_x;
   bid /= tiles_x;
   const int ty_tile = bid % tiles_y;

@@ -90,8 +90,19 @@ def select_topk(scores: torch.Tensor, mask: torch.Tensor, k: int, score_threshol
     return _topk_from_candidates(cand, count, seg, cap, b, h, w, k)
 
 
+def bad_plan(pair_geom: torch.Tensor, pair_thr: torch.Tensor) -> torch.Tensor:
+    """Device-resident fast-path plan for a pair table (built once; see mi_bad_plan_build)."""
+    p = pair_geom.numel()
+    nbytes = int(N.load().mi_bad_plan_bytes(p))
+    plan = torch.empty(((nbytes + 15) // 16 * 2,), dtype=torch.int64, device=pair_geom.device)
+    N.call("mi_bad_plan_build", N.dev(pair_geom, torch.int32, "pair_geom"), N.dev(pair_thr, F32, "pair_thr"), p,
+           plan.data_ptr(), N.stream_ptr())
+    return plan
+
+
 def sparse_bad(image: torch.Tensor, keypoints: torch.Tensor, pair_geom: torch.Tensor, pair_thr: torch.Tensor,
-               mode: int, temperature: float, normalize: bool, want_desc: bool = True, want_bits: bool = False):
+               mode: int, temperature: float, normalize: bool, want_desc: bool = True, want_bits: bool = False,
+               plan: torch.Tensor | None = None):
     img = _images(image, "image")
     n, _, h, w = img.shape
     if keypoints.dim() != 3 or keypoints.shape[0] != n or keypoints.shape[2] != 2:
@@ -104,7 +115,7 @@ def sparse_bad(image: torch.Tensor, keypoints: torch.Tensor, pair_geom: torch.Te
     N.call("mi_sparse_bad", N.dev(img, F32, "image"), n, h, w, N.dev(kp, F32, "keypoints"), k,
            N.dev(pair_geom, torch.int32, "pair_geom"), N.dev(pair_thr, F32, "pair_thr"), p, int(mode),
            float(temperature), int(bool(normalize)), desc.data_ptr() if want_desc else None,
-           bits.data_ptr() if want_bits else None, N.stream_ptr())
+           bits.data_ptr() if want_bits else None, plan.data_ptr() if plan is not None else None, N.stream_ptr())
     return desc, bits
 
 

@@ -58,6 +58,8 @@ class SparseBAD(nn.Module):
         geom = b[:, 0] | (b[:, 1] << 5) | (b[:, 2] << 10) | (b[:, 3] << 15) | (b[:, 4] << 20)
         self.register_buffer("pair_geom", geom.to(torch.int32), persistent=False)
         self.register_buffer("pair_thr", thr.clone(), persistent=False)
+        self._plan = None          # device-side fast-path plan, built lazily per device
+        self.use_fast_path = True  # tests switch this off to exercise the general kernel path
 
     @property
     def mode(self) -> int:
@@ -76,11 +78,18 @@ class SparseBAD(nn.Module):
                 "move the module with .to(device)"
             )
 
+    def _get_plan(self):
+        if not self.use_fast_path or self.mode != N.MI_BAD_HARD:
+            return None
+        if self._plan is None or self._plan.device != self.pair_geom.device:
+            self._plan = ops.bad_plan(self.pair_geom, self.pair_thr)
+        return self._plan
+
     @torch.no_grad()
     def forward(self, image: torch.Tensor, keypoints: torch.Tensor, orientation: torch.Tensor | None = None):
         self._check(image, orientation)
         desc, _ = ops.sparse_bad(image, keypoints, self.pair_geom, self.pair_thr, self.mode, self.temperature,
-                                 self.normalize_descriptors, want_desc=True, want_bits=False)
+                                 self.normalize_descriptors, want_desc=True, want_bits=False, plan=self._get_plan())
         return desc
 
     @torch.no_grad()
@@ -91,5 +100,5 @@ class SparseBAD(nn.Module):
             raise RuntimeError("forward_bits needs binarize=True, soft_binarize=False")
         self._check(image, None)
         _, bits = ops.sparse_bad(image, keypoints, self.pair_geom, self.pair_thr, N.MI_BAD_HARD, self.temperature,
-                                 self.normalize_descriptors, want_desc=False, want_bits=True)
+                                 self.normalize_descriptors, want_desc=False, want_bits=True, plan=self._get_plan())
         return bits

@@ -145,6 +145,27 @@ def test_sparse_bad_modes_vs_oracle(mods, num_pairs):
         assert np.all(got[0, 5] == 0)
 
 
+def test_sparse_bad_fast_path_equals_general(mods):
+    """The int32 fast path (interior integer keypoints on uint8 patches) and the general fp64 path give
+    identical bits and descriptors; non-integer pixels or fractional keypoints fall back per keypoint."""
+    a, _ = synth_batch(910, 2, 240, 320)
+    a[1, 0, 100:140, 100:180] += 0.5                                            # non-integer patch region
+    rng = np.random.default_rng(4)
+    kp = np.stack([rng.integers(0, 240, (2, 300)), rng.integers(0, 320, (2, 300))], -1).astype(np.float32)
+    kp[0, :6] = [(15, 15), (14, 15), (225, 305), (226, 305), (15, 306), (-1, -1)]   # eligibility edges
+    kp[0, 6] = (100.5, 50.0)                                                    # fractional keypoint
+    box, thr = bad_tables(512)
+    for kw in (dict(normalize_descriptors=True), dict(normalize_descriptors=False)):
+        fast = mods["SparseBAD"](512, binarize=True, soft_binarize=False, **kw).to(DEV)
+        slow = mods["SparseBAD"](512, binarize=True, soft_binarize=False, **kw).to(DEV)
+        slow.use_fast_path = False
+        assert torch.equal(fast(gpu(a), gpu(kp)), slow(gpu(a), gpu(kp)))
+        bf = fast.forward_bits(gpu(a), gpu(kp))
+        assert torch.equal(bf, slow.forward_bits(gpu(a), gpu(kp)))
+        _, aux = O.sparse_bad(a, kp, box, thr, binarize=True, soft_binarize=False, return_aux=True, **kw)
+        assert np.array_equal(bf.cpu().numpy().view(np.uint32), O.pack_bits(aux["bits"]))
+
+
 # ------------------------------------------------------------------ K5 / K6
 def test_sinkhorn_unit_golden(mods):
     g = load_golden("sinkhorn_unit")

@@ -51,8 +51,14 @@ def main():
     res = {}
     score = ops.corner_response(img, 3)
     if "corner" in args.which:
-        ms = timeit(lambda: ops.corner_response(img, 3), args.iters)
-        res["corner"] = (ms, 8.0 * px / ms / 1e6)
+        for impl, rows, name in ((1, 8, "corner(tile)"), (0, 8, "corner(stream R=8)"), (0, 5, "corner(stream R=5)"),
+                                 (0, 4, "corner(stream R=4)")):
+            N.load().mi_debug_set(1, impl)
+            N.load().mi_debug_set(2, rows)
+            alt = ops.corner_response(img, 3)
+            assert torch.equal(alt, score), name
+            ms = timeit(lambda: ops.corner_response(img, 3), args.iters)
+            res[name] = (ms, 8.0 * px / ms / 1e6)
     sc = score.squeeze(1)
     if "nms" in args.which:
         cand, count, seg, cap = ops._candidate_buffers(n, H, W, dev)
