@@ -139,7 +139,7 @@ def main() -> None:
                        "pairs_per_gpu_per_step": B, "global_pairs_per_step": pairs_per_step,
                        "height": H, "width": W, "max_keypoints": K, "parallelism": f"pair-sharded x{world}",
                        "mean_valid_matches_per_pair": nvalid},
-            "roofline": {"kernel": "corner_tile_kernel<3,8> (mi_corner_response)", "bound": "hbm",
+            "roofline": {"kernel": "corner_stream_kernel<3,4> (mi_corner_response)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "bytes_per_launch": k1_bytes, "ms_per_launch": k1_ms},
             "kernels": kernels,

@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256) void corner_stream_kernel(const float *__restr
   const int t = threadIdx.x;
   const int wave_base = t & ~63;
 
+  // tile id -> (image, x0, y0).  Blockidx-derived, hence scalar (SGPR) arithmetic.
   auto decode = [&](int v, int &img, int &x0, int &y0) {
     int id = (int)xcd_contiguous_id((unsigned)v, (unsigned)total_tiles);
     const int tx_tile = id % tiles_x;
@@ -312,18 +313,22 @@ __global__ __launch_bounds__(256) void corner_stream_kernel(const float *__restr
     x0 = tx_tile * TW;
     y0 = ty_tile * TH;
   };
-  auto issue = [&](int v, int buf) {
-    int img, x0, y0;
-    decode(v, img, x0, y0);
+  // per-thread chunk coordinates of its NCH pieces never change: (row, 4*col) inside the tile
+  int prow[NCH], pcol[NCH];
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    int i = t + q * 256;
+    if (i >= LH * LW4) i = 0;                                     // scratch slots: any valid source
+    prow[q] = i / LW4 - HL;
+    pcol[q] = 4 * (i % LW4) - LPAD;
+  }
+  auto issue = [&](int img, int x0, int y0, int buf) {
     const float *im = image + (size_t)img * h * w;
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
-      int i = t + q * 256;
-      if (i >= LH * LW4) i = 0;                                   // scratch slots: any valid source
-      const int r = i / LW4, c = i - r * LW4;
-      const int gy = clampi(y0 - HL + r, 0, h - 1);
-      const int gx = clampi(x0 - LPAD + 4 * c, 0, w - 4);
-      __builtin_amdgcn_global_load_lds(im + (size_t)gy * w + gx,
+      const int gy = clampi(y0 + prow[q], 0, h - 1);
+      const int gx = clampi(x0 + pcol[q], 0, w - 4);
+      __builtin_amdgcn_global_load_lds(im + (gy * w + gx),
                                        (__attribute__((address_space(3))) void *)&lds[buf * BUF + q * 256 + wave_base],
                                        16, 0, 0);
     }
@@ -331,7 +336,9 @@ __global__ __launch_bounds__(256) void corner_stream_kernel(const float *__restr
 
   int v = blockIdx.x;
   if (v >= total_tiles) return;
-  issue(v, 0);
+  int img, x0, y0;
+  decode(v, img, x0, y0);
+  issue(img, x0, y0, 0);
   bool prev_full = false;                         // previous tile issued exactly R stores per lane
   for (int it = 0; v < total_tiles; v += gridDim.x, ++it) {
     const int cur = it & 1;
@@ -343,12 +350,15 @@ __global__ __launch_bounds__(256) void corner_stream_kernel(const float *__restr
     // One barrier per tile: every wave's pieces have landed, and every wave has finished
     // computing the previous tile, whose buffer the next DMA is about to overwrite.
     __builtin_amdgcn_s_barrier();
-    if (nxt < total_tiles) issue(nxt, cur ^ 1);
-    int img, x0, y0;
-    decode(v, img, x0, y0);
+    int nimg = 0, nx0 = 0, ny0 = 0;
+    if (nxt < total_tiles) {
+      decode(nxt, nimg, nx0, ny0);
+      issue(nimg, nx0, ny0, cur ^ 1);
+    }
     prev_full = (x0 + TW <= w) && (y0 + TH <= h);  // workgroup-uniform
     const float4 *tile = &lds[cur * BUF];
     corner_compute<BS, R>(tile, score, img, h, w, x0, y0, t);
+    img = nimg; x0 = nx0; y0 = ny0;
   }
 }
 
@@ -414,7 +424,7 @@ int launch_stream(const float *image, int n, int h, int w, float *score, hipStre
 }
 
 int g_corner_impl = 0;   // 0 = streaming (LDS-DMA) kernel, 1 = register-staged tile kernel
-int g_corner_rows = 8;   // rows per thread of the streaming kernel (tile height = 8 * rows)
+int g_corner_rows = 4;   // rows per thread of the streaming kernel (tile height = 8 * rows)
 
 }  // namespace
 
