@@ -129,6 +129,23 @@ int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, float dustbi
                 int iterations, float *u, float *v, float *p, void *workspace, size_t workspace_bytes,
                 mi_stream_t stream);
 
+/* ---- packed-descriptor form of the two calls above (hard-binarised descriptors, L2) -----------
+ * mi_cost_dots_bits stores the exact integer dot products popcount(a_i & b_j) as uint16
+ * (dots[b, i, j], row pitch `pitch` uint16 elements, pitch % 8 == 0, pitch >= m, 16-byte aligned)
+ * and, per descriptor, the pair (scale, squared norm) = (1/sqrt(pop), pop * scale^2) if
+ * `normalized` else (1, pop): row_info float[batch][n][2], col_info float[batch][m][2].
+ * mi_sinkhorn_dots runs the same iterations as mi_sinkhorn but rebuilds
+ *     z = -max(|a|^2 + |b|^2 - 2 * dot * s_a * s_b, 0) * (1/epsilon)
+ * in registers on every pass: 2 bytes per matrix element per iteration instead of 4.
+ * m <= 1024 (mi_sinkhorn_dots_workspace_bytes returns 0 otherwise: use the fp32 form). */
+int mi_cost_dots_bits(const uint32_t *bits1, const uint32_t *bits2, int batch, int n, int m, int num_bits,
+                      int normalized, uint16_t *dots, int pitch, float *row_info, float *col_info,
+                      mi_stream_t stream);
+size_t mi_sinkhorn_dots_workspace_bytes(int batch, int n, int m);
+int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch, int n,
+                     int m, int pitch, double epsilon, double unused_score, int iterations, float *u,
+                     float *v, float *p, void *workspace, size_t workspace_bytes, mi_stream_t stream);
+
 /* ---- matching/match_extraction.py:72-181  MutualNearestNeighborMatcher.forward --------------
  * p (batch, n+1, m+1); kpts1 (batch,n,2); kpts2 (batch,m,2).  Workspace: row_best (batch*n) u64,
  * col_best (batch*m) u64.  Outputs mk1/mk2 (batch,max_matches,2), scores (batch,max_matches),

@@ -35,10 +35,16 @@ SIGNATURES = {
     "mi_sinkhorn_workspace_bytes": [c_int, c_int, c_int],
     "mi_sinkhorn": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                     c_size_t, c_void_p],
+    "mi_cost_dots_bits": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                          c_void_p],
+    "mi_sinkhorn_dots_workspace_bytes": [c_int, c_int, c_int],
+    "mi_sinkhorn_dots": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_int,
+                         c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
     "mi_mnn_extract": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
 }
-_RESTYPE = {"mi_error_string": c_char_p, "mi_sinkhorn_workspace_bytes": c_size_t, "mi_bad_plan_bytes": c_size_t}
+_RESTYPE = {"mi_error_string": c_char_p, "mi_sinkhorn_workspace_bytes": c_size_t, "mi_bad_plan_bytes": c_size_t,
+            "mi_sinkhorn_dots_workspace_bytes": c_size_t}
 
 MI_BAD_RAW, MI_BAD_SOFT, MI_BAD_HARD = 0, 1, 2
 MI_DIST_L2, MI_DIST_L1 = 0, 1

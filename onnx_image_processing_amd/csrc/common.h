@@ -27,6 +27,31 @@ __device__ __forceinline__ unsigned xcd_contiguous_id(unsigned bid, unsigned nbl
   return base + k;
 }
 
+// Wave-wide reductions on the DPP path (VALU with lane-select modifiers: no LDS crossbar round
+// trips as with __shfl/ds_bpermute).  quad_perm -> row_half_mirror -> row_mirror leave every
+// lane of a 16-lane row with its row's result; row_bcast15 / row_bcast31 fold the four rows into
+// lane 63, which v_readlane broadcasts as a scalar.  Returns the same value in every lane.
+#define MI_DPP(old, src, ctrl, rmask) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), ctrl, rmask, 0xf, false))
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, MI_DPP(v, v, 0xB1, 0xf));    // quad_perm [1,0,3,2]
+  v = fmaxf(v, MI_DPP(v, v, 0x4E, 0xf));    // quad_perm [2,3,0,1]
+  v = fmaxf(v, MI_DPP(v, v, 0x141, 0xf));   // row_half_mirror
+  v = fmaxf(v, MI_DPP(v, v, 0x140, 0xf));   // row_mirror
+  v = fmaxf(v, MI_DPP(v, v, 0x142, 0xa));   // row_bcast15 into rows 1 and 3
+  v = fmaxf(v, MI_DPP(v, v, 0x143, 0xc));   // row_bcast31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += MI_DPP(0.0f, v, 0xB1, 0xf);
+  v += MI_DPP(0.0f, v, 0x4E, 0xf);
+  v += MI_DPP(0.0f, v, 0x141, 0xf);
+  v += MI_DPP(0.0f, v, 0x140, 0xf);
+  v += MI_DPP(0.0f, v, 0x142, 0xa);
+  v += MI_DPP(0.0f, v, 0x143, 0xc);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -32,10 +32,18 @@ __device__ __forceinline__ v4i spread16(uint32_t half) {
 
 constexpr int CB_T = 128;  // block tile edge (bits path)
 
+// DOTS = false: write z = -cost/eps as fp32 (pitch in floats).
+// DOTS = true : write the exact integer dot products as uint16 (pitch in uint16 elements) plus the
+//               per-descriptor (scale, squared norm) pairs; K6 rebuilds z from them on the fly,
+//               which halves the bytes every Sinkhorn iteration has to stream.
+template <bool DOTS>
 __global__ __launch_bounds__(256) void cost_bits_kernel(const uint32_t *__restrict__ bits1,
                                                         const uint32_t *__restrict__ bits2, int n, int m,
                                                         int words, int normalized, float eps,
-                                                        float *__restrict__ z, int pitch) {
+                                                        float *__restrict__ z, int pitch,
+                                                        uint16_t *__restrict__ dots,
+                                                        float2 *__restrict__ row_info,
+                                                        float2 *__restrict__ col_info) {
   extern __shared__ uint32_t lds_u[];
   const int wp = words + 1;                          // +1 word: conflict-free column reads
   uint32_t *sa = lds_u;                              // [128][wp]
@@ -96,23 +104,52 @@ __global__ __launch_bounds__(256) void cost_bits_kernel(const uint32_t *__restri
         acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
   }
 
-  float *zb = z + (size_t)b * (size_t)n * pitch;
+  if constexpr (DOTS) {
+    // per-descriptor (scale, squared norm): written once, by the first tile column / row
+    if (blockIdx.x == 0 && t < CB_T && i0 + t < n) row_info[(size_t)b * n + i0 + t] = make_float2(inv_a[t], nrm_a[t]);
+    if (blockIdx.y == 0 && t < CB_T && j0 + t < m) col_info[(size_t)b * m + j0 + t] = make_float2(inv_b[t], nrm_b[t]);
+    __syncthreads();                                    // bit tiles are dead: reuse LDS as the u16 staging tile
+    constexpr int SP16 = CB_T + 8;                      // staging pitch (uint16), rows stay 16-byte aligned
+    uint16_t *stage = reinterpret_cast<uint16_t *>(lds_u);
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int rl = wm + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const int cl = wn + ni * 32 + lr;
-        const int gi = i0 + rl, gj = j0 + cl;
-        if (gi < n && gj < m) {
-          const float dot = (float)acc[mi][ni][e];
-          const float cross = dot * (inv_a[rl] * inv_b[cl]);
-          const float cost = fmaxf((nrm_a[rl] + nrm_b[cl]) - 2.0f * cross, 0.0f);   // sinkhorn.py:101-103
-          zb[(size_t)gi * pitch + gj] = -cost / eps;                                 // sinkhorn.py:178
+        for (int e = 0; e < 16; ++e) {
+          const int rl = wm + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          const int cl = wn + ni * 32 + lr;
+          stage[rl * SP16 + cl] = (uint16_t)acc[mi][ni][e];
         }
-      }
+    __syncthreads();
+    uint16_t *db = dots + (size_t)b * (size_t)n * pitch;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int id = t + 256 * k;
+      const int row = id >> 4, c8 = (id & 15) * 8;
+      if (i0 + row < n && j0 + c8 < m)                  // pitch >= round_up(m, 8): the 16-byte store stays in the row
+        *reinterpret_cast<uint4 *>(db + (size_t)(i0 + row) * pitch + j0 + c8) =
+            *reinterpret_cast<const uint4 *>(stage + row * SP16 + c8);
+    }
+  } else {
+    float *zb = z + (size_t)b * (size_t)n * pitch;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int rl = wm + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          const int cl = wn + ni * 32 + lr;
+          const int gi = i0 + rl, gj = j0 + cl;
+          if (gi < n && gj < m) {
+            const float dot = (float)acc[mi][ni][e];
+            const float cross = dot * (inv_a[rl] * inv_b[cl]);
+            const float cost = fmaxf((nrm_a[rl] + nrm_b[cl]) - 2.0f * cross, 0.0f);   // sinkhorn.py:101-103
+            zb[(size_t)gi * pitch + gj] = -cost / eps;                                 // sinkhorn.py:178
+          }
+        }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -229,8 +266,28 @@ extern "C" int mi_cost_logscores_bits(const uint32_t *bits1, const uint32_t *bit
   const int words = num_bits / 32;
   const size_t lds = (size_t)2 * CB_T * (words + 1) * 4 + 4 * CB_T * 4;
   dim3 grid(ceil_div(m, CB_T), ceil_div(n, CB_T), batch);
-  hipLaunchKernelGGL(cost_bits_kernel, grid, dim3(256), lds, (hipStream_t)stream, bits1, bits2, n, m, words,
-                     normalized, (float)epsilon, z, pitch);
+  hipLaunchKernelGGL(cost_bits_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, bits1, bits2, n, m,
+                     words, normalized, (float)epsilon, z, pitch, nullptr, nullptr, nullptr);
+  return mi_launch_status();
+}
+
+extern "C" int mi_cost_dots_bits(const uint32_t *bits1, const uint32_t *bits2, int batch, int n, int m,
+                                 int num_bits, int normalized, uint16_t *dots, int pitch, float *row_info,
+                                 float *col_info, mi_stream_t stream) {
+  if (!bits1 || !bits2 || !dots || !row_info || !col_info) return MI_E_NULL;
+  if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
+  if (pitch < m || pitch % 8 != 0 || ((uintptr_t)dots % 16) != 0 || ((uintptr_t)row_info % 8) != 0 ||
+      ((uintptr_t)col_info % 8) != 0)
+    return MI_E_ALIGN;
+  if (num_bits <= 0 || num_bits % 32 != 0 || num_bits > 4096) return MI_E_PARAM;   // dot <= 4096 fits uint16
+  const int words = num_bits / 32;
+  size_t lds = (size_t)2 * CB_T * (words + 1) * 4 + 4 * CB_T * 4;
+  const size_t stage = (size_t)CB_T * (CB_T + 8) * 2;
+  if (lds < stage) lds = stage;
+  dim3 grid(ceil_div(m, CB_T), ceil_div(n, CB_T), batch);
+  hipLaunchKernelGGL(cost_bits_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, bits1, bits2, n, m, words,
+                     normalized, 1.0f, nullptr, pitch, dots, reinterpret_cast<float2 *>(row_info),
+                     reinterpret_cast<float2 *>(col_info));
   return mi_launch_status();
 }
 

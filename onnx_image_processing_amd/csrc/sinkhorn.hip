@@ -239,14 +239,15 @@ __global__ __launch_bounds__(256) void sk_exp_kernel(const float *__restrict__ z
 // 4 B/element once instead of twice; partials are 8 B per column per band (~6 % extra).
 // Band index nb = number of row bands carries the dustbin ROW (x = dust + u_n, computed
 // without Z); column index m of every partial carries the dustbin COLUMN (x = dust + u_i).
-template <int E4, int RW>
-__global__ __launch_bounds__(256) void sk_band_kernel(const float *__restrict__ z, int n, int m, int pitch,
+template <int E4, int RW, int NW>
+__global__ __launch_bounds__(64 * NW) void sk_band_kernel(const float *__restrict__ z, int n, int m, int pitch,
                                                       float dust, const float *__restrict__ v,
                                                       float *__restrict__ u, float2 *__restrict__ part,
                                                       float log_m, int v_is_zero) {
-  constexpr int BAND = 4 * RW;
-  __shared__ float red_m[4][256 * E4 + 1];
-  __shared__ float red_s[4][256 * E4 + 1];
+  constexpr int BAND = NW * RW;   // NW waves x RW rows each
+  constexpr int NT = 64 * NW;
+  __shared__ float red_m[NW][256 * E4 + 1];
+  __shared__ float red_s[NW][256 * E4 + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y, band = blockIdx.x, nb = gridDim.x - 1;
   const float *vb = v + (size_t)b * (m + 1);
@@ -256,20 +257,25 @@ __global__ __launch_bounds__(256) void sk_band_kernel(const float *__restrict__ 
   if (band == nb) {
     // dustbin row: u_n = log m - LSE_j(dust + v_j), then its term for every column
     float mx = dust + vd;
-    for (int j = threadIdx.x; j < m; j += 256) mx = fmaxf(mx, dust + (v_is_zero ? 0.0f : vb[j]));
-    mx = wave_max(mx);
+    for (int j = threadIdx.x; j < m; j += NT) mx = fmaxf(mx, dust + (v_is_zero ? 0.0f : vb[j]));
+    mx = wave_max_dpp(mx);
     if (lane == 0) red_m[wave][0] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red_m[0][0], red_m[1][0]), fmaxf(red_m[2][0], red_m[3][0]));
+    mx = red_m[0][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red_m[w][0]);
     float s = 0.0f;
-    for (int j = threadIdx.x; j < m; j += 256) s += expf((dust + (v_is_zero ? 0.0f : vb[j])) - mx);
-    s = wave_sum(s);
+    for (int j = threadIdx.x; j < m; j += NT) s += expf((dust + (v_is_zero ? 0.0f : vb[j])) - mx);
+    s = wave_sum_dpp(s);
     if (lane == 0) red_s[wave][0] = s;
     __syncthreads();
-    s = ((red_s[0][0] + red_s[1][0]) + (red_s[2][0] + red_s[3][0])) + expf((dust + vd) - mx);
+    s = red_s[0][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s += red_s[w][0];
+    s += expf((dust + vd) - mx);
     const float un = log_m - (logf(s) + mx);
     if (threadIdx.x == 0) u[(size_t)b * (n + 1) + n] = un;
-    for (int j = threadIdx.x; j <= m; j += 256) pb[j] = make_float2(dust + un, 1.0f);
+    for (int j = threadIdx.x; j <= m; j += NT) pb[j] = make_float2(dust + un, 1.0f);
     return;
   }
 
@@ -311,13 +317,13 @@ __global__ __launch_bounds__(256) void sk_band_kernel(const float *__restrict__ 
     for (int e = 0; e < E4; ++e)
 #pragma unroll
       for (int q = 0; q < 4; ++q) mx = fmaxf(mx, zr[r][e][q] + vv[e][q]);
-    mx = wave_max(mx);
+    mx = wave_max_dpp(mx);
     float s = 0.0f;
 #pragma unroll
     for (int e = 0; e < E4; ++e)
 #pragma unroll
       for (int q = 0; q < 4; ++q) s += sk_exp((zr[r][e][q] + vv[e][q]) - mx);
-    s = wave_sum(s) + expf(xd - mx);
+    s = wave_sum_dpp(s) + expf(xd - mx);
     ur[r] = 0.0f - (logf(s) + mx);
     if (lane == 0 && row0 + r < n) u[(size_t)b * (n + 1) + row0 + r] = ur[r];
   }
@@ -351,14 +357,16 @@ __global__ __launch_bounds__(256) void sk_band_kernel(const float *__restrict__ 
     if (lane == 0) { red_m[wave][256 * E4] = cm; red_s[wave][256 * E4] = cs; }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c <= 256 * E4; c += 256) {
+  for (int c = threadIdx.x; c <= 256 * E4; c += NT) {
     const int j = (c == 256 * E4) ? m : c;
     if (c < 256 * E4 && j >= m) continue;
-    float fm = fmaxf(fmaxf(red_m[0][c], red_m[1][c]), fmaxf(red_m[2][c], red_m[3][c]));
+    float fm = red_m[0][c];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) fm = fmaxf(fm, red_m[w][c]);
     float fs = 0.0f;
     if (fm > -INFINITY) {
 #pragma unroll
-      for (int w = 0; w < 4; ++w)
+      for (int w = 0; w < NW; ++w)
         if (red_m[w][c] > -INFINITY) fs += red_s[w][c] * expf(red_m[w][c] - fm);
     }
     pb[j] = make_float2(fm, fs);
@@ -382,12 +390,12 @@ __global__ __launch_bounds__(256) void sk_vcombine_kernel(const float2 *__restri
   v[(size_t)b * (m + 1) + j] = ((j == m) ? log_n : 0.0f) - (logf(s) + mx);
 }
 
-template <int E4, int RW>
+template <int E4, int RW, int NW>
 void launch_fused(const float *z, int batch, int n, int m, int pitch, float dust, int iterations, float *u,
                   float *v, float2 *part, float log_m, float log_n, hipStream_t s) {
-  const int nb = ceil_div(n, 4 * RW);
+  const int nb = ceil_div(n, NW * RW);
   for (int it = 0; it < iterations; ++it) {
-    hipLaunchKernelGGL((sk_band_kernel<E4, RW>), dim3(nb + 1, batch), dim3(256), 0, s, z, n, m, pitch, dust, v,
+    hipLaunchKernelGGL((sk_band_kernel<E4, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, z, n, m, pitch, dust, v,
                        u, part, log_m, it == 0 ? 1 : 0);
     hipLaunchKernelGGL(sk_vcombine_kernel, dim3(ceil_div(m + 1, 256), batch), dim3(256), 0, s, part, m, nb + 1,
                        v, log_n);
@@ -423,9 +431,9 @@ extern "C" int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, f
     if (workspace_bytes < need) return MI_E_CAPACITY;
     float2 *part = reinterpret_cast<float2 *>(workspace);
     const int e4 = ceil_div(m, 256);
-    if (e4 == 1) launch_fused<1, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, log_m, log_n, s);
-    else if (e4 == 2) launch_fused<2, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, log_m, log_n, s);
-    else launch_fused<4, 4>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, log_m, log_n, s);
+    if (e4 == 1) launch_fused<1, 4, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, log_m, log_n, s);
+    else if (e4 == 2) launch_fused<2, 4, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, log_m, log_n, s);
+    else launch_fused<4, 2, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, log_m, log_n, s);
     if (p) {
       hipLaunchKernelGGL(sk_exp_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, z, n, m, pitch,
                          dustbin_logscore, u, v, p);

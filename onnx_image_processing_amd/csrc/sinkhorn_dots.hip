@@ -1,0 +1,273 @@
+// K6 (packed-descriptor form): log-space Sinkhorn straight from the integer dot products.
+// Semantics: reference pytorch_model/matching/sinkhorn.py:95-103 (cost), :112-147 (iterations),
+// :178-206 (dustbins, marginals, exp) for hard-binarised descriptors.
+//
+// K5 stores dot(a_i, b_j) = popcount(a_i & b_j) as uint16 (exact) plus one (scale, squared norm)
+// pair per descriptor.  Every pass rebuilds
+//     z_ij = -max((|a_i|^2 + |b_j|^2) - 2 * dot_ij * (s_i * s_j), 0) * (1/epsilon)
+// in registers (7 VALU ops per element), so an iteration streams 2 bytes per matrix element
+// instead of 4: the loop is bandwidth-bound and this halves its bytes.  z here differs from the
+// fp32 path only in the last rounding (multiply by 1/epsilon instead of divide: <= 1 ulp of z).
+// Structure of the iteration is the band-fused one of sinkhorn.hip: a workgroup keeps a band of
+// rows in registers, computes their u, then the band's (max, sum) contribution to every column.
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ float sk_exp(float d) { return __builtin_amdgcn_exp2f(d * 1.4426950408889634f); }
+
+struct ZParams {
+  float neg_inv_eps;   // -1/epsilon
+  float dust;          // -unused_score/epsilon
+};
+
+__device__ __forceinline__ float z_of(float dot, float2 row, float2 col, float neg_inv_eps) {
+  const float cross = dot * (row.x * col.x);
+  const float cost = fmaxf((row.y + col.y) - 2.0f * cross, 0.0f);    // sinkhorn.py:101-103
+  return cost * neg_inv_eps;                                         // sinkhorn.py:178
+}
+
+// E8 = 16-byte (8 x uint16) loads per lane per row: covers m <= 512 * E8 columns.
+template <int E8, int RW, int NW>
+__global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *__restrict__ dots, int n, int m,
+                                                           int pitch, const float2 *__restrict__ row_info,
+                                                           const float2 *__restrict__ col_info, ZParams zp,
+                                                           const float *__restrict__ v, float *__restrict__ u,
+                                                           float2 *__restrict__ part, float log_m, int v_is_zero) {
+  constexpr int BAND = NW * RW;   // NW waves x RW rows each
+  constexpr int NT = 64 * NW;
+  constexpr int NC = 512 * E8;                     // columns covered by one wave
+  __shared__ float red_m[NW][NC + 1];
+  __shared__ float red_s[NW][NC + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, band = blockIdx.x, nb = gridDim.x - 1;
+  const float *vb = v + (size_t)b * (m + 1);
+  float2 *pb = part + ((size_t)b * (nb + 1) + band) * (size_t)(m + 1);
+  const float vd = v_is_zero ? 0.0f : vb[m];
+  const float dust = zp.dust;
+
+  if (band == nb) {
+    // dustbin row: u_n = log m - LSE_j(dust + v_j), then its term for every column
+    float mx = dust + vd;
+    for (int j = threadIdx.x; j < m; j += NT) mx = fmaxf(mx, dust + (v_is_zero ? 0.0f : vb[j]));
+    mx = wave_max_dpp(mx);
+    if (lane == 0) red_m[wave][0] = mx;
+    __syncthreads();
+    mx = red_m[0][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red_m[w][0]);
+    float s = 0.0f;
+    for (int j = threadIdx.x; j < m; j += NT) s += expf((dust + (v_is_zero ? 0.0f : vb[j])) - mx);
+    s = wave_sum_dpp(s);
+    if (lane == 0) red_s[wave][0] = s;
+    __syncthreads();
+    s = red_s[0][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s += red_s[w][0];
+    s += expf((dust + vd) - mx);
+    const float un = log_m - (logf(s) + mx);
+    if (threadIdx.x == 0) u[(size_t)b * (n + 1) + n] = un;
+    for (int j = threadIdx.x; j <= m; j += NT) pb[j] = make_float2(dust + un, 1.0f);
+    return;
+  }
+
+  // per-lane column data: v_j and the column descriptor's (scale, norm)
+  float vv[E8][8];
+  float2 ci[E8][8];
+#pragma unroll
+  for (int e = 0; e < E8; ++e)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = e * 512 + lane * 8 + q;
+      vv[e][q] = (j < m && !v_is_zero) ? vb[j] : 0.0f;
+      ci[e][q] = (j < m) ? col_info[(size_t)b * m + j] : make_float2(0.f, 0.f);
+    }
+  const float xd = dust + vd;
+  const int row0 = band * BAND + wave * RW;
+
+  uint4 raw[RW][E8];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int i = row0 + r;
+    const uint16_t *src = dots + ((size_t)b * n + (i < n ? i : 0)) * pitch;
+#pragma unroll
+    for (int e = 0; e < E8; ++e) {
+      const int j = e * 512 + lane * 8;
+      raw[r][e] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < n && j < m) raw[r][e] = *reinterpret_cast<const uint4 *>(src + j);   // pitch >= round_up(m,8)
+    }
+  }
+  float zr[RW][E8][8];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int i = row0 + r;
+    const float2 ri = row_info[(size_t)b * n + (i < n ? i : 0)];                   // wave-uniform
+#pragma unroll
+    for (int e = 0; e < E8; ++e) {
+      const uint32_t w4[4] = {raw[r][e].x, raw[r][e].y, raw[r][e].z, raw[r][e].w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = e * 512 + lane * 8 + q;
+        const float dot = (float)((q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu));
+        // outside the matrix (row padding, rows past n): -inf, i.e. no contribution anywhere
+        zr[r][e][q] = (i < n && j < m) ? z_of(dot, ri, ci[e][q], zp.neg_inv_eps) : -INFINITY;
+      }
+    }
+  }
+
+  // row pass (sinkhorn.py:139): u_i = log mu_i - LSE_j(Z_ij + v_j), dustbin column included
+  float ur[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    float mx = xd;
+#pragma unroll
+    for (int e = 0; e < E8; ++e)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) mx = fmaxf(mx, zr[r][e][q] + vv[e][q]);
+    mx = wave_max_dpp(mx);
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < E8; ++e)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += sk_exp((zr[r][e][q] + vv[e][q]) - mx);
+    s = wave_sum_dpp(s) + expf(xd - mx);
+    ur[r] = 0.0f - (logf(s) + mx);
+    if (lane == 0 && row0 + r < n) u[(size_t)b * (n + 1) + row0 + r] = ur[r];
+  }
+
+  // column partials over this wave's RW rows (sinkhorn.py:141: Z_ij + u_i)
+#pragma unroll
+  for (int e = 0; e < E8; ++e)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float cm = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < RW; ++r) cm = fmaxf(cm, zr[r][e][q] + ur[r]);
+      float cs = 0.0f;
+      if (cm > -INFINITY) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) cs += sk_exp((zr[r][e][q] + ur[r]) - cm);
+      }
+      red_m[wave][e * 512 + lane * 8 + q] = cm;
+      red_s[wave][e * 512 + lane * 8 + q] = cs;
+    }
+  {
+    // dustbin column: x_i = dust + u_i over this wave's valid rows (uniform across lanes)
+    float cm = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+      if (row0 + r < n) cm = fmaxf(cm, dust + ur[r]);
+    float cs = 0.0f;
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+      if (row0 + r < n) cs += expf((dust + ur[r]) - cm);
+    if (lane == 0) { red_m[wave][NC] = cm; red_s[wave][NC] = cs; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c <= NC; c += NT) {
+    const int j = (c == NC) ? m : c;
+    if (c < NC && j >= m) continue;
+    float fm = red_m[0][c];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) fm = fmaxf(fm, red_m[w][c]);
+    float fs = 0.0f;
+    if (fm > -INFINITY) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        if (red_m[w][c] > -INFINITY) fs += red_s[w][c] * expf(red_m[w][c] - fm);
+    }
+    pb[j] = make_float2(fm, fs);
+  }
+}
+
+// v_j = log nu_j - LSE over all bands' partials (including the dustbin-row band)
+__global__ __launch_bounds__(256) void sk_vcombine_dots_kernel(const float2 *__restrict__ part, int m, int nparts,
+                                                               float *__restrict__ v, float log_n) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j > m) return;
+  const float2 *p = part + (size_t)b * nparts * (size_t)(m + 1) + j;
+  float mx = -INFINITY;
+  for (int k = 0; k < nparts; ++k) mx = fmaxf(mx, p[(size_t)k * (m + 1)].x);
+  float s = 0.0f;
+  for (int k = 0; k < nparts; ++k) {
+    const float2 q = p[(size_t)k * (m + 1)];
+    if (q.x > -INFINITY) s += q.y * expf(q.x - mx);
+  }
+  v[(size_t)b * (m + 1) + j] = ((j == m) ? log_n : 0.0f) - (logf(s) + mx);
+}
+
+// P = exp(Z + u + v) over the augmented matrix; one wave per row
+__global__ __launch_bounds__(256) void sk_exp_dots_kernel(const uint16_t *__restrict__ dots, int n, int m, int pitch,
+                                                          const float2 *__restrict__ row_info,
+                                                          const float2 *__restrict__ col_info, ZParams zp,
+                                                          const float *__restrict__ u, const float *__restrict__ v,
+                                                          float *__restrict__ p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 4 + wave;
+  if (i > n) return;
+  const float ui = u[(size_t)b * (n + 1) + i];
+  const float *vb = v + (size_t)b * (m + 1);
+  const uint16_t *dr = dots + ((size_t)b * n + (i < n ? i : 0)) * pitch;
+  const float2 ri = row_info[(size_t)b * n + (i < n ? i : 0)];
+  float *pr = p + ((size_t)b * (n + 1) + i) * (size_t)(m + 1);
+  for (int j = lane; j <= m; j += 64) {
+    float zz = zp.dust;
+    if (i < n && j < m) zz = z_of((float)dr[j], ri, col_info[(size_t)b * m + j], zp.neg_inv_eps);
+    pr[j] = expf((zz + ui) + vb[j]);                         // sinkhorn.py:145,206
+  }
+}
+
+template <int E8, int RW, int NW>
+void launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int batch, int n, int m, int pitch,
+                 ZParams zp, int iterations, float *u, float *v, float2 *part, float log_m, float log_n,
+                 hipStream_t s) {
+  const int nb = ceil_div(n, NW * RW);
+  for (int it = 0; it < iterations; ++it) {
+    hipLaunchKernelGGL((sk_band_dots_kernel<E8, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, dots, n, m, pitch, ri,
+                       ci, zp, v, u, part, log_m, it == 0 ? 1 : 0);
+    hipLaunchKernelGGL(sk_vcombine_dots_kernel, dim3(ceil_div(m + 1, 256), batch), dim3(256), 0, s, part, m, nb + 1,
+                       v, log_n);
+  }
+}
+
+int dots_rows_per_band(int m) { return m <= 512 ? 32 : (m <= 1024 ? 16 : 0); }
+
+}  // namespace
+
+extern "C" size_t mi_sinkhorn_dots_workspace_bytes(int batch, int n, int m) {
+  const int band = dots_rows_per_band(m);
+  if (batch <= 0 || n <= 0 || m <= 0 || band == 0) return 0;
+  return (size_t)batch * (size_t)(ceil_div(n, band) + 1) * (size_t)(m + 1) * sizeof(float2);
+}
+
+extern "C" int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch,
+                                int n, int m, int pitch, double epsilon, double unused_score, int iterations,
+                                float *u, float *v, float *p, void *workspace, size_t workspace_bytes,
+                                mi_stream_t stream) {
+  if (!dots || !row_info || !col_info || !u || !v || !workspace) return MI_E_NULL;
+  if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
+  if (pitch < m || pitch % 8 != 0 || ((uintptr_t)dots % 16) != 0 || ((uintptr_t)workspace % 8) != 0) return MI_E_ALIGN;
+  if (iterations <= 0 || !(epsilon > 0.0)) return MI_E_PARAM;
+  const size_t need = mi_sinkhorn_dots_workspace_bytes(batch, n, m);
+  if (need == 0) return MI_E_PARAM;                 // m > 1024: use the fp32 form
+  if (workspace_bytes < need) return MI_E_CAPACITY;
+  hipStream_t s = (hipStream_t)stream;
+  const float log_m = logf((float)m), log_n = logf((float)n);      // sinkhorn.py:197-198
+  ZParams zp;
+  zp.neg_inv_eps = (float)(-1.0 / epsilon);
+  zp.dust = (float)(-unused_score / epsilon);
+  const float2 *ri = reinterpret_cast<const float2 *>(row_info);
+  const float2 *ci = reinterpret_cast<const float2 *>(col_info);
+  float2 *part = reinterpret_cast<float2 *>(workspace);
+  if (m <= 512) launch_dots<1, 4, 8>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, log_m, log_n, s);
+  else launch_dots<2, 2, 8>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, log_m, log_n, s);
+  if (p) {
+    hipLaunchKernelGGL(sk_exp_dots_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, dots, n, m, pitch, ri, ci,
+                       zp, u, v, p);
+  }
+  return mi_launch_status();
+}

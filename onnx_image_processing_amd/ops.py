@@ -161,6 +161,34 @@ def sinkhorn(z: torch.Tensor, m: int, pitch: int, dustbin_logscore: float, itera
     return (p, u, v) if return_duals else p
 
 
+def sinkhorn_bits(bits1: torch.Tensor, bits2: torch.Tensor, normalized: bool, epsilon: float, unused_score: float,
+                  iterations: int, return_duals: bool = False):
+    """Cost + Sinkhorn for packed hard-bit descriptors (B,N,D/32),(B,M,D/32) int32 -> P (B,N+1,M+1).
+    M <= 1024: the uint16 dot-product form (half the bytes per iteration); larger M: fp32 Z form."""
+    b, n, words = bits1.shape
+    m = bits2.shape[1]
+    dev = bits1.device
+    wbytes = int(N.load().mi_sinkhorn_dots_workspace_bytes(b, n, m))
+    if wbytes == 0:
+        z, pitch = cost_logscores_bits(bits1, bits2, normalized, epsilon)
+        return sinkhorn(z, m, pitch, -unused_score / epsilon, iterations, return_duals=return_duals)
+    pitch = (m + 7) // 8 * 8
+    dots = torch.empty((b, n, pitch), dtype=torch.int16, device=dev)
+    row_info = torch.empty((b, n, 2), dtype=F32, device=dev)
+    col_info = torch.empty((b, m, 2), dtype=F32, device=dev)
+    N.call("mi_cost_dots_bits", N.dev(bits1, torch.int32, "bits1"), N.dev(bits2, torch.int32, "bits2"), b, n, m,
+           words * 32, int(bool(normalized)), dots.data_ptr(), pitch, row_info.data_ptr(), col_info.data_ptr(),
+           N.stream_ptr())
+    u = torch.empty((b, n + 1), dtype=F32, device=dev)
+    v = torch.empty((b, m + 1), dtype=F32, device=dev)
+    p = torch.empty((b, n + 1, m + 1), dtype=F32, device=dev)
+    work = torch.empty((wbytes // 8,), dtype=torch.int64, device=dev)
+    N.call("mi_sinkhorn_dots", dots.data_ptr(), row_info.data_ptr(), col_info.data_ptr(), b, n, m, pitch,
+           float(epsilon), float(unused_score), int(iterations), u.data_ptr(), v.data_ptr(), p.data_ptr(),
+           work.data_ptr(), wbytes, N.stream_ptr())
+    return (p, u, v) if return_duals else p
+
+
 def mnn_extract(p: torch.Tensor, kpts1: torch.Tensor, kpts2: torch.Tensor, max_matches: int, threshold: float,
                 return_indices: bool = False):
     if p.dim() != 3:

@@ -28,6 +28,10 @@ class SinkhornMatcher(nn.Module):
         self.distance_type = distance_type.lower()
         if self.distance_type not in ("l1", "l2"):
             raise ValueError(f"distance_type must be 'l1' or 'l2', got {distance_type}")
+        # forward_bits only: keep the K x K dot products as uint16 and rebuild Z every pass (half the
+        # bytes per iteration, more arithmetic).  Measured slower than the fp32-Z form on MI355X at
+        # K = 512 (the iteration is not bandwidth-bound there), so it is off by default.
+        self.use_dot_storage = False
 
     @property
     def dustbin_logscore(self) -> float:
@@ -45,6 +49,8 @@ class SinkhornMatcher(nn.Module):
         the dot products become exact integer popcounts (i8 MFMA).  L2 only."""
         if self.distance_type != "l2":
             raise RuntimeError("forward_bits implements the l2 cost only")
+        if self.use_dot_storage:
+            return ops.sinkhorn_bits(bits1, bits2, normalized, self.epsilon, self.unused_score, self.iterations)
         z, pitch = ops.cost_logscores_bits(bits1, bits2, normalized, self.epsilon)
         return ops.sinkhorn(z, bits2.shape[1], pitch, self.dustbin_logscore, self.iterations)
 

@@ -1,0 +1,92 @@
+"""Multi-process path on CPU (gloo, world_size 2): pair sharding + the result gather.
+
+The per-pair compute needs a GPU, so each rank produces its shard's match records with the
+oracle (small images); what is under test is the product's distributed layer
+(onnx_image_processing_amd.distributed): contiguous sharding, record packing, gather order and
+the max-over-ranks timing reduction -- the same code bench.py runs over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _records_for(seeds):
+    """Match records (len(seeds), Mx, 6) of small pairs via the oracle (CPU checker)."""
+    sys.path.insert(0, ROOT)
+    from onnx_image_processing_amd import distributed as D
+    from onnx_image_processing_amd.synth import synth_batch
+    from oracle import numpy_oracle as O
+    t = np.load(os.path.join(ROOT, "onnx_image_processing_amd", "data", "bad_tables.npz"))
+    recs = []
+    for s in seeds:
+        a, b = synth_batch(s, 1, 64, 96)
+        k1, k2, p = O.match_pair(a, b, t["box_256"], t["thr_256"], 32, binarize=True, soft_binarize=False,
+                                 epsilon=0.05, nms_radius=2, sinkhorn_iterations=5)
+        mk1, mk2, sc, valid, _ = O.mnn_extract(p, k1, k2, 16, 0.1)
+        recs.append(D.pack_records(torch.from_numpy(mk1), torch.from_numpy(mk2), torch.from_numpy(sc),
+                                   torch.from_numpy(valid)))
+    return torch.cat(recs, 0)
+
+
+def _worker(rank, world, port, total, out_path):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from onnx_image_processing_amd import distributed as D
+    r, w, _ = D.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    begin, end = D.shard_range(total, rank, world)
+    rec = _records_for(range(5000 + begin, 5000 + end))
+    gathered = D.gather_records(rec, dst=0)
+    slowest = D.barrier_max_ms(10.0 * (rank + 1), "cpu")
+    assert slowest == 10.0 * world
+    if rank == 0:
+        torch.save(gathered, out_path)
+    else:
+        assert gathered is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions_exactly():
+    from onnx_image_processing_amd.distributed import shard_range
+    for total in (0, 1, 7, 8, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def test_record_pack_roundtrip():
+    from onnx_image_processing_amd.distributed import pack_records, unpack_records
+    mk1, mk2 = torch.rand(3, 5, 2), torch.rand(3, 5, 2)
+    sc = torch.rand(3, 5)
+    valid = sc > 0.5
+    a, b, c, d = unpack_records(pack_records(mk1, mk2, sc, valid))
+    assert torch.equal(a, mk1) and torch.equal(b, mk2) and torch.equal(c, sc) and torch.equal(d, valid)
+
+
+def test_two_rank_gather_equals_single_process(tmp_path):
+    total, world = 4, 2
+    out = str(tmp_path / "gathered.pt")
+    mp.spawn(_worker, args=(world, _free_port(), total, out), nprocs=world, join=True)
+    gathered = torch.load(out)
+    assert gathered.shape == (total, 16, 6)
+    assert torch.equal(gathered, _records_for(range(5000, 5000 + total)))     # global pair order preserved

@@ -195,7 +195,9 @@ def test_sinkhorn_bits_vs_float_vs_oracle(mods, n, m, d):
         mt = mods["SinkhornMatcher"](iterations=20, epsilon=eps, unused_score=unused)
         pb = mt.forward_bits(gpu(O.pack_bits(b1).view(np.int32)), gpu(O.pack_bits(b2).view(np.int32)), normalized)
         pf = mt(gpu(d1), gpu(d2))
-        for name, p in (("bits", pb), ("f32", pf)):
+        mt.use_dot_storage = True                     # uint16 dot-product storage (m <= 1024), same answer
+        pd = mt.forward_bits(gpu(O.pack_bits(b1).view(np.int32)), gpu(O.pack_bits(b2).view(np.int32)), normalized)
+        for name, p in (("bits", pb), ("f32", pf), ("dots", pd)):
             ok, worst = p_close(p.cpu().numpy(), ref)
             assert ok, (name, normalized, worst)
 

@@ -1,0 +1,156 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol the header declares (no
+compute call is made without a GPU), the nn.Module mirrors keep the reference's constructor
+contract, and the product refuses CPU tensors instead of falling back."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+HEADER = os.path.join(ROOT, "include", "mi355x_match.h")
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from onnx_image_processing_amd.build import build
+    return build(verbose=False)          # hipcc cross-compiles gfx950 without a GPU
+
+
+def header_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    names = header_functions()
+    assert len(names) >= 18
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/mi355x_match.h but not exported"
+    assert lib.mi_abi_version() == 1
+    lib.mi_error_string.restype = ctypes.c_char_p
+    assert lib.mi_error_string(0) == b"ok" and b"NULL" in lib.mi_error_string(-1)
+
+
+def test_binding_covers_the_header(lib_path):
+    from onnx_image_processing_amd import _native
+    assert sorted(_native.SIGNATURES) == header_functions()
+    _native.load()
+
+
+def test_argument_validation_happens_before_any_launch(lib_path):
+    """Bad arguments are rejected on the host (negative MI_E_* codes): safe to call without a GPU."""
+    lib = ctypes.CDLL(lib_path)
+    lib.mi_corner_response.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_void_p]
+    assert lib.mi_corner_response(None, 1, 8, 8, 3, None, None) == -1            # MI_E_NULL
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.mi_corner_response(p, 0, 8, 8, 3, p, None) == -2                  # MI_E_SHAPE
+    assert lib.mi_corner_response(p, 1, 8, 8, 4, p, None) == -3                  # MI_E_PARAM (even block)
+    lib.mi_sinkhorn_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.mi_sinkhorn_workspace_bytes(2, 512, 512) == 2 * 17 * 513 * 8
+    assert lib.mi_sinkhorn_workspace_bytes(2, 512, 5000) == 0
+    seg, cap = ctypes.c_int(), ctypes.c_int()
+    assert lib.mi_candidate_layout(480, 640, ctypes.byref(seg), ctypes.byref(cap)) == 0
+    assert (seg.value, cap.value) == (75, 4096) and seg.value * cap.value >= 480 * 640
+
+
+def test_constructor_contract_matches_reference():
+    from onnx_image_processing_amd.pytorch_model.descriptor.bad import SparseBAD
+    from onnx_image_processing_amd.pytorch_model.detector import ShiTomasiScore
+    from onnx_image_processing_amd.pytorch_model.feature_detection import (
+        MatchExtractionWrapper, ShiTomasiSparseBADSinkhornMatcher)
+    from onnx_image_processing_amd.pytorch_model.matching import SinkhornMatcher
+    # reference detector/shi_tomasi.py:37-41
+    with pytest.raises(ValueError, match="sobel_size must be 3"):
+        ShiTomasiScore(3, 5)
+    for bad in (0, 4, -1):
+        with pytest.raises(ValueError, match="positive odd integer"):
+            ShiTomasiScore(bad)
+    # reference descriptor/bad.py:385-392
+    with pytest.raises(ValueError, match="num_pairs must be 256 or 512"):
+        SparseBAD(128)
+    with pytest.raises(ValueError, match="sampling_mode"):
+        SparseBAD(256, sampling_mode="bicubic")
+    # reference matching/sinkhorn.py:66-77
+    with pytest.raises(ValueError, match="iterations must be positive"):
+        SinkhornMatcher(iterations=0)
+    with pytest.raises(ValueError, match="epsilon must be positive"):
+        SinkhornMatcher(epsilon=-1.0)
+    with pytest.raises(ValueError, match="distance_type"):
+        SinkhornMatcher(distance_type="cos")
+    assert SinkhornMatcher(distance_type="L2").distance_type == "l2"
+    m = ShiTomasiSparseBADSinkhornMatcher(max_keypoints=64)
+    assert m.border_margin == 7 and m.descriptor.max_radius == 7        # :120-124 (None -> max radius)
+    assert ShiTomasiSparseBADSinkhornMatcher(64, border_margin=0).border_margin == 0
+    assert (m.descriptor.num_pairs, m.descriptor.binarize, m.matcher.epsilon, m.nms_radius) == (256, False, 1.0, 3)
+    w = MatchExtractionWrapper(m)
+    assert (w.match_extractor.max_matches, w.match_extractor.threshold) == (100, 0.1)
+    # buffer names / shapes / dtypes (state_dict round trip with the reference)
+    sd = ShiTomasiSparseBADSinkhornMatcher(64, num_pairs=512).state_dict()
+    expect = {"corner_detector.sobel_xy": (2, 1, 3, 3), "corner_detector.sum_kernel_grouped": (3, 1, 3, 3),
+              "descriptor.offset_x1": (512,), "descriptor.radii": (512,), "descriptor.thresholds_v": (1, 1, 512),
+              "descriptor.radius_select": (8, 512), "descriptor.box_kernel_bank": (8, 1, 15, 15)}
+    for k, shape in expect.items():
+        assert tuple(sd[k].shape) == shape, k
+    assert sd["descriptor.radii"].dtype == torch.int64 and len(sd) == 15
+    assert torch.allclose(sd["descriptor.box_kernel_bank"].sum((1, 2, 3)), torch.ones(8))
+
+
+def test_bad_tables_geometry_invariants():
+    """Properties the K4 window proof and the fast path rely on."""
+    from onnx_image_processing_amd.pytorch_model.descriptor.bad_params import _get_bad_learned_params
+    for p in (256, 512):
+        box, thr = _get_bad_learned_params(p)
+        assert box.shape == (p, 5) and thr.shape == (p,) and box.dtype == torch.float32
+        x1, x2, y1, y2, r = box.T
+        for c in (x1, x2, y1, y2):
+            assert (c - r).min() >= 0 and (c + r).max() <= 31
+        assert r.min() >= 1 and r.max() == 7
+        # thresholds are odd multiples of 0.05: (S1 - S2)/area == thr can never hold for integers
+        k = torch.round(thr.double() * 20)
+        assert torch.allclose(k / 20, thr.double(), atol=1e-5) and bool((k.long() % 2 != 0).all())
+    with pytest.raises(ValueError):
+        _get_bad_learned_params(64)
+
+
+def test_cpu_tensors_are_refused_not_emulated(lib_path):
+    from onnx_image_processing_amd.pytorch_model.detector import ShiTomasiScore
+    from onnx_image_processing_amd.pytorch_model.matching import SinkhornMatcher
+    from onnx_image_processing_amd.pytorch_model.utils import apply_nms_maxpool
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ShiTomasiScore()(torch.zeros(1, 1, 16, 16))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        apply_nms_maxpool(torch.zeros(1, 16, 16), 2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        SinkhornMatcher()(torch.zeros(1, 4, 8), torch.zeros(1, 4, 8))
+    with pytest.raises(RuntimeError, match=r"\(N, 1, H, W\)"):
+        ShiTomasiScore()(torch.zeros(1, 3, 16, 16))
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "onnx_image_processing_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(d, f)).read()
+                assert "numpy_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_synthetic_inputs_are_deterministic():
+    from onnx_image_processing_amd.synth import synth_batch, synth_image, synth_pair
+    a = synth_image(1000)
+    assert a.dtype == np.uint8 and a.shape == (480, 640)
+    assert int(a[:4, :4].astype(np.int64).sum()) == int(synth_image(1000)[:4, :4].astype(np.int64).sum())
+    assert (int(a.min()), int(a.max())) == (0, 253) or a.max() <= 255
+    p, q = synth_pair(7, 64, 96)
+    assert np.array_equal(np.roll(p, (3, 5), (0, 1)), q)
+    x, y = synth_batch(5, 2, 32, 48, noise=2)
+    assert x.shape == (2, 1, 32, 48) and x.dtype == np.float32 and np.abs(y[0, 0] - np.roll(x[0, 0], (3, 5), (0, 1))).max() <= 2
+    import hashlib
+    assert hashlib.sha256(synth_image(1000).tobytes()).hexdigest()[:16] == hashlib.sha256(a.tobytes()).hexdigest()[:16]

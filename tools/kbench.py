@@ -98,6 +98,8 @@ def main():
         res["sinkhorn_fused(20 it)"] = (ms, (21.0 * 4 * n * K * K + 4.0 * n * (K + 1) ** 2) / ms / 1e6)
         ms = timeit(lambda: ops.sinkhorn(z, K, pitch, -20.0, 20, use_workspace=False), args.iters)
         res["sinkhorn_2pass(20 it)"] = (ms, (41.0 * 4 * n * K * K + 4.0 * n * (K + 1) ** 2) / ms / 1e6)
+        ms = timeit(lambda: ops.sinkhorn_bits(bits, b2, True, 0.05, 1.0, 20), args.iters)
+        res["cost+sinkhorn dots(20 it)"] = (ms, (20.0 * 2 * n * K * K + 4.0 * n * (K + 1) ** 2) / ms / 1e6)
     p = ops.sinkhorn(z, K, pitch, -20.0, 20)
     if "mnn" in args.which:
         ms = timeit(lambda: ops.mnn_extract(p, kp, torch.roll(kp, 1, 0), 100, 0.1), args.iters)
@@ -117,8 +119,9 @@ def main():
         tb1 = torch.from_numpy(O.pack_bits(b1).view(np.int32)).to(dev)
         tb2 = torch.from_numpy(O.pack_bits(b2).view(np.int32)).to(dev)
         zz, pp = ops.cost_logscores_bits(tb1, tb2, True, 0.05)
-        for name, ws in (("fused", True), ("two-pass", False)):
-            got = ops.sinkhorn(zz, 512, pp, -20.0, 20, use_workspace=ws).cpu().numpy().astype(np.float64)
+        for name, ws in (("fused", True), ("two-pass", False), ("dots", None)):
+            got = (ops.sinkhorn_bits(tb1, tb2, True, 0.05, 1.0, 20) if ws is None else
+                   ops.sinkhorn(zz, 512, pp, -20.0, 20, use_workspace=ws)).cpu().numpy().astype(np.float64)
             ratio = np.abs(got - ref) / (1e-4 * np.maximum(1.0, np.abs(ref)))
             print(f"accuracy {name}: worst |dP|/bound = {ratio.max():.4f}, max |dP| core = {np.abs(got - ref)[:, :512, :512].max():.3e}")
     for k, (ms, gbs) in res.items():
