@@ -45,7 +45,8 @@ int mi_abi_version(void);
 const char *mi_error_string(int code);
 /* Development/test hook: choose between equivalent kernel implementations (results are
  * identical).  key 1: corner response, 0 = streaming LDS-DMA kernel (default), 1 = register-
- * staged tile kernel. */
+ * staged tile kernel.  key 2: rows per thread of the streaming corner kernel (4, 5 or 8).
+ * key 4: Sinkhorn band partials, 0 = probability form (default), 1 = log-domain (max,sum) form. */
 int mi_debug_set(int key, int value);
 
 /* ---- detector/shi_tomasi.py:66-112  ShiTomasiScore.forward ---------------------------------

@@ -13,6 +13,8 @@
 
 #pragma clang fp contract(off)
 
+extern int mi_g_sinkhorn_log_partials;   // defined in sinkhorn.hip
+
 namespace {
 
 constexpr int TW = 128;  // tile width: 32 threads x 4 pixels
@@ -431,6 +433,7 @@ int g_corner_rows = 4;   // rows per thread of the streaming kernel (tile height
 // Development/test hook: select between equivalent kernel implementations (results identical).
 extern "C" int mi_debug_set(int key, int value) {
   if (key == 1) { g_corner_impl = value; return MI_OK; }
+  if (key == 4) { mi_g_sinkhorn_log_partials = value; return MI_OK; }
   if (key == 2 && (value == 4 || value == 5 || value == 8)) { g_corner_rows = value; return MI_OK; }
   return MI_E_PARAM;
 }

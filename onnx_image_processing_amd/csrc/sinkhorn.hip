@@ -15,6 +15,10 @@
 
 #include <math.h>
 
+// test hook (mi_debug_set key 4): 1 = log-domain (max, sum) band partials with two exps per element,
+// 0 = probability-form partials with one exp per element (default)
+int mi_g_sinkhorn_log_partials = 0;
+
 namespace {
 
 constexpr int ROWS_PER_WAVE = 4;
@@ -230,6 +234,155 @@ __global__ __launch_bounds__(256) void sk_exp_kernel(const float *__restrict__ z
   }
 }
 
+// ---- fused iteration, probability form: ONE exp per matrix element per iteration ----------------
+// After the row pass the row-normalised entries are already known:
+//     P_ij = exp(Z_ij + u_i + v_j) = e_ij / s_i,  e_ij = exp(Z_ij + v_j - max_i),  s_i = sum_j e_ij
+// (all in [0,1]), and the column update of sinkhorn.py:141 is
+//     v_j <- log nu_j - LSE_i(Z_ij + u_i) = v_j + log nu_j - log(sum_i P_ij).
+// So the column pass needs no second exponential: a band just adds up its P_ij per column
+// (plain fp32 sums of numbers in [0,1]) and the combine kernel takes one log per column.  The
+// dustbin ROW's term is kept in the log domain (B_j = dust + u_n + v_j) and merged with a
+// log-sum-exp, so a column whose regular entries all underflow still gets the exact dustbin
+// answer.  Per element: add, max, sub, mul, v_exp, add (row) + mul, add (column) instead of
+// two full exp chains -- the loop is VALU-bound on gfx950, so this is what sets its speed.
+// Partials: one float per column per band (band nb = the dustbin row's B_j).
+template <int E4, int RW, int NW>
+__global__ __launch_bounds__(64 * NW) void sk_band_p_kernel(const float *__restrict__ z, int n, int m, int pitch,
+                                                            float dust, const float *__restrict__ v,
+                                                            float *__restrict__ u, float *__restrict__ part,
+                                                            float log_m, int v_is_zero) {
+  constexpr int BAND = NW * RW;
+  constexpr int NT = 64 * NW;
+  constexpr int NC = 256 * E4;
+  __shared__ float red[NW][NC + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, band = blockIdx.x, nb = gridDim.x - 1;
+  const float *vb = v + (size_t)b * (m + 1);
+  float *pb = part + ((size_t)b * (nb + 1) + band) * (size_t)(m + 1);
+  const float vd = v_is_zero ? 0.0f : vb[m];
+
+  if (band == nb) {
+    // dustbin row: u_n = log m - LSE_j(dust + v_j); its log-probabilities B_j = dust + u_n + v_j
+    float mx = dust + vd;
+    for (int j = threadIdx.x; j < m; j += NT) mx = fmaxf(mx, dust + (v_is_zero ? 0.0f : vb[j]));
+    mx = wave_max_dpp(mx);
+    if (lane == 0) red[wave][0] = mx;
+    __syncthreads();
+    mx = red[0][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w][0]);
+    float s = 0.0f;
+    for (int j = threadIdx.x; j < m; j += NT) s += expf((dust + (v_is_zero ? 0.0f : vb[j])) - mx);
+    s = wave_sum_dpp(s);
+    if (lane == 0) red[wave][1] = s;
+    __syncthreads();
+    s = red[0][1];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s += red[w][1];
+    s += expf((dust + vd) - mx);
+    const float un = log_m - (logf(s) + mx);
+    if (threadIdx.x == 0) u[(size_t)b * (n + 1) + n] = un;
+    for (int j = threadIdx.x; j <= m; j += NT) pb[j] = (dust + un) + (v_is_zero ? 0.0f : vb[j]);
+    return;
+  }
+
+  float vv[E4][4];
+#pragma unroll
+  for (int e = 0; e < E4; ++e)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = e * 256 + lane * 4 + q;
+      vv[e][q] = (j < m && !v_is_zero) ? vb[j] : 0.0f;
+    }
+  const float xd = dust + vd;
+  const int row0 = band * BAND + wave * RW;
+
+  float x[RW][E4][4];            // Z_ij + v_j, then e_ij in place
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int i = row0 + r;
+    const float *src = z + ((size_t)b * n + (i < n ? i : 0)) * pitch;
+#pragma unroll
+    for (int e = 0; e < E4; ++e) {
+      const int j = e * 256 + lane * 4;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < n && j < m) q = *reinterpret_cast<const float4 *>(src + j);
+      // outside the matrix (row padding, rows past n): -inf, i.e. no contribution anywhere
+      x[r][e][0] = (i < n && j + 0 < m) ? q.x + vv[e][0] : -INFINITY;
+      x[r][e][1] = (i < n && j + 1 < m) ? q.y + vv[e][1] : -INFINITY;
+      x[r][e][2] = (i < n && j + 2 < m) ? q.z + vv[e][2] : -INFINITY;
+      x[r][e][3] = (i < n && j + 3 < m) ? q.w + vv[e][3] : -INFINITY;
+    }
+  }
+
+  float colsum[E4][4];
+#pragma unroll
+  for (int e = 0; e < E4; ++e)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) colsum[e][q] = 0.0f;
+  float dustcol = 0.0f;          // sum of P_i,dustbin over this wave's rows (wave-uniform)
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    float mx = xd;
+#pragma unroll
+    for (int e = 0; e < E4; ++e)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mx = fmaxf(mx, x[r][e][q]);
+    mx = wave_max_dpp(mx);
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < E4; ++e)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        x[r][e][q] = sk_exp(x[r][e][q] - mx);        // e_ij; exp(-inf) = 0 outside the matrix
+        s += x[r][e][q];
+      }
+    const float ed = expf(xd - mx);                  // dustbin column entry of this row
+    s = wave_sum_dpp(s) + ed;
+    const float inv_s = 1.0f / s;
+    const bool live = row0 + r < n;
+    if (lane == 0 && live) u[(size_t)b * (n + 1) + row0 + r] = 0.0f - (logf(s) + mx);   // sinkhorn.py:139
+    const float wgt = live ? inv_s : 0.0f;
+#pragma unroll
+    for (int e = 0; e < E4; ++e)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) colsum[e][q] += x[r][e][q] * wgt;                     // P_ij
+    dustcol += ed * wgt;
+  }
+#pragma unroll
+  for (int e = 0; e < E4; ++e)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[wave][e * 256 + lane * 4 + q] = colsum[e][q];
+  if (lane == 0) red[wave][NC] = dustcol;
+  __syncthreads();
+  for (int c = threadIdx.x; c <= NC; c += NT) {
+    const int j = (c == NC) ? m : c;
+    if (c < NC && j >= m) continue;
+    float t = red[0][c];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += red[w][c];
+    pb[j] = t;
+  }
+}
+
+// v_j <- v_j + log nu_j - log(sum of the bands' P_ij + exp(B_j))   (B_j: dustbin row, log domain)
+__global__ __launch_bounds__(256) void sk_vcombine_p_kernel(const float *__restrict__ part, int m, int nparts,
+                                                            float *__restrict__ v, float log_n, int v_is_zero) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j > m) return;
+  const float *p = part + (size_t)b * nparts * (size_t)(m + 1) + j;
+  float s = 0.0f;
+  for (int k = 0; k < nparts - 1; ++k) s += p[(size_t)k * (m + 1)];
+  const float bj = p[(size_t)(nparts - 1) * (m + 1)];
+  // log(s + exp(bj)) as a two-term log-sum-exp; s == 0 (everything underflowed) leaves bj
+  const float a = s > 0.0f ? logf(s) : -INFINITY;
+  const float hi = fmaxf(a, bj), lo = fminf(a, bj);
+  const float lse = hi + log1pf(expf(lo - hi));
+  const float vold = v_is_zero ? 0.0f : v[(size_t)b * (m + 1) + j];
+  v[(size_t)b * (m + 1) + j] = (vold + ((j == m) ? log_n : 0.0f)) - lse;
+}
+
 // ---- fused iteration: Z is read ONCE per iteration ----------------------------------------------
 // A workgroup owns a band of 4*RW rows.  Each wave keeps RW whole rows of Z in registers
 // (RW * E4 float4 per lane, all loads issued up front), computes u for them (row pass), and
@@ -395,10 +548,19 @@ void launch_fused(const float *z, int batch, int n, int m, int pitch, float dust
                   float *v, float2 *part, float log_m, float log_n, hipStream_t s) {
   const int nb = ceil_div(n, NW * RW);
   for (int it = 0; it < iterations; ++it) {
-    hipLaunchKernelGGL((sk_band_kernel<E4, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, z, n, m, pitch, dust, v,
-                       u, part, log_m, it == 0 ? 1 : 0);
-    hipLaunchKernelGGL(sk_vcombine_kernel, dim3(ceil_div(m + 1, 256), batch), dim3(256), 0, s, part, m, nb + 1,
-                       v, log_n);
+    const int vz = it == 0 ? 1 : 0;
+    if (mi_g_sinkhorn_log_partials) {
+      hipLaunchKernelGGL((sk_band_kernel<E4, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, z, n, m, pitch, dust,
+                         v, u, part, log_m, vz);
+      hipLaunchKernelGGL(sk_vcombine_kernel, dim3(ceil_div(m + 1, 256), batch), dim3(256), 0, s, part, m, nb + 1,
+                         v, log_n);
+    } else {
+      float *pf = reinterpret_cast<float *>(part);
+      hipLaunchKernelGGL((sk_band_p_kernel<E4, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, z, n, m, pitch,
+                         dust, v, u, pf, log_m, vz);
+      hipLaunchKernelGGL(sk_vcombine_p_kernel, dim3(ceil_div(m + 1, 256), batch), dim3(256), 0, s, pf, m, nb + 1, v,
+                         log_n, vz);
+    }
   }
 }
 

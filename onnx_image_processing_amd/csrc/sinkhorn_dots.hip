@@ -5,11 +5,11 @@
 // K5 stores dot(a_i, b_j) = popcount(a_i & b_j) as uint16 (exact) plus one (scale, squared norm)
 // pair per descriptor.  Every pass rebuilds
 //     z_ij = -max((|a_i|^2 + |b_j|^2) - 2 * dot_ij * (s_i * s_j), 0) * (1/epsilon)
-// in registers (7 VALU ops per element), so an iteration streams 2 bytes per matrix element
-// instead of 4: the loop is bandwidth-bound and this halves its bytes.  z here differs from the
-// fp32 path only in the last rounding (multiply by 1/epsilon instead of divide: <= 1 ulp of z).
-// Structure of the iteration is the band-fused one of sinkhorn.hip: a workgroup keeps a band of
-// rows in registers, computes their u, then the band's (max, sum) contribution to every column.
+// in registers, so an iteration streams 2 bytes per matrix element instead of 4.  z here differs
+// from the fp32 path only in the last rounding (multiply by 1/epsilon instead of divide: <= 1 ulp).
+// The iteration is the probability-form band kernel of sinkhorn.hip (one exp per element: the
+// row pass leaves P_ij = e_ij / s_i in registers, the column update is v_j += log nu_j -
+// log(sum_i P_ij), the dustbin row is merged in the log domain).
 #include "common.h"
 
 #include <math.h>
@@ -32,44 +32,44 @@ __device__ __forceinline__ float z_of(float dot, float2 row, float2 col, float n
 // E8 = 16-byte (8 x uint16) loads per lane per row: covers m <= 512 * E8 columns.
 template <int E8, int RW, int NW>
 __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *__restrict__ dots, int n, int m,
-                                                           int pitch, const float2 *__restrict__ row_info,
-                                                           const float2 *__restrict__ col_info, ZParams zp,
-                                                           const float *__restrict__ v, float *__restrict__ u,
-                                                           float2 *__restrict__ part, float log_m, int v_is_zero) {
+                                                               int pitch, const float2 *__restrict__ row_info,
+                                                               const float2 *__restrict__ col_info, ZParams zp,
+                                                               const float *__restrict__ v, float *__restrict__ u,
+                                                               float *__restrict__ part, float log_m,
+                                                               int v_is_zero) {
   constexpr int BAND = NW * RW;   // NW waves x RW rows each
   constexpr int NT = 64 * NW;
-  constexpr int NC = 512 * E8;                     // columns covered by one wave
-  __shared__ float red_m[NW][NC + 1];
-  __shared__ float red_s[NW][NC + 1];
+  constexpr int NC = 512 * E8;    // columns covered by one wave
+  __shared__ float red[NW][NC + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y, band = blockIdx.x, nb = gridDim.x - 1;
   const float *vb = v + (size_t)b * (m + 1);
-  float2 *pb = part + ((size_t)b * (nb + 1) + band) * (size_t)(m + 1);
+  float *pb = part + ((size_t)b * (nb + 1) + band) * (size_t)(m + 1);
   const float vd = v_is_zero ? 0.0f : vb[m];
   const float dust = zp.dust;
 
   if (band == nb) {
-    // dustbin row: u_n = log m - LSE_j(dust + v_j), then its term for every column
+    // dustbin row: u_n = log m - LSE_j(dust + v_j); its log-probabilities B_j = dust + u_n + v_j
     float mx = dust + vd;
     for (int j = threadIdx.x; j < m; j += NT) mx = fmaxf(mx, dust + (v_is_zero ? 0.0f : vb[j]));
     mx = wave_max_dpp(mx);
-    if (lane == 0) red_m[wave][0] = mx;
+    if (lane == 0) red[wave][0] = mx;
     __syncthreads();
-    mx = red_m[0][0];
+    mx = red[0][0];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red_m[w][0]);
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w][0]);
     float s = 0.0f;
     for (int j = threadIdx.x; j < m; j += NT) s += expf((dust + (v_is_zero ? 0.0f : vb[j])) - mx);
     s = wave_sum_dpp(s);
-    if (lane == 0) red_s[wave][0] = s;
+    if (lane == 0) red[wave][1] = s;
     __syncthreads();
-    s = red_s[0][0];
+    s = red[0][1];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) s += red_s[w][0];
+    for (int w = 1; w < NW; ++w) s += red[w][1];
     s += expf((dust + vd) - mx);
     const float un = log_m - (logf(s) + mx);
     if (threadIdx.x == 0) u[(size_t)b * (n + 1) + n] = un;
-    for (int j = threadIdx.x; j <= m; j += NT) pb[j] = make_float2(dust + un, 1.0f);
+    for (int j = threadIdx.x; j <= m; j += NT) pb[j] = (dust + un) + (v_is_zero ? 0.0f : vb[j]);
     return;
   }
 
@@ -99,11 +99,20 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
       if (i < n && j < m) raw[r][e] = *reinterpret_cast<const uint4 *>(src + j);   // pitch >= round_up(m,8)
     }
   }
-  float zr[RW][E8][8];
+
+  float colsum[E8][8];
+#pragma unroll
+  for (int e = 0; e < E8; ++e)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) colsum[e][q] = 0.0f;
+  float dustcol = 0.0f;          // sum of P_i,dustbin over this wave's rows (wave-uniform)
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
     const int i = row0 + r;
-    const float2 ri = row_info[(size_t)b * n + (i < n ? i : 0)];                   // wave-uniform
+    const bool live = i < n;
+    const float2 ri = row_info[(size_t)b * n + (live ? i : 0)];                    // wave-uniform
+    float x[E8][8];              // Z_ij + v_j, then e_ij in place
+    float mx = xd;
 #pragma unroll
     for (int e = 0; e < E8; ++e) {
       const uint32_t w4[4] = {raw[r][e].x, raw[r][e].y, raw[r][e].z, raw[r][e].w};
@@ -112,91 +121,62 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
         const int j = e * 512 + lane * 8 + q;
         const float dot = (float)((q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu));
         // outside the matrix (row padding, rows past n): -inf, i.e. no contribution anywhere
-        zr[r][e][q] = (i < n && j < m) ? z_of(dot, ri, ci[e][q], zp.neg_inv_eps) : -INFINITY;
+        x[e][q] = (live && j < m) ? z_of(dot, ri, ci[e][q], zp.neg_inv_eps) + vv[e][q] : -INFINITY;
+        mx = fmaxf(mx, x[e][q]);
       }
     }
-  }
-
-  // row pass (sinkhorn.py:139): u_i = log mu_i - LSE_j(Z_ij + v_j), dustbin column included
-  float ur[RW];
-#pragma unroll
-  for (int r = 0; r < RW; ++r) {
-    float mx = xd;
-#pragma unroll
-    for (int e = 0; e < E8; ++e)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) mx = fmaxf(mx, zr[r][e][q] + vv[e][q]);
     mx = wave_max_dpp(mx);
     float s = 0.0f;
 #pragma unroll
     for (int e = 0; e < E8; ++e)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) s += sk_exp((zr[r][e][q] + vv[e][q]) - mx);
-    s = wave_sum_dpp(s) + expf(xd - mx);
-    ur[r] = 0.0f - (logf(s) + mx);
-    if (lane == 0 && row0 + r < n) u[(size_t)b * (n + 1) + row0 + r] = ur[r];
+      for (int q = 0; q < 8; ++q) {
+        x[e][q] = sk_exp(x[e][q] - mx);              // e_ij; exp(-inf) = 0 outside the matrix
+        s += x[e][q];
+      }
+    const float ed = expf(xd - mx);                  // dustbin column entry of this row
+    s = wave_sum_dpp(s) + ed;
+    const float inv_s = 1.0f / s;
+    if (lane == 0 && live) u[(size_t)b * (n + 1) + i] = 0.0f - (logf(s) + mx);     // sinkhorn.py:139
+    const float wgt = live ? inv_s : 0.0f;
+#pragma unroll
+    for (int e = 0; e < E8; ++e)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) colsum[e][q] += x[e][q] * wgt;                  // P_ij
+    dustcol += ed * wgt;
   }
-
-  // column partials over this wave's RW rows (sinkhorn.py:141: Z_ij + u_i)
 #pragma unroll
   for (int e = 0; e < E8; ++e)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      float cm = -INFINITY;
-#pragma unroll
-      for (int r = 0; r < RW; ++r) cm = fmaxf(cm, zr[r][e][q] + ur[r]);
-      float cs = 0.0f;
-      if (cm > -INFINITY) {
-#pragma unroll
-        for (int r = 0; r < RW; ++r) cs += sk_exp((zr[r][e][q] + ur[r]) - cm);
-      }
-      red_m[wave][e * 512 + lane * 8 + q] = cm;
-      red_s[wave][e * 512 + lane * 8 + q] = cs;
-    }
-  {
-    // dustbin column: x_i = dust + u_i over this wave's valid rows (uniform across lanes)
-    float cm = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < RW; ++r)
-      if (row0 + r < n) cm = fmaxf(cm, dust + ur[r]);
-    float cs = 0.0f;
-#pragma unroll
-    for (int r = 0; r < RW; ++r)
-      if (row0 + r < n) cs += expf((dust + ur[r]) - cm);
-    if (lane == 0) { red_m[wave][NC] = cm; red_s[wave][NC] = cs; }
-  }
+    for (int q = 0; q < 8; ++q) red[wave][e * 512 + lane * 8 + q] = colsum[e][q];
+  if (lane == 0) red[wave][NC] = dustcol;
   __syncthreads();
   for (int c = threadIdx.x; c <= NC; c += NT) {
     const int j = (c == NC) ? m : c;
     if (c < NC && j >= m) continue;
-    float fm = red_m[0][c];
+    float t = red[0][c];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) fm = fmaxf(fm, red_m[w][c]);
-    float fs = 0.0f;
-    if (fm > -INFINITY) {
-#pragma unroll
-      for (int w = 0; w < NW; ++w)
-        if (red_m[w][c] > -INFINITY) fs += red_s[w][c] * expf(red_m[w][c] - fm);
-    }
-    pb[j] = make_float2(fm, fs);
+    for (int w = 1; w < NW; ++w) t += red[w][c];
+    pb[j] = t;
   }
 }
 
-// v_j = log nu_j - LSE over all bands' partials (including the dustbin-row band)
-__global__ __launch_bounds__(256) void sk_vcombine_dots_kernel(const float2 *__restrict__ part, int m, int nparts,
-                                                               float *__restrict__ v, float log_n) {
+// v_j <- v_j + log nu_j - log(sum of the bands' P_ij + exp(B_j))   (B_j: dustbin row, log domain)
+__global__ __launch_bounds__(256) void sk_vcombine_dots_kernel(const float *__restrict__ part, int m, int nparts,
+                                                               float *__restrict__ v, float log_n,
+                                                               int v_is_zero) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j > m) return;
-  const float2 *p = part + (size_t)b * nparts * (size_t)(m + 1) + j;
-  float mx = -INFINITY;
-  for (int k = 0; k < nparts; ++k) mx = fmaxf(mx, p[(size_t)k * (m + 1)].x);
+  const float *p = part + (size_t)b * nparts * (size_t)(m + 1) + j;
   float s = 0.0f;
-  for (int k = 0; k < nparts; ++k) {
-    const float2 q = p[(size_t)k * (m + 1)];
-    if (q.x > -INFINITY) s += q.y * expf(q.x - mx);
-  }
-  v[(size_t)b * (m + 1) + j] = ((j == m) ? log_n : 0.0f) - (logf(s) + mx);
+  for (int k = 0; k < nparts - 1; ++k) s += p[(size_t)k * (m + 1)];
+  const float bj = p[(size_t)(nparts - 1) * (m + 1)];
+  const float a = s > 0.0f ? logf(s) : -INFINITY;
+  const float hi = fmaxf(a, bj), lo = fminf(a, bj);
+  const float lse = hi + log1pf(expf(lo - hi));
+  const float vold = v_is_zero ? 0.0f : v[(size_t)b * (m + 1) + j];
+  v[(size_t)b * (m + 1) + j] = (vold + ((j == m) ? log_n : 0.0f)) - lse;
 }
 
 // P = exp(Z + u + v) over the augmented matrix; one wave per row
@@ -223,14 +203,15 @@ __global__ __launch_bounds__(256) void sk_exp_dots_kernel(const uint16_t *__rest
 
 template <int E8, int RW, int NW>
 void launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int batch, int n, int m, int pitch,
-                 ZParams zp, int iterations, float *u, float *v, float2 *part, float log_m, float log_n,
+                 ZParams zp, int iterations, float *u, float *v, float *part, float log_m, float log_n,
                  hipStream_t s) {
   const int nb = ceil_div(n, NW * RW);
   for (int it = 0; it < iterations; ++it) {
-    hipLaunchKernelGGL((sk_band_dots_kernel<E8, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, dots, n, m, pitch, ri,
-                       ci, zp, v, u, part, log_m, it == 0 ? 1 : 0);
+    const int vz = it == 0 ? 1 : 0;
+    hipLaunchKernelGGL((sk_band_dots_kernel<E8, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, dots, n, m, pitch,
+                       ri, ci, zp, v, u, part, log_m, vz);
     hipLaunchKernelGGL(sk_vcombine_dots_kernel, dim3(ceil_div(m + 1, 256), batch), dim3(256), 0, s, part, m, nb + 1,
-                       v, log_n);
+                       v, log_n, vz);
   }
 }
 
@@ -241,7 +222,7 @@ int dots_rows_per_band(int m) { return m <= 512 ? 32 : (m <= 1024 ? 16 : 0); }
 extern "C" size_t mi_sinkhorn_dots_workspace_bytes(int batch, int n, int m) {
   const int band = dots_rows_per_band(m);
   if (batch <= 0 || n <= 0 || m <= 0 || band == 0) return 0;
-  return (size_t)batch * (size_t)(ceil_div(n, band) + 1) * (size_t)(m + 1) * sizeof(float2);
+  return (size_t)batch * (size_t)(ceil_div(n, band) + 1) * (size_t)(m + 1) * sizeof(float);
 }
 
 extern "C" int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch,
@@ -262,7 +243,7 @@ extern "C" int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, con
   zp.dust = (float)(-unused_score / epsilon);
   const float2 *ri = reinterpret_cast<const float2 *>(row_info);
   const float2 *ci = reinterpret_cast<const float2 *>(col_info);
-  float2 *part = reinterpret_cast<float2 *>(workspace);
+  float *part = reinterpret_cast<float *>(workspace);
   if (m <= 512) launch_dots<1, 4, 8>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, log_m, log_n, s);
   else launch_dots<2, 2, 8>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, log_m, log_n, s);
   if (p) {

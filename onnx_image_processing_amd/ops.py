@@ -182,7 +182,7 @@ def sinkhorn_bits(bits1: torch.Tensor, bits2: torch.Tensor, normalized: bool, ep
     u = torch.empty((b, n + 1), dtype=F32, device=dev)
     v = torch.empty((b, m + 1), dtype=F32, device=dev)
     p = torch.empty((b, n + 1, m + 1), dtype=F32, device=dev)
-    work = torch.empty((wbytes // 8,), dtype=torch.int64, device=dev)
+    work = torch.empty(((wbytes + 7) // 8,), dtype=torch.int64, device=dev)
     N.call("mi_sinkhorn_dots", dots.data_ptr(), row_info.data_ptr(), col_info.data_ptr(), b, n, m, pitch,
            float(epsilon), float(unused_score), int(iterations), u.data_ptr(), v.data_ptr(), p.data_ptr(),
            work.data_ptr(), wbytes, N.stream_ptr())

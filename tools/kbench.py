@@ -94,8 +94,10 @@ def main():
         res["cost_f32(32 pairs)"] = (ms, 2.0 * 32 * K * K * 512 / ms / 1e9)
     z, pitch = ops.cost_logscores_bits(bits, b2, True, 0.05)
     if "sinkhorn" in args.which:
-        ms = timeit(lambda: ops.sinkhorn(z, K, pitch, -20.0, 20), args.iters)
-        res["sinkhorn_fused(20 it)"] = (ms, (21.0 * 4 * n * K * K + 4.0 * n * (K + 1) ** 2) / ms / 1e6)
+        for mode, name in ((1, "sinkhorn_fused log-partials"), (0, "sinkhorn_fused prob-partials")):
+            N.load().mi_debug_set(4, mode)
+            ms = timeit(lambda: ops.sinkhorn(z, K, pitch, -20.0, 20), args.iters)
+            res[name] = (ms, (21.0 * 4 * n * K * K + 4.0 * n * (K + 1) ** 2) / ms / 1e6)
         ms = timeit(lambda: ops.sinkhorn(z, K, pitch, -20.0, 20, use_workspace=False), args.iters)
         res["sinkhorn_2pass(20 it)"] = (ms, (41.0 * 4 * n * K * K + 4.0 * n * (K + 1) ** 2) / ms / 1e6)
         ms = timeit(lambda: ops.sinkhorn_bits(bits, b2, True, 0.05, 1.0, 20), args.iters)
