@@ -92,14 +92,16 @@ int mi_topk_keypoints(const uint64_t *cand, const uint32_t *count, int segments,
  * plan (optional, may be NULL): device buffer of mi_bad_plan_bytes(num_pairs) bytes, 16-byte
  * aligned, filled once per pair table by mi_bad_plan_build.  With a plan, HARD-mode keypoints
  * that are integer-valued, at least 15 px from the border and sit on an integer-valued (uint8)
- * patch take an int32 fast path with precomputed table corners; results are identical. */
+ * patch take an int32 fast path with precomputed table corners; results are identical.
+ * status (optional, required for the fast path): n*k bytes of workspace; the fast kernel marks
+ * the keypoints it handled and the general kernel visits the rest. */
 size_t mi_bad_plan_bytes(int num_pairs);
 int mi_bad_plan_build(const uint32_t *pair_geom, const float *pair_thr, int num_pairs, void *plan,
                       mi_stream_t stream);
 int mi_sparse_bad(const float *image, int n, int h, int w, const float *keypoints, int k,
                   const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
                   float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
-                  mi_stream_t stream);
+                  uint8_t *status, mi_stream_t stream);
 
 /* ---- matching/sinkhorn.py:79-110,178  cost matrix -> core log-score matrix --------------------
  * z[b, i, j] = -cost(desc1[b,i], desc2[b,j]) / epsilon for i < n, j < m; row pitch `pitch` floats

@@ -29,7 +29,7 @@ SIGNATURES = {
     "mi_bad_plan_bytes": [c_int],
     "mi_bad_plan_build": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "mi_sparse_bad": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
-                      c_void_p, c_void_p, c_void_p, c_void_p],
+                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mi_cost_logscores_bits": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p],
     "mi_cost_logscores_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p],
     "mi_sinkhorn_workspace_bytes": [c_int, c_int, c_int],

@@ -3,16 +3,27 @@
 // sampling_mode="nearest".  The reference builds a dense 8-channel 15x15 box-mean bank over
 // the whole image and gathers 2*8*K*P samples from it; here nothing dense is built.
 //
-// One wave (64 lanes) per keypoint.  Every box of every pair lies inside a 34x34 window of
-// the replicate-extended image around the keypoint (see window proof below), so the wave
-// stages that window, turns it into an fp64 summed-area table in LDS (exact for integer-valued
-// images, ~1e-13 otherwise) and evaluates each box with four 8-byte LDS reads.  Lane l owns
-// pairs l, l+64, ...; a wave ballot turns 64 sign tests into one 64-bit word of the packed
+// One wave (64 lanes) per keypoint.  Every box of every pair lies inside a small window of the
+// replicate-extended image around the keypoint, so the wave stages that window, turns it into a
+// summed-area table in LDS and evaluates each box with four LDS reads.  Lane l owns pairs
+// l, l+64, ...; a wave ballot turns 64 sign tests into one 64-bit word of the packed
 // descriptor, and its popcount gives the L2 norm of the bit vector exactly.
 //
-// Window proof (non-oriented): table offsets satisfy -16 <= o - r, o + r <= 15 (boxes stay
-// inside the 32x32 patch).  With f = floor(ky), the unclamped centre c = nearbyint(ky + o)
-// lies in [f + o, f + o + 1]; clamping c into the image and then taking rows c-r..c+r of the
+// Two kernels:
+//  * bad_fast_kernel (hard bits, needs a plan): keypoints with integer coordinates, >= 15 px from
+//    the border, on an integer-valued (uint8) patch.  Then no box centre is clamped, every box
+//    lies in the 32x32 window [k-16, k+15], the four table corners of each box are the same for
+//    every keypoint (precomputed byte offsets), sums are exact int32 and the sign test is
+//    D <= floor(thr*area).  4 keypoints per 256-thread workgroup, wave-private LDS (4.3 KiB per
+//    wave) and no workgroup barrier, so occupancy is high.  Keypoints it cannot take are flagged.
+//  * sparse_bad_kernel (general): 34x34 window, fp64 table (exact for integer images, ~1e-13
+//    otherwise), box centres through the exact grid_sample(nearest, border, align_corners)
+//    arithmetic, all output modes.  With a status array it only visits the flagged keypoints.
+// Both are exact, so which one handled a keypoint cannot be seen in the result.
+//
+// Window proof (general path): table offsets satisfy -16 <= o - r, o + r <= 15 (boxes stay inside
+// the 32x32 patch).  With f = floor(ky), the unclamped centre c = nearbyint(ky + o) lies in
+// [f + o, f + o + 1]; clamping c into the image and then taking rows c-r..c+r of the
 // replicate-extended image never leaves [f - 16, f + 17].
 #include "common.h"
 
@@ -20,15 +31,15 @@
 
 namespace {
 
-constexpr int WIN = 34;          // window edge
+constexpr int WIN = 34;          // general window edge
 constexpr int WOFF = 16;         // window origin = floor(k) - WOFF
-constexpr int SP = WIN + 1;      // SAT edge (leading zero row/column)
+constexpr int SP = WIN + 1;      // general SAT edge (leading zero row/column)
 constexpr int FW = 33;           // fast-path SAT edge (32x32 window + leading zero row/column)
 
 // Device-resident plan for the fast path, built once per pair table by mi_bad_plan_build:
 // header, then uint4 offs[P] (eight 16-bit BYTE offsets into the int32 33x33 table: box 1
-// corners (b,r) (a,r) (b,l) (a,l) in x,y; box 2 in z,w; low half first), then int tint[P] =
-// floor(thr * area).
+// corners (b,r) (a,r) in x, (b,l) (a,l) in y; box 2 in z, w; low half first), then
+// int tint[P] = floor(thr * area).
 struct BadPlan {
   int geometry_ok;   // every box of the table stays inside the 32x32 patch
   int num_pairs;
@@ -44,121 +55,140 @@ __device__ __forceinline__ int nearest_centre(float pos, float scale, int size) 
   return (int)nearbyintf(x);
 }
 
+// ---- fast kernel: 4 waves = 4 keypoints per workgroup, no workgroup-level synchronisation -----
+__global__ __launch_bounds__(256) void bad_fast_kernel(const float *__restrict__ image, int h, int w,
+                                                       const float *__restrict__ kpts, int k, int total,
+                                                       int num_pairs, int normalize,
+                                                       const BadPlan *__restrict__ plan,
+                                                       float *__restrict__ desc, uint32_t *__restrict__ bits,
+                                                       uint8_t *__restrict__ status) {
+  __shared__ int sat_all[4][FW * FW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // XCD-contiguous order: the keypoints of one image run on one XCD, so their overlapping windows
+  // are fetched through one L2 instead of once per XCD
+  const int flat = (int)xcd_contiguous_id(blockIdx.x, gridDim.x) * 4 + wave;
+  if (flat >= total) return;                                   // wave-uniform
+  const int img = flat / k;
+  const float *im = image + (size_t)img * h * w;
+  const float ky = kpts[(size_t)flat * 2 + 0];
+  const float kx = kpts[(size_t)flat * 2 + 1];
+  const int groups = num_pairs / 64;
+  const int words = num_pairs / 32;
+
+  if (!(ky >= 0.0f)) {                                         // invalid keypoint: zero descriptor (bad.py:461,570)
+    if (bits) for (int q = lane; q < words; q += 64) bits[(size_t)flat * words + q] = 0u;
+    if (desc) for (int q = lane; q < num_pairs; q += 64) desc[(size_t)flat * num_pairs + q] = 0.0f;
+    if (lane == 0) status[flat] = 1;
+    return;
+  }
+  const bool interior = ky == floorf(ky) && kx == floorf(kx) && ky >= 15.0f && ky <= (float)(h - 15) &&
+                        kx >= 15.0f && kx <= (float)(w - 15);
+  if (!interior) {
+    if (lane == 0) status[flat] = 0;
+    return;
+  }
+  const int oy = (int)ky - 16, ox = (int)kx - 16;
+  int *isat = sat_all[wave];
+  const int half = lane >> 5, c = lane & 31;
+  // lane = (half, column c): 16 rows of its column, all loads issued before use
+  const int gx = clampi(ox + c, 0, w - 1);
+  float px[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) px[r] = im[(size_t)clampi(oy + 16 * half + r, 0, h - 1) * w + gx];
+  const uint4 *plan_offs = reinterpret_cast<const uint4 *>(plan + 1);
+  const int *plan_tint = reinterpret_cast<const int *>(plan_offs + num_pairs);
+  bool integral = true;
+  int col[16];
+  int acc = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int v = (int)px[r];
+    integral = integral && ((float)v == px[r]) && (v >= 0) && (v <= 255);
+    acc += v;
+    col[r] = acc;
+  }
+  if (!__all(integral)) {
+    if (lane == 0) status[flat] = 0;
+    return;
+  }
+  const int upper = __shfl(acc, c, 64);            // column total of rows 0..15 (held by half 0)
+  if (lane < FW) { isat[lane] = 0; isat[lane * FW] = 0; }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) isat[(16 * half + r + 1) * FW + c + 1] = col[r] + (half ? upper : 0);
+  __builtin_amdgcn_wave_barrier();                 // same wave: DS operations execute in order
+  {
+    int *row = isat + (c + 1) * FW + 16 * half + 1;   // lane = (half, row c): 16 entries of row c
+    int v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = row[q];
+    int racc = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { racc += v[q]; v[q] = racc; }
+    const int left = __shfl(racc, c, 64);          // total of columns 0..15 of this row
+#pragma unroll
+    for (int q = 0; q < 16; ++q) row[q] = v[q] + (half ? left : 0);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const char *sbase = reinterpret_cast<const char *>(isat);
+  unsigned long long wordv[16];
+  int pop = 0;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    wordv[g] = 0ull;
+    if (g < groups) {
+      const uint4 o = plan_offs[g * 64 + lane];
+      const int tint = plan_tint[g * 64 + lane];
+      auto at = [&](uint32_t byte_off) { return *reinterpret_cast<const int *>(sbase + byte_off); };
+      const int s1 = (at(o.x & 0xFFFFu) - at(o.x >> 16)) - (at(o.y & 0xFFFFu) - at(o.y >> 16));
+      const int s2 = (at(o.z & 0xFFFFu) - at(o.z >> 16)) - (at(o.w & 0xFFFFu) - at(o.w >> 16));
+      const unsigned long long word = __ballot((s1 - s2) <= tint);   // bad.py:567
+      wordv[g] = word;
+      pop += (int)__popcll(word);
+      if (bits && lane == 0) {
+        bits[(size_t)flat * words + 2 * g] = (uint32_t)word;
+        bits[(size_t)flat * words + 2 * g + 1] = (uint32_t)(word >> 32);
+      }
+    }
+  }
+  if (desc) {
+    const float inv = normalize ? fmaxf(sqrtf((float)pop), 1e-12f) : 1.0f;       // bad.py:573
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      if (g < groups) {
+        const float v = ((wordv[g] >> lane) & 1ull) ? 1.0f : 0.0f;
+        desc[(size_t)flat * num_pairs + g * 64 + lane] = normalize ? v / inv : v;
+      }
+    }
+  }
+  if (lane == 0) status[flat] = 1;
+}
+
+// ---- general kernel ----------------------------------------------------------------------------
+// status == nullptr: one workgroup (one wave) per keypoint.  status != nullptr: one workgroup per
+// 64 consecutive keypoints; it visits only those the fast kernel flagged (status == 0).
 __global__ __launch_bounds__(64) void sparse_bad_kernel(const float *__restrict__ image, int h, int w,
-                                                        const float *__restrict__ kpts, int k,
+                                                        const float *__restrict__ kpts, int k, int total,
                                                         const uint32_t *__restrict__ geom,
                                                         const float *__restrict__ thr, int num_pairs,
                                                         int mode, float temperature, int normalize,
                                                         float scale_y, float scale_x,
                                                         float *__restrict__ desc,
                                                         uint32_t *__restrict__ bits,
-                                                        const BadPlan *__restrict__ plan) {
+                                                        const uint8_t *__restrict__ status) {
   __shared__ double sat[SP * SP];
-  const uint4 *plan_offs = reinterpret_cast<const uint4 *>(plan + 1);
-  const int *plan_tint = reinterpret_cast<const int *>(plan_offs + num_pairs);
   __shared__ float vals[1024];               // un-normalised descriptor row (num_pairs <= 1024)
   const int lane = threadIdx.x;
-  const int kp = blockIdx.x;                 // keypoint index within the image
-  const int img = blockIdx.y;
-  const float *im = image + (size_t)img * h * w;
-  const float ky_raw = kpts[((size_t)img * k + kp) * 2 + 0];
-  const float kx_raw = kpts[((size_t)img * k + kp) * 2 + 1];
-  const bool valid = ky_raw >= 0.0f;                                   // bad.py:461
-  const float ky = fminf(fmaxf(ky_raw, 0.0f), (float)(h - 1));         // bad.py:464-465
-  const float kx = fminf(fmaxf(kx_raw, 0.0f), (float)(w - 1));
-  const int oy = (int)floorf(ky) - WOFF, ox = (int)floorf(kx) - WOFF;
-
-  // ---- fast path (hard bits): integer keypoint whose 512 box centres need no clamping, over an
-  // integer-valued (uint8) patch.  Then every box lies in the 32x32 window [k-16, k+15], its four
-  // summed-area-table corners are the same for every keypoint (precomputed byte offsets in
-  // `plan`), sums are exact int32 and the sign test is D <= floor(thr * area).  All 64 lanes
-  // build the table: lane = (half, column) holds 16 rows of its column, then lane = (half, row).
-  if (plan != nullptr && mode == MI_BAD_HARD && plan->geometry_ok) {
-    const bool interior = valid && ky == floorf(ky) && kx == floorf(kx) && ky >= 15.0f &&
-                          ky <= (float)(h - 15) && kx >= 15.0f && kx <= (float)(w - 15);
-    if (interior) {                                  // wave-uniform: one keypoint per wave
-      int *isat = reinterpret_cast<int *>(sat);      // [33][33], aliases the fp64 table
-      const int half = lane >> 5, c = lane & 31;
-      const int gx = clampi(ox + c, 0, w - 1);
-      float px[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) px[r] = im[(size_t)clampi(oy + 16 * half + r, 0, h - 1) * w + gx];
-      bool integral = true;
-      int col[16];
-      int acc = 0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int v = (int)px[r];
-        integral = integral && ((float)v == px[r]) && (v >= 0) && (v <= 255);
-        acc += v;
-        col[r] = acc;
-      }
-      if (__all(integral)) {
-        const int upper = __shfl(acc, c, 64);        // column total of rows 0..15 (held by half 0)
-        if (lane < 33) { isat[lane] = 0; isat[lane * 33] = 0; }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) isat[(16 * half + r + 1) * 33 + c + 1] = col[r] + (half ? upper : 0);
-        __syncthreads();
-        {
-          int *row = isat + (c + 1) * 33 + 16 * half + 1;   // lane = (half, row c): 16 entries of row c
-          int v[16];
-#pragma unroll
-          for (int q = 0; q < 16; ++q) v[q] = row[q];
-          int racc = 0;
-#pragma unroll
-          for (int q = 0; q < 16; ++q) { racc += v[q]; v[q] = racc; }
-          const int left = __shfl(racc, c, 64);      // total of columns 0..15 of this row
-#pragma unroll
-          for (int q = 0; q < 16; ++q) row[q] = v[q] + (half ? left : 0);
-        }
-        __syncthreads();
-        const int groups_f = num_pairs / 64;
-        const int words_f = num_pairs / 32;
-        uint32_t *brow_f = bits ? bits + ((size_t)img * k + kp) * words_f : nullptr;
-        const char *sbase = reinterpret_cast<const char *>(isat);
-        unsigned long long wordv[16];
-        int pop_f = 0;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          wordv[g] = 0ull;
-          if (g < groups_f) {
-            const uint4 o = plan_offs[g * 64 + lane];
-            const int tint = plan_tint[g * 64 + lane];
-            auto at = [&](uint32_t byte_off) { return *reinterpret_cast<const int *>(sbase + byte_off); };
-            const int s1 = (at(o.x & 0xFFFFu) - at(o.x >> 16)) - (at(o.y & 0xFFFFu) - at(o.y >> 16));
-            const int s2 = (at(o.z & 0xFFFFu) - at(o.z >> 16)) - (at(o.w & 0xFFFFu) - at(o.w >> 16));
-            const unsigned long long word = __ballot((s1 - s2) <= tint);
-            wordv[g] = word;
-            pop_f += (int)__popcll(word);
-            if (brow_f && lane == 0) {
-              brow_f[2 * g] = (uint32_t)word;
-              brow_f[2 * g + 1] = (uint32_t)(word >> 32);
-            }
-          }
-        }
-        if (desc) {
-          const float inv = normalize ? fmaxf(sqrtf((float)pop_f), 1e-12f) : 1.0f;
-          const size_t drow_f = ((size_t)img * k + kp) * (size_t)num_pairs;
-#pragma unroll
-          for (int g = 0; g < 16; ++g) {
-            if (g < groups_f) {
-              const float v = ((wordv[g] >> lane) & 1ull) ? 1.0f : 0.0f;
-              desc[drow_f + g * 64 + lane] = normalize ? v / inv : v;
-            }
-          }
-        }
-        return;
-      }
-      __syncthreads();   // not integral: fall through to the general path (window reloaded below)
-    }
-  }
-
-  // ---- summed-area table of the replicate-extended window, sat[r+1][c+1] = sum of rows<=r, cols<=c
-  // Lane c < 34 owns window column c: its 34 row loads are all issued before any use (34 loads in
-  // flight per lane, each wave-instruction one 136-byte row segment), the column prefix runs in
-  // registers, then lane r < 34 takes row r for the horizontal prefix (stride 35 doubles between
-  // lanes: conflict-free for ds_read_b64).
   const int groups = num_pairs / 64;
+  const int words = num_pairs / 32;
+
+  unsigned long long todo = 1ull;
+  int first = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);   // one image's keypoints share an XCD's L2
+  if (status) {
+    first = (int)blockIdx.x * 64;
+    const int mine = first + lane;
+    todo = __ballot(mine < total && status[mine] == 0);
+  }
+  // pair table words of the first 8 groups: fetched once, reused for every keypoint of this wave
   uint32_t qg[8];
   float tg[8];
 #pragma unroll
@@ -166,93 +196,109 @@ __global__ __launch_bounds__(64) void sparse_bad_kernel(const float *__restrict_
     qg[g] = (g < groups) ? geom[g * 64 + lane] : 0u;
     tg[g] = (g < groups) ? thr[g * 64 + lane] : 0.0f;
   }
-  for (int i = lane; i < SP; i += 64) { sat[i] = 0.0; sat[i * SP] = 0.0; }
-  if (lane < WIN) {
-    const int gx = clampi(ox + lane, 0, w - 1);
-    float px[WIN];
-#pragma unroll
-    for (int r = 0; r < WIN; ++r) px[r] = im[(size_t)clampi(oy + r, 0, h - 1) * w + gx];
-    double acc = 0.0;
-#pragma unroll
-    for (int r = 0; r < WIN; ++r) {
-      acc += (double)px[r];
-      sat[(r + 1) * SP + (lane + 1)] = acc;
-    }
-  }
-  __syncthreads();
-  if (lane < WIN) {
-    double *row = sat + (lane + 1) * SP + 1;
-    double v[WIN];
-#pragma unroll
-    for (int c = 0; c < WIN; ++c) v[c] = row[c];
-    double acc = 0.0;
-#pragma unroll
-    for (int c = 0; c < WIN; ++c) { acc += v[c]; row[c] = acc; }
-  }
-  __syncthreads();
 
-  const size_t drow = ((size_t)img * k + kp) * (size_t)num_pairs;
-  const int words = num_pairs / 32;
-  uint32_t *brow = bits ? bits + ((size_t)img * k + kp) * words : nullptr;
-  int pop = 0;
-  float sumsq = 0.0f;
+  while (todo) {                                               // wave-uniform loop
+    const int bit = __ffsll((long long)todo) - 1;
+    todo &= todo - 1ull;
+    const int flat = first + bit;
+    const int img = flat / k;
+    const float *im = image + (size_t)img * h * w;
+    const float ky_raw = kpts[(size_t)flat * 2 + 0];
+    const float kx_raw = kpts[(size_t)flat * 2 + 1];
+    const bool valid = ky_raw >= 0.0f;                                   // bad.py:461
+    const float ky = fminf(fmaxf(ky_raw, 0.0f), (float)(h - 1));         // bad.py:464-465
+    const float kx = fminf(fmaxf(kx_raw, 0.0f), (float)(w - 1));
+    const int oy = (int)floorf(ky) - WOFF, ox = (int)floorf(kx) - WOFF;
 
-  // one group = 64 pairs (one per lane).  Geometry/threshold words of the first 8 groups were
-  // fetched before the SAT was built (their latency hides behind it).
-  auto eval_group = [&](int g, uint32_t q, float thr_p) {
-    const int p = g * 64 + lane;
-    const int x1 = (int)(q & 31u) - 16, x2 = (int)((q >> 5) & 31u) - 16;
-    const int y1 = (int)((q >> 10) & 31u) - 16, y2 = (int)((q >> 15) & 31u) - 16;
-    const int r = (int)((q >> 20) & 15u);
-    const int c1y = nearest_centre(ky + (float)y1, scale_y, h) - oy;
-    const int c1x = nearest_centre(kx + (float)x1, scale_x, w) - ox;
-    const int c2y = nearest_centre(ky + (float)y2, scale_y, h) - oy;
-    const int c2x = nearest_centre(kx + (float)x2, scale_x, w) - ox;
-    // box rows [c-r, c+r] of the window -> SAT rows c-r and c+r+1 (clamped: cannot trigger for
-    // table geometry; keeps arbitrary user tables memory-safe)
-    const int a1 = clampi(c1y - r, 0, WIN), b1 = clampi(c1y + r + 1, 0, WIN);
-    const int l1 = clampi(c1x - r, 0, WIN), r1 = clampi(c1x + r + 1, 0, WIN);
-    const int a2 = clampi(c2y - r, 0, WIN), b2 = clampi(c2y + r + 1, 0, WIN);
-    const int l2 = clampi(c2x - r, 0, WIN), r2 = clampi(c2x + r + 1, 0, WIN);
-    const double s1 = (sat[b1 * SP + r1] - sat[a1 * SP + r1]) - (sat[b1 * SP + l1] - sat[a1 * SP + l1]);
-    const double s2 = (sat[b2 * SP + r2] - sat[a2 * SP + r2]) - (sat[b2 * SP + l2] - sat[a2 * SP + l2]);
-    const double area = (double)((2 * r + 1) * (2 * r + 1));
-    const double t = (double)thr_p;
-    if (mode == MI_BAD_HARD) {
-      // bit = (mean1 - mean2 - t <= 0)  <=>  s1 - s2 <= t * area   (t*area exact in fp64)
-      const bool bit = valid && ((s1 - s2) <= t * area);                // bad.py:567,570
-      const unsigned long long word = __ballot(bit);
-      pop += (int)__popcll(word);
-      if (brow && lane == 0) {
-        brow[2 * g] = (uint32_t)word;
-        brow[2 * g + 1] = (uint32_t)(word >> 32);
+    // summed-area table of the replicate-extended window, sat[r+1][c+1] = sum of rows<=r, cols<=c.
+    // Lane c < 34 owns window column c (34 loads in flight), column prefix in registers, then
+    // lane r < 34 takes row r (stride 35 doubles between lanes: conflict-free for ds_read_b64).
+    __syncthreads();                                                     // previous keypoint's reads are done
+    for (int i = lane; i < SP; i += 64) { sat[i] = 0.0; sat[i * SP] = 0.0; }
+    if (lane < WIN) {
+      const int gx = clampi(ox + lane, 0, w - 1);
+      float px[WIN];
+#pragma unroll
+      for (int r = 0; r < WIN; ++r) px[r] = im[(size_t)clampi(oy + r, 0, h - 1) * w + gx];
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < WIN; ++r) {
+        acc += (double)px[r];
+        sat[(r + 1) * SP + (lane + 1)] = acc;
       }
-      if (desc) vals[p] = bit ? 1.0f : 0.0f;
-    } else {
-      const float c = (float)((s1 - s2) / area - t);                    // bad.py:559
-      float v = c;
-      if (mode == MI_BAD_SOFT) v = 1.0f / (1.0f + expf(c * temperature));  // sigmoid(-c*T), bad.py:565
-      v = valid ? v : 0.0f;
-      sumsq += v * v;
-      vals[p] = v;
     }
-  };
+    __syncthreads();
+    if (lane < WIN) {
+      double *row = sat + (lane + 1) * SP + 1;
+      double v[WIN];
 #pragma unroll
-  for (int g = 0; g < 8; ++g)
-    if (g < groups) eval_group(g, qg[g], tg[g]);
-#pragma unroll 1
-  for (int g = 8; g < groups; ++g) eval_group(g, geom[g * 64 + lane], thr[g * 64 + lane]);
+      for (int c = 0; c < WIN; ++c) v[c] = row[c];
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < WIN; ++c) { acc += v[c]; row[c] = acc; }
+    }
+    __syncthreads();
 
-  if (!desc) return;
-  float inv = 1.0f;
-  if (normalize) {                                                      // F.normalize(p=2, eps=1e-12), bad.py:573
-    const float ss = (mode == MI_BAD_HARD) ? (float)pop : wave_sum(sumsq);
-    inv = fmaxf(sqrtf(ss), 1e-12f);
-  }
-  // each lane re-reads only what it wrote itself (p = g*64 + lane): no barrier needed
-  for (int g = 0; g < groups; ++g) {
-    const float v = vals[g * 64 + lane];
-    desc[drow + g * 64 + lane] = normalize ? v / inv : v;
+    const size_t drow = (size_t)flat * (size_t)num_pairs;
+    uint32_t *brow = bits ? bits + (size_t)flat * words : nullptr;
+    int pop = 0;
+    float sumsq = 0.0f;
+    auto eval_group = [&](int g, uint32_t q, float thr_p) {
+      const int p = g * 64 + lane;
+      const int x1 = (int)(q & 31u) - 16, x2 = (int)((q >> 5) & 31u) - 16;
+      const int y1 = (int)((q >> 10) & 31u) - 16, y2 = (int)((q >> 15) & 31u) - 16;
+      const int r = (int)((q >> 20) & 15u);
+      const int c1y = nearest_centre(ky + (float)y1, scale_y, h) - oy;
+      const int c1x = nearest_centre(kx + (float)x1, scale_x, w) - ox;
+      const int c2y = nearest_centre(ky + (float)y2, scale_y, h) - oy;
+      const int c2x = nearest_centre(kx + (float)x2, scale_x, w) - ox;
+      // box rows [c-r, c+r] of the window -> SAT rows c-r and c+r+1 (clamped: cannot trigger for
+      // table geometry; keeps arbitrary user tables memory-safe)
+      const int a1 = clampi(c1y - r, 0, WIN), b1 = clampi(c1y + r + 1, 0, WIN);
+      const int l1 = clampi(c1x - r, 0, WIN), r1 = clampi(c1x + r + 1, 0, WIN);
+      const int a2 = clampi(c2y - r, 0, WIN), b2 = clampi(c2y + r + 1, 0, WIN);
+      const int l2 = clampi(c2x - r, 0, WIN), r2 = clampi(c2x + r + 1, 0, WIN);
+      const double s1 = (sat[b1 * SP + r1] - sat[a1 * SP + r1]) - (sat[b1 * SP + l1] - sat[a1 * SP + l1]);
+      const double s2 = (sat[b2 * SP + r2] - sat[a2 * SP + r2]) - (sat[b2 * SP + l2] - sat[a2 * SP + l2]);
+      const double area = (double)((2 * r + 1) * (2 * r + 1));
+      const double t = (double)thr_p;
+      if (mode == MI_BAD_HARD) {
+        // bit = (mean1 - mean2 - t <= 0)  <=>  s1 - s2 <= t * area   (t*area exact in fp64)
+        const bool bitv = valid && ((s1 - s2) <= t * area);              // bad.py:567,570
+        const unsigned long long word = __ballot(bitv);
+        pop += (int)__popcll(word);
+        if (brow && lane == 0) {
+          brow[2 * g] = (uint32_t)word;
+          brow[2 * g + 1] = (uint32_t)(word >> 32);
+        }
+        if (desc) vals[p] = bitv ? 1.0f : 0.0f;
+      } else {
+        const float c = (float)((s1 - s2) / area - t);                   // bad.py:559
+        float v = c;
+        if (mode == MI_BAD_SOFT) v = 1.0f / (1.0f + expf(c * temperature));   // sigmoid(-c*T), bad.py:565
+        v = valid ? v : 0.0f;
+        sumsq += v * v;
+        vals[p] = v;
+      }
+    };
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+      if (g < groups) eval_group(g, qg[g], tg[g]);
+#pragma unroll 1
+    for (int g = 8; g < groups; ++g) eval_group(g, geom[g * 64 + lane], thr[g * 64 + lane]);
+
+    if (desc) {
+      float inv = 1.0f;
+      if (normalize) {                                                   // F.normalize(p=2, eps=1e-12), bad.py:573
+        const float ss = (mode == MI_BAD_HARD) ? (float)pop : wave_sum(sumsq);
+        inv = fmaxf(sqrtf(ss), 1e-12f);
+      }
+      // each lane re-reads only what it wrote itself (p = g*64 + lane)
+      for (int g = 0; g < groups; ++g) {
+        const float v = vals[g * 64 + lane];
+        desc[drow + g * 64 + lane] = normalize ? v / inv : v;
+      }
+    }
   }
 }
 
@@ -285,6 +331,12 @@ __global__ __launch_bounds__(64) void bad_plan_kernel(const uint32_t *__restrict
   }
 }
 
+__global__ void bad_plan_gate_kernel(const BadPlan *__restrict__ plan, uint8_t *__restrict__ status, int total) {
+  // a plan whose geometry check failed must not be used: hand every keypoint to the general kernel
+  if (plan->geometry_ok) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) status[i] = 0;
+}
+
 }  // namespace
 
 extern "C" size_t mi_bad_plan_bytes(int num_pairs) {
@@ -305,19 +357,32 @@ extern "C" int mi_bad_plan_build(const uint32_t *pair_geom, const float *pair_th
 extern "C" int mi_sparse_bad(const float *image, int n, int h, int w, const float *keypoints, int k,
                              const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
                              float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
-                             mi_stream_t stream) {
+                             uint8_t *status, mi_stream_t stream) {
   if (!image || !keypoints || !pair_geom || !pair_thr) return MI_E_NULL;
   if (!desc && !bits) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0 || k <= 0) return MI_E_SHAPE;
   if (num_pairs <= 0 || num_pairs % 64 != 0 || num_pairs > 1024) return MI_E_PARAM;
   if (mode != MI_BAD_RAW && mode != MI_BAD_SOFT && mode != MI_BAD_HARD) return MI_E_PARAM;
   if (bits && mode != MI_BAD_HARD) return MI_E_PARAM;
-  if (n > 65535) return MI_E_SHAPE;
+  if ((long long)n * k > 0x7fffffffLL) return MI_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int total = n * k;
   // bad.py:469-470: python double 2/(size-1+1e-8), multiplied into an fp32 tensor
   const float scale_y = (float)(2.0 / ((double)(h - 1) + 1e-8));
   const float scale_x = (float)(2.0 / ((double)(w - 1) + 1e-8));
-  hipLaunchKernelGGL(sparse_bad_kernel, dim3(k, n), dim3(64), 0, (hipStream_t)stream, image, h, w, keypoints,
-                     k, pair_geom, pair_thr, num_pairs, mode, temperature, normalize, scale_y, scale_x, desc,
-                     bits, reinterpret_cast<const BadPlan *>(plan));
+  const bool fast = plan != nullptr && status != nullptr && mode == MI_BAD_HARD && h >= 32 && w >= 32;
+  if (fast) {
+    const BadPlan *bp = reinterpret_cast<const BadPlan *>(plan);
+    hipLaunchKernelGGL(bad_fast_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, s, image, h, w, keypoints,
+                       k, total, num_pairs, normalize, bp, desc, bits, status);
+    hipLaunchKernelGGL(bad_plan_gate_kernel, dim3(64), dim3(256), 0, s, bp, status, total);
+    hipLaunchKernelGGL(sparse_bad_kernel, dim3((unsigned)ceil_div(total, 64)), dim3(64), 0, s, image, h, w, keypoints,
+                       k, total, pair_geom, pair_thr, num_pairs, mode, temperature, normalize, scale_y, scale_x,
+                       desc, bits, status);
+  } else {
+    hipLaunchKernelGGL(sparse_bad_kernel, dim3((unsigned)total), dim3(64), 0, s, image, h, w, keypoints, k, total,
+                       pair_geom, pair_thr, num_pairs, mode, temperature, normalize, scale_y, scale_x, desc, bits,
+                       nullptr);
+  }
   return mi_launch_status();
 }

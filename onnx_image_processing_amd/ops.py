@@ -115,7 +115,9 @@ def sparse_bad(image: torch.Tensor, keypoints: torch.Tensor, pair_geom: torch.Te
     N.call("mi_sparse_bad", N.dev(img, F32, "image"), n, h, w, N.dev(kp, F32, "keypoints"), k,
            N.dev(pair_geom, torch.int32, "pair_geom"), N.dev(pair_thr, F32, "pair_thr"), p, int(mode),
            float(temperature), int(bool(normalize)), desc.data_ptr() if want_desc else None,
-           bits.data_ptr() if want_bits else None, plan.data_ptr() if plan is not None else None, N.stream_ptr())
+           bits.data_ptr() if want_bits else None, plan.data_ptr() if plan is not None else None,
+           torch.empty((n * k,), dtype=torch.uint8, device=img.device).data_ptr() if plan is not None else None,
+           N.stream_ptr())
     return desc, bits
 
 
