@@ -103,6 +103,25 @@ int mi_sparse_bad(const float *image, int n, int h, int w, const float *keypoint
                   float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
                   uint8_t *status, mi_stream_t stream);
 
+/* ---- orientation/angle_estimation.py:86-172  AngleEstimator.forward --------------------------
+ * angle = atan2(m01, m10) of the Gaussian-weighted first moments, conv with ZERO padding.
+ * moment_kernels: the module's (2,1,ps,ps) weight buffer (x*G then y*G), patch_size odd <= 31.
+ * mi_angle_map writes the dense (n,1,h,w) map; mi_angle_at_keypoints writes theta (n,k) only at
+ * the keypoints (what descriptor/bad.py:487-500 samples from the map, same nearest rounding). */
+int mi_angle_map(const float *image, int n, int h, int w, int patch_size, const float *moment_kernels,
+                 float *angle, mi_stream_t stream);
+int mi_angle_at_keypoints(const float *image, int n, int h, int w, const float *keypoints, int k,
+                          int patch_size, const float *moment_kernels, float *theta, mi_stream_t stream);
+
+/* ---- descriptor/bad.py:487-517  SparseBAD.forward, oriented branch (sampling "nearest") -------
+ * Pair offsets rotated by the keypoint's angle, which comes either from a dense orientation map
+ * (n,1,h,w) sampled at the keypoint, or from a per-keypoint array (n,k): exactly one non-NULL. */
+int mi_sparse_bad_oriented(const float *image, int n, int h, int w, const float *keypoints, int k,
+                           const float *orientation_map, const float *keypoint_angles,
+                           const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
+                           float temperature, int normalize, float *desc, uint32_t *bits,
+                           mi_stream_t stream);
+
 /* ---- matching/sinkhorn.py:79-110,178  cost matrix -> core log-score matrix --------------------
  * z[b, i, j] = -cost(desc1[b,i], desc2[b,j]) / epsilon for i < n, j < m; row pitch `pitch` floats
  * (pitch % 4 == 0, pitch >= m, z 16-byte aligned).  The dustbin row/column of the reference's
@@ -148,6 +167,13 @@ size_t mi_sinkhorn_dots_workspace_bytes(int batch, int n, int m);
 int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch, int n,
                      int m, int pitch, double epsilon, double unused_score, int iterations, float *u,
                      float *v, float *p, void *workspace, size_t workspace_bytes, mi_stream_t stream);
+
+/* ---- matching/sinkhorn.py:317-465  SinkhornMatcherWithFilters (filter stage) -----------------
+ * In place on p (batch, n+1, m+1): per row i < n, best/second-best core probability and the
+ * dustbin entry decide valid[b,i] (ratio_threshold <= 0 / dustbin_margin < 0 disable a filter);
+ * failing rows get core * 0 and dustbin entry 1, as the reference writes them. */
+int mi_match_filters(float *p, int batch, int n, int m, float ratio_threshold, float dustbin_margin,
+                     uint8_t *valid, mi_stream_t stream);
 
 /* ---- matching/match_extraction.py:72-181  MutualNearestNeighborMatcher.forward --------------
  * p (batch, n+1, m+1); kpts1 (batch,n,2); kpts2 (batch,m,2).  Workspace: row_best (batch*n) u64,

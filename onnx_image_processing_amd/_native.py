@@ -30,6 +30,10 @@ SIGNATURES = {
     "mi_bad_plan_build": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "mi_sparse_bad": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mi_angle_map": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "mi_angle_at_keypoints": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "mi_sparse_bad_oriented": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p],
     "mi_cost_logscores_bits": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p],
     "mi_cost_logscores_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p],
     "mi_sinkhorn_workspace_bytes": [c_int, c_int, c_int],
@@ -40,6 +44,7 @@ SIGNATURES = {
     "mi_sinkhorn_dots_workspace_bytes": [c_int, c_int, c_int],
     "mi_sinkhorn_dots": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_int,
                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
+    "mi_match_filters": [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p],
     "mi_mnn_extract": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
 }

@@ -1,0 +1,163 @@
+// K4 (oriented): sparse BAD descriptors with the pair offsets rotated by the keypoint's angle.
+// Semantics: reference pytorch_model/descriptor/bad.py:487-517 (oriented branch) + :518-574:
+//   theta  = grid_sample(orientation, keypoint, nearest)            (or a per-keypoint angle)
+//   dy = ox*sin + oy*cos ; dx = ox*cos - oy*sin   (ox, oy = table offset - 16, fp32 op by op)
+//   pos = keypoint + (dy, dx) ; centre = grid_sample "nearest" arithmetic ; box mean over the
+//   replicate-extended image ; response = mean1 - mean2 - thr ; raw / sigmoid / hard bit.
+// Rotated offsets reach sqrt(15^2+15^2) = 21.2 px; with the box radius (<= 7) and the rounding
+// of the centre every box lies in the 60x60 window [f-29, f+30] around f = floor(keypoint)
+// (same clamping argument as the non-oriented kernel).  One wave per keypoint, fp64 summed-area
+// table in LDS (exact for integer images): lane c owns window column c, then row c.
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int OW = 60;            // window edge
+constexpr int OOFF = 29;          // window origin = floor(k) - OOFF
+constexpr int OSP = OW + 1;       // SAT edge
+
+__device__ __forceinline__ int nearest_centre_o(float pos, float scale, int size) {
+  const float g = pos * scale - 1.0f;
+  float x = ((g + 1.0f) / 2.0f) * (float)(size - 1);
+  x = fminf(fmaxf(x, 0.0f), (float)(size - 1));
+  return (int)nearbyintf(x);
+}
+
+__global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restrict__ image, int h, int w,
+                                                          const float *__restrict__ kpts, int k,
+                                                          const float *__restrict__ theta_map,
+                                                          const float *__restrict__ theta_kp,
+                                                          const uint32_t *__restrict__ geom,
+                                                          const float *__restrict__ thr, int num_pairs, int mode,
+                                                          float temperature, int normalize, float scale_y,
+                                                          float scale_x, float *__restrict__ desc,
+                                                          uint32_t *__restrict__ bits) {
+  __shared__ double sat[OSP * OSP];
+  __shared__ float vals[1024];
+  const int lane = threadIdx.x;
+  const int flat = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int img = flat / k;
+  const float *im = image + (size_t)img * h * w;
+  const float ky_raw = kpts[(size_t)flat * 2 + 0];
+  const float kx_raw = kpts[(size_t)flat * 2 + 1];
+  const bool valid = ky_raw >= 0.0f;                                   // bad.py:461
+  const float ky = fminf(fmaxf(ky_raw, 0.0f), (float)(h - 1));         // bad.py:464-465
+  const float kx = fminf(fmaxf(kx_raw, 0.0f), (float)(w - 1));
+  float theta;
+  if (theta_map) {                                                     // bad.py:490-500
+    const int cy = nearest_centre_o(ky, scale_y, h), cx = nearest_centre_o(kx, scale_x, w);
+    theta = theta_map[((size_t)img * h + cy) * w + cx];
+  } else {
+    theta = theta_kp[flat];
+  }
+  const float cos_t = cosf(theta), sin_t = sinf(theta);                // bad.py:502-503
+  const int oy = (int)floorf(ky) - OOFF, ox = (int)floorf(kx) - OOFF;
+  const int groups = num_pairs / 64;
+  const int words = num_pairs / 32;
+
+  for (int i = lane; i < OSP; i += 64) { sat[i] = 0.0; sat[i * OSP] = 0.0; }
+  if (lane < OW) {
+    const int gx = clampi(ox + lane, 0, w - 1);
+    double acc = 0.0;
+#pragma unroll 4
+    for (int r0 = 0; r0 < OW; r0 += 15) {
+      float px[15];
+#pragma unroll
+      for (int r = 0; r < 15; ++r) px[r] = im[(size_t)clampi(oy + r0 + r, 0, h - 1) * w + gx];
+#pragma unroll
+      for (int r = 0; r < 15; ++r) {
+        acc += (double)px[r];
+        sat[(r0 + r + 1) * OSP + (lane + 1)] = acc;
+      }
+    }
+  }
+  __syncthreads();
+  if (lane < OW) {
+    double *row = sat + (lane + 1) * OSP + 1;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int c0 = 0; c0 < OW; c0 += 15) {
+      double v[15];
+#pragma unroll
+      for (int c = 0; c < 15; ++c) v[c] = row[c0 + c];
+#pragma unroll
+      for (int c = 0; c < 15; ++c) { acc += v[c]; row[c0 + c] = acc; }
+    }
+  }
+  __syncthreads();
+
+  uint32_t *brow = bits ? bits + (size_t)flat * words : nullptr;
+  int pop = 0;
+  float sumsq = 0.0f;
+  for (int g = 0; g < groups; ++g) {
+    const int p = g * 64 + lane;
+    const uint32_t q = geom[p];
+    const float ox1 = (float)((int)(q & 31u) - 16), ox2 = (float)((int)((q >> 5) & 31u) - 16);
+    const float oy1 = (float)((int)((q >> 10) & 31u) - 16), oy2 = (float)((int)((q >> 15) & 31u) - 16);
+    const int r = (int)((q >> 20) & 15u);
+    // bad.py:505-517: rot_dy = ox*sin + oy*cos ; rot_dx = ox*cos - oy*sin ; pos = kp + rot
+    const float p1y = ky + (ox1 * sin_t + oy1 * cos_t), p1x = kx + (ox1 * cos_t - oy1 * sin_t);
+    const float p2y = ky + (ox2 * sin_t + oy2 * cos_t), p2x = kx + (ox2 * cos_t - oy2 * sin_t);
+    const int c1y = nearest_centre_o(p1y, scale_y, h) - oy, c1x = nearest_centre_o(p1x, scale_x, w) - ox;
+    const int c2y = nearest_centre_o(p2y, scale_y, h) - oy, c2x = nearest_centre_o(p2x, scale_x, w) - ox;
+    const int a1 = clampi(c1y - r, 0, OW), b1 = clampi(c1y + r + 1, 0, OW);
+    const int l1 = clampi(c1x - r, 0, OW), r1 = clampi(c1x + r + 1, 0, OW);
+    const int a2 = clampi(c2y - r, 0, OW), b2 = clampi(c2y + r + 1, 0, OW);
+    const int l2 = clampi(c2x - r, 0, OW), r2 = clampi(c2x + r + 1, 0, OW);
+    const double s1 = (sat[b1 * OSP + r1] - sat[a1 * OSP + r1]) - (sat[b1 * OSP + l1] - sat[a1 * OSP + l1]);
+    const double s2 = (sat[b2 * OSP + r2] - sat[a2 * OSP + r2]) - (sat[b2 * OSP + l2] - sat[a2 * OSP + l2]);
+    const double area = (double)((2 * r + 1) * (2 * r + 1));
+    const double t = (double)thr[p];
+    if (mode == MI_BAD_HARD) {
+      const bool bitv = valid && ((s1 - s2) <= t * area);               // bad.py:567,570
+      const unsigned long long word = __ballot(bitv);
+      pop += (int)__popcll(word);
+      if (brow && lane == 0) {
+        brow[2 * g] = (uint32_t)word;
+        brow[2 * g + 1] = (uint32_t)(word >> 32);
+      }
+      if (desc) vals[p] = bitv ? 1.0f : 0.0f;
+    } else {
+      const float c = (float)((s1 - s2) / area - t);                    // bad.py:559
+      float v = c;
+      if (mode == MI_BAD_SOFT) v = 1.0f / (1.0f + expf(c * temperature));   // bad.py:565
+      v = valid ? v : 0.0f;
+      sumsq += v * v;
+      vals[p] = v;
+    }
+  }
+  if (!desc) return;
+  float inv = 1.0f;
+  if (normalize) {                                                      // bad.py:573
+    const float ss = (mode == MI_BAD_HARD) ? (float)pop : wave_sum(sumsq);
+    inv = fmaxf(sqrtf(ss), 1e-12f);
+  }
+  for (int g = 0; g < groups; ++g) {
+    const float v = vals[g * 64 + lane];
+    desc[(size_t)flat * num_pairs + g * 64 + lane] = normalize ? v / inv : v;
+  }
+}
+
+}  // namespace
+
+extern "C" int mi_sparse_bad_oriented(const float *image, int n, int h, int w, const float *keypoints, int k,
+                                      const float *orientation_map, const float *keypoint_angles,
+                                      const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
+                                      float temperature, int normalize, float *desc, uint32_t *bits,
+                                      mi_stream_t stream) {
+  if (!image || !keypoints || !pair_geom || !pair_thr) return MI_E_NULL;
+  if (!orientation_map == !keypoint_angles) return MI_E_NULL;          // exactly one angle source
+  if (!desc && !bits) return MI_E_NULL;
+  if (n <= 0 || h <= 0 || w <= 0 || k <= 0 || (long long)n * k > 0x7fffffffLL) return MI_E_SHAPE;
+  if (num_pairs <= 0 || num_pairs % 64 != 0 || num_pairs > 1024) return MI_E_PARAM;
+  if (mode != MI_BAD_RAW && mode != MI_BAD_SOFT && mode != MI_BAD_HARD) return MI_E_PARAM;
+  if (bits && mode != MI_BAD_HARD) return MI_E_PARAM;
+  const float scale_y = (float)(2.0 / ((double)(h - 1) + 1e-8));
+  const float scale_x = (float)(2.0 / ((double)(w - 1) + 1e-8));
+  hipLaunchKernelGGL(bad_oriented_kernel, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, image, h, w,
+                     keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, num_pairs, mode, temperature,
+                     normalize, scale_y, scale_x, desc, bits);
+  return mi_launch_status();
+}

@@ -147,6 +147,54 @@ extern "C" int mi_mnn_extract(const float *p, int batch, int n, int m, const flo
   return mi_launch_status();
 }
 
+// ---- outlier filters on P: reference matching/sinkhorn.py:317-465 (SinkhornMatcherWithFilters) --
+// Per row i < n of P: best and second-best core probability (top-2 with multiplicity, as
+// torch.topk), dustbin entry d = P[i, m].  valid = (ratio_threshold <= 0 or best/(second+1e-8) >=
+// ratio_threshold) and (dustbin_margin < 0 or best - d >= dustbin_margin).  Rows that fail are
+// rewritten in place as the reference does (:441-463): core entries *0, dustbin entry 1.
+namespace {
+__global__ __launch_bounds__(256) void match_filters_kernel(float *__restrict__ p, int n, int m,
+                                                            float ratio_threshold, float dustbin_margin,
+                                                            uint8_t *__restrict__ valid) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, i = blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  float *pr = p + ((size_t)b * (n + 1) + i) * (size_t)(m + 1);
+  float a1 = -INFINITY, a2 = -INFINITY;             // lane-local two largest
+  for (int j = lane; j < m; j += 64) {
+    const float x = pr[j];
+    if (x > a1) { a2 = a1; a1 = x; } else if (x > a2) { a2 = x; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float b1 = __shfl_xor(a1, o, 64), b2 = __shfl_xor(a2, o, 64);
+    const float hi = fmaxf(a1, b1), lo = fminf(a1, b1);
+    a2 = fmaxf(lo, fmaxf(a2, b2));
+    a1 = hi;
+  }
+  const float best = a1;
+  const float second = (m >= 2) ? a2 : 0.0f;        // sinkhorn.py:346-348
+  const float dust = pr[m];
+  bool ok = true;
+  if (ratio_threshold > 0.0f) ok = ok && (best / (second + 1e-8f) >= ratio_threshold);   // :350-351
+  if (dustbin_margin >= 0.0f) ok = ok && ((best - dust) >= dustbin_margin);             // :384-386
+  if (lane == 0) valid[(size_t)b * n + i] = ok ? 1 : 0;
+  if (!ok) {
+    for (int j = lane; j < m; j += 64) pr[j] = pr[j] * 0.0f;
+    if (lane == 0) pr[m] = 1.0f + 0.0f * dust;
+  }
+}
+}  // namespace
+
+extern "C" int mi_match_filters(float *p, int batch, int n, int m, float ratio_threshold, float dustbin_margin,
+                                uint8_t *valid, mi_stream_t stream) {
+  if (!p || !valid) return MI_E_NULL;
+  if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
+  hipLaunchKernelGGL(match_filters_kernel, dim3(ceil_div(n, 4), batch), dim3(256), 0, (hipStream_t)stream, p, n, m,
+                     ratio_threshold, dustbin_margin, valid);
+  return mi_launch_status();
+}
+
 extern "C" int mi_abi_version(void) { return 1; }
 
 extern "C" const char *mi_error_string(int code) {

@@ -1,0 +1,128 @@
+// K8: orientation from Gaussian-weighted first moments.
+// Semantics: reference pytorch_model/orientation/angle_estimation.py:86-172 (AngleEstimator):
+//   moments = conv2d(image, moment_kernels (2,1,ps,ps), padding = ps//2)   [ZERO padding]
+//   angle   = atan2(m01, m10),  m10 = sum x*G*I,  m01 = sum y*G*I
+// The weights are the module's own `moment_kernels` buffer (built on the host exactly as the
+// reference builds it), so both sides multiply by bit-identical fp32 weights; only the fp32
+// summation order differs (the reference's is oneDNN's), hence tolerance parity.
+//
+// Two entry points:
+//  * mi_angle_map: the dense (n,1,h,w) map AngleEstimator.forward returns.  Tile 64x16 in LDS
+//    (+halo), each thread 4 adjacent pixels, the weight planes in LDS.
+//  * mi_angle_at_keypoints: only what the matching pipeline consumes -- the angle at the K
+//    keypoints (the reference samples its dense map there with grid_sample(nearest),
+//    descriptor/bad.py:487-500).  One wave per keypoint, 4 pixels of the patch per lane.
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int AT_W = 64, AT_H = 16;   // dense tile
+constexpr int MAX_PS = 31;
+
+__global__ __launch_bounds__(256) void angle_map_kernel(const float *__restrict__ image, int h, int w, int ps,
+                                                        const float *__restrict__ weights,
+                                                        float *__restrict__ angle, int tiles_x, int tiles_y) {
+  extern __shared__ float lds[];
+  const int half = ps / 2;
+  const int sw = AT_W + 2 * half, sh = AT_H + 2 * half;
+  float *tile = lds;                       // [sh][sw], zero outside the image
+  float *wx = lds + sh * sw;               // [ps*ps] x-moment weights
+  float *wy = wx + ps * ps;                // [ps*ps] y-moment weights
+  const int t = threadIdx.x;
+  int bid = (int)blockIdx.x;
+  const int tx_tile = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty_tile = bid % tiles_y;
+  const int img = bid / tiles_y;
+  const int x0 = tx_tile * AT_W, y0 = ty_tile * AT_H;
+  const float *im = image + (size_t)img * h * w;
+  for (int i = t; i < sh * sw; i += 256) {
+    const int r = i / sw, c = i - r * sw;
+    const int gy = y0 - half + r, gx = x0 - half + c;
+    tile[i] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? im[(size_t)gy * w + gx] : 0.0f;
+  }
+  for (int i = t; i < ps * ps; i += 256) { wx[i] = weights[i]; wy[i] = weights[ps * ps + i]; }
+  __syncthreads();
+  const int lx = (t & 15) * 4, ly = t >> 4;          // 16 x 16 threads, 4 pixels each
+  float m10[4] = {0.f, 0.f, 0.f, 0.f}, m01[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int dy = 0; dy < ps; ++dy) {
+    const float *row = tile + (ly + dy) * sw + lx;
+    const float *rx = wx + dy * ps, *ry = wy + dy * ps;
+    for (int dx = 0; dx < ps; ++dx) {
+      const float a = rx[dx], b = ry[dx];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v = row[dx + q];
+        m10[q] += a * v;
+        m01[q] += b * v;
+      }
+    }
+  }
+  const int gy = y0 + ly;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int gx = x0 + lx + q;
+    if (gy < h && gx < w) angle[((size_t)img * h + gy) * w + gx] = atan2f(m01[q], m10[q]);   // :170
+  }
+}
+
+__global__ __launch_bounds__(64) void angle_kp_kernel(const float *__restrict__ image, int h, int w,
+                                                      const float *__restrict__ kpts, int k, int ps,
+                                                      const float *__restrict__ weights,
+                                                      float *__restrict__ theta) {
+  const int lane = threadIdx.x;
+  const int flat = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int img = flat / k;
+  const float *im = image + (size_t)img * h * w;
+  // the reference samples the dense angle map at the clamped keypoint with grid_sample(nearest):
+  // same normalise / un-normalise / round-half-even arithmetic as the descriptor's centres
+  const float ky = fminf(fmaxf(kpts[(size_t)flat * 2 + 0], 0.0f), (float)(h - 1));   // bad.py:464-465
+  const float kx = fminf(fmaxf(kpts[(size_t)flat * 2 + 1], 0.0f), (float)(w - 1));
+  const float sy = (float)(2.0 / ((double)(h - 1) + 1e-8)), sx = (float)(2.0 / ((double)(w - 1) + 1e-8));
+  float ny = ((ky * sy - 1.0f + 1.0f) / 2.0f) * (float)(h - 1);
+  float nx = ((kx * sx - 1.0f + 1.0f) / 2.0f) * (float)(w - 1);
+  const int cy = (int)nearbyintf(fminf(fmaxf(ny, 0.0f), (float)(h - 1)));
+  const int cx = (int)nearbyintf(fminf(fmaxf(nx, 0.0f), (float)(w - 1)));
+  const int half = ps / 2;
+  float m10 = 0.0f, m01 = 0.0f;
+  for (int i = lane; i < ps * ps; i += 64) {
+    const int dy = i / ps, dx = i - dy * ps;
+    const int gy = cy + dy - half, gx = cx + dx - half;
+    const float v = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? im[(size_t)gy * w + gx] : 0.0f;   // zero padding
+    m10 += weights[i] * v;
+    m01 += weights[ps * ps + i] * v;
+  }
+  m10 = wave_sum(m10);
+  m01 = wave_sum(m01);
+  if (lane == 0) theta[flat] = atan2f(m01, m10);
+}
+
+}  // namespace
+
+extern "C" int mi_angle_map(const float *image, int n, int h, int w, int patch_size, const float *moment_kernels,
+                            float *angle, mi_stream_t stream) {
+  if (!image || !moment_kernels || !angle) return MI_E_NULL;
+  if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
+  if (patch_size <= 0 || (patch_size & 1) == 0 || patch_size > MAX_PS) return MI_E_PARAM;
+  const int tiles_x = ceil_div(w, AT_W), tiles_y = ceil_div(h, AT_H);
+  const long long blocks = (long long)n * tiles_x * tiles_y;
+  if (blocks > 0x7fffffffLL) return MI_E_SHAPE;
+  const int half = patch_size / 2;
+  const size_t lds = ((size_t)(AT_W + 2 * half) * (AT_H + 2 * half) + 2 * (size_t)patch_size * patch_size) * 4;
+  hipLaunchKernelGGL(angle_map_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, image, h, w,
+                     patch_size, moment_kernels, angle, tiles_x, tiles_y);
+  return mi_launch_status();
+}
+
+extern "C" int mi_angle_at_keypoints(const float *image, int n, int h, int w, const float *keypoints, int k,
+                                     int patch_size, const float *moment_kernels, float *theta,
+                                     mi_stream_t stream) {
+  if (!image || !keypoints || !moment_kernels || !theta) return MI_E_NULL;
+  if (n <= 0 || h <= 0 || w <= 0 || k <= 0 || (long long)n * k > 0x7fffffffLL) return MI_E_SHAPE;
+  if (patch_size <= 0 || (patch_size & 1) == 0 || patch_size > MAX_PS) return MI_E_PARAM;
+  hipLaunchKernelGGL(angle_kp_kernel, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, image, h, w,
+                     keypoints, k, patch_size, moment_kernels, theta);
+  return mi_launch_status();
+}

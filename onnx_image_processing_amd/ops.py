@@ -121,6 +121,54 @@ def sparse_bad(image: torch.Tensor, keypoints: torch.Tensor, pair_geom: torch.Te
     return desc, bits
 
 
+def angle_map(image: torch.Tensor, moment_kernels: torch.Tensor, patch_size: int) -> torch.Tensor:
+    img = _images(image, "image")
+    n, _, h, w = img.shape
+    out = torch.empty_like(img)
+    N.call("mi_angle_map", N.dev(img, F32, "image"), n, h, w, int(patch_size),
+           N.dev(moment_kernels.contiguous(), F32, "moment_kernels"), out.data_ptr(), N.stream_ptr())
+    return out
+
+
+def angle_at_keypoints(image: torch.Tensor, keypoints: torch.Tensor, moment_kernels: torch.Tensor,
+                       patch_size: int) -> torch.Tensor:
+    img = _images(image, "image")
+    n, _, h, w = img.shape
+    kp = keypoints.float().contiguous()
+    theta = torch.empty((n, kp.shape[1]), dtype=F32, device=img.device)
+    N.call("mi_angle_at_keypoints", N.dev(img, F32, "image"), n, h, w, N.dev(kp, F32, "keypoints"), kp.shape[1],
+           int(patch_size), N.dev(moment_kernels.contiguous(), F32, "moment_kernels"), theta.data_ptr(),
+           N.stream_ptr())
+    return theta
+
+
+def sparse_bad_oriented(image: torch.Tensor, keypoints: torch.Tensor, orientation: torch.Tensor,
+                        pair_geom: torch.Tensor, pair_thr: torch.Tensor, mode: int, temperature: float,
+                        normalize: bool, want_desc: bool = True, want_bits: bool = False):
+    """orientation: dense map (B,1,H,W) -- the reference's argument -- or per-keypoint angles (B,K)."""
+    img = _images(image, "image")
+    n, _, h, w = img.shape
+    if keypoints.dim() != 3 or keypoints.shape[0] != n or keypoints.shape[2] != 2:
+        raise RuntimeError(f"keypoints must have shape ({n}, K, 2), got {tuple(keypoints.shape)}")
+    kp = keypoints.float().contiguous()
+    k = kp.shape[1]
+    ang = orientation.float().contiguous()
+    if ang.dim() == 4 and tuple(ang.shape) == (n, 1, h, w):
+        amap, akp = N.dev(ang, F32, "orientation"), None
+    elif ang.dim() == 2 and tuple(ang.shape) == (n, k):
+        amap, akp = None, N.dev(ang, F32, "orientation")
+    else:
+        raise RuntimeError(f"orientation must be ({n}, 1, {h}, {w}) or ({n}, {k}), got {tuple(ang.shape)}")
+    p = pair_geom.numel()
+    desc = torch.empty((n, k, p), dtype=F32, device=img.device) if want_desc else None
+    bits = torch.empty((n, k, p // 32), dtype=torch.int32, device=img.device) if want_bits else None
+    N.call("mi_sparse_bad_oriented", N.dev(img, F32, "image"), n, h, w, N.dev(kp, F32, "keypoints"), k, amap, akp,
+           N.dev(pair_geom, torch.int32, "pair_geom"), N.dev(pair_thr, F32, "pair_thr"), p, int(mode),
+           float(temperature), int(bool(normalize)), desc.data_ptr() if want_desc else None,
+           bits.data_ptr() if want_bits else None, N.stream_ptr())
+    return desc, bits
+
+
 def _pitch(m: int) -> int:
     return (m + 3) // 4 * 4
 
@@ -189,6 +237,15 @@ def sinkhorn_bits(bits1: torch.Tensor, bits2: torch.Tensor, normalized: bool, ep
            float(epsilon), float(unused_score), int(iterations), u.data_ptr(), v.data_ptr(), p.data_ptr(),
            work.data_ptr(), wbytes, N.stream_ptr())
     return (p, u, v) if return_duals else p
+
+
+def match_filters(p: torch.Tensor, ratio_threshold: float, dustbin_margin: float):
+    """In-place outlier filters on P (B,N+1,M+1) -> (P, valid (B,N) bool)."""
+    b, n1, m1 = p.shape
+    valid = torch.empty((b, n1 - 1), dtype=torch.uint8, device=p.device)
+    N.call("mi_match_filters", N.dev(p, F32, "P"), b, n1 - 1, m1 - 1, float(ratio_threshold), float(dustbin_margin),
+           valid.data_ptr(), N.stream_ptr())
+    return p, valid.bool()
 
 
 def mnn_extract(p: torch.Tensor, kpts1: torch.Tensor, kpts2: torch.Tensor, max_matches: int, threshold: float,

@@ -68,8 +68,6 @@ class SparseBAD(nn.Module):
         return N.MI_BAD_SOFT if self.soft_binarize else N.MI_BAD_HARD
 
     def _check(self, image: torch.Tensor, orientation):
-        if orientation is not None:
-            raise NotImplementedError("oriented SparseBAD (bad.py:487-517) is not built yet in this round")
         if self.sampling_mode != "nearest":
             raise NotImplementedError("sampling_mode='bilinear' is not built yet in this round")
         if self.pair_geom.device != image.device:
@@ -87,18 +85,30 @@ class SparseBAD(nn.Module):
 
     @torch.no_grad()
     def forward(self, image: torch.Tensor, keypoints: torch.Tensor, orientation: torch.Tensor | None = None):
+        """orientation: None (non-oriented), the reference's dense angle map (B,1,H,W) in radians, or --
+        an extension -- the angles at the keypoints themselves (B,K)."""
         self._check(image, orientation)
+        if orientation is not None:                      # oriented branch, bad.py:487-517
+            desc, _ = ops.sparse_bad_oriented(image, keypoints, orientation, self.pair_geom, self.pair_thr, self.mode,
+                                              self.temperature, self.normalize_descriptors)
+            return desc
         desc, _ = ops.sparse_bad(image, keypoints, self.pair_geom, self.pair_thr, self.mode, self.temperature,
                                  self.normalize_descriptors, want_desc=True, want_bits=False, plan=self._get_plan())
         return desc
 
     @torch.no_grad()
-    def forward_bits(self, image: torch.Tensor, keypoints: torch.Tensor) -> torch.Tensor:
+    def forward_bits(self, image: torch.Tensor, keypoints: torch.Tensor,
+                     orientation: torch.Tensor | None = None) -> torch.Tensor:
         """Hard-binarised descriptors as packed bits (B,K,num_pairs/32) int32 -- the form the
         bit-exact cost kernel consumes.  Only meaningful for binarize=True, soft_binarize=False."""
         if self.mode != N.MI_BAD_HARD:
             raise RuntimeError("forward_bits needs binarize=True, soft_binarize=False")
-        self._check(image, None)
+        self._check(image, orientation)
+        if orientation is not None:
+            _, bits = ops.sparse_bad_oriented(image, keypoints, orientation, self.pair_geom, self.pair_thr,
+                                              N.MI_BAD_HARD, self.temperature, self.normalize_descriptors,
+                                              want_desc=False, want_bits=True)
+            return bits
         _, bits = ops.sparse_bad(image, keypoints, self.pair_geom, self.pair_thr, N.MI_BAD_HARD, self.temperature,
                                  self.normalize_descriptors, want_desc=False, want_bits=True, plan=self._get_plan())
         return bits

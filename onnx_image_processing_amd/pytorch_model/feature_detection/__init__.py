@@ -1,4 +1,9 @@
 from .match_extraction_wrapper import MatchExtractionWrapper
+from .shi_tomasi_angle import ShiTomasiAngleSparseBAD, ShiTomasiAngleSparseBADDetector, ShiTomasiWithAngle
+from .shi_tomasi_angle_sparse_bad_sinkhorn import (ShiTomasiAngleSparseBADSinkhornMatcher,
+                                                   ShiTomasiAngleSparseBADSinkhornMatcherWithFilters)
 from .shi_tomasi_sparse_bad_sinkhorn import ShiTomasiSparseBADSinkhornMatcher
 
-__all__ = ["ShiTomasiSparseBADSinkhornMatcher", "MatchExtractionWrapper"]
+__all__ = ["ShiTomasiSparseBADSinkhornMatcher", "MatchExtractionWrapper", "ShiTomasiWithAngle",
+           "ShiTomasiAngleSparseBAD", "ShiTomasiAngleSparseBADDetector", "ShiTomasiAngleSparseBADSinkhornMatcher",
+           "ShiTomasiAngleSparseBADSinkhornMatcherWithFilters"]

@@ -1,3 +1,3 @@
-from .sinkhorn import SinkhornMatcher, SinkhornMatcherWithScores
+from .sinkhorn import SinkhornMatcher, SinkhornMatcherWithFilters, SinkhornMatcherWithScores
 
-__all__ = ["SinkhornMatcher", "SinkhornMatcherWithScores"]
+__all__ = ["SinkhornMatcher", "SinkhornMatcherWithScores", "SinkhornMatcherWithFilters"]

@@ -64,3 +64,26 @@ class SinkhornMatcherWithScores(SinkhornMatcher):
         p = super().forward(desc1, desc2)
         core = p[:, : desc1.shape[1], : desc2.shape[1]]
         return p, core.amax(dim=-1), core.amax(dim=-2)
+
+
+class SinkhornMatcherWithFilters(SinkhornMatcher):
+    """forward -> (P_filtered (B,N+1,M+1), valid_mask (B,N) bool): Sinkhorn followed by the
+    probability-ratio filter (best / (second + 1e-8) >= ratio_threshold) and the dustbin-margin
+    filter (best - P[i, M] >= dustbin_margin); rows that fail are reassigned to the dustbin
+    (sinkhorn.py:303-315 arguments, :391-465 forward).  None disables a filter, as in the
+    reference.  K7 `mi_match_filters` works in place on the freshly computed P."""
+
+    def __init__(self, iterations: int = 20, epsilon: float = 1.0, unused_score: float = 1.0,
+                 distance_type: str = "l2", ratio_threshold: float = None, dustbin_margin: float = None) -> None:
+        super().__init__(iterations, epsilon, unused_score, distance_type)
+        self.ratio_threshold = ratio_threshold if ratio_threshold is not None else -1.0
+        self.dustbin_margin = dustbin_margin if dustbin_margin is not None else -1.0
+
+    @torch.no_grad()
+    def forward(self, desc1: torch.Tensor, desc2: torch.Tensor):
+        return ops.match_filters(super().forward(desc1, desc2), self.ratio_threshold, self.dustbin_margin)
+
+    @torch.no_grad()
+    def forward_bits(self, bits1: torch.Tensor, bits2: torch.Tensor, normalized: bool):
+        return ops.match_filters(super().forward_bits(bits1, bits2, normalized), self.ratio_threshold,
+                                 self.dustbin_margin)

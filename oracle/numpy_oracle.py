@@ -358,3 +358,164 @@ def match_pair(
         aux["desc1"], aux["desc2"] = out[0][1], out[1][1]
         return out[0][0], out[1][0], p, aux
     return out[0][0], out[1][0], p
+
+
+# --------------------------------------------------------------------------
+# outlier filters: reference pytorch_model/matching/sinkhorn.py:317-465
+# --------------------------------------------------------------------------
+def match_filters(p, ratio_threshold=None, dustbin_margin=None):
+    """SinkhornMatcherWithFilters' filter stage on P (B,N+1,M+1) -> (P_filtered, valid (B,N) bool).
+    :337-351 top-2 ratio (with multiplicity; second = 0 when M == 1), :370-387 best - dustbin,
+    :441-463 failing rows: core * 0, dustbin entry 1."""
+    p = np.asarray(p, F32).copy()
+    bsz, n, m = p.shape[0], p.shape[1] - 1, p.shape[2] - 1
+    rt = -1.0 if ratio_threshold is None else ratio_threshold
+    dm = -1.0 if dustbin_margin is None else dustbin_margin
+    core = p[:, :n, :m]
+    srt = np.sort(core, axis=2)
+    best = srt[:, :, -1]
+    second = srt[:, :, -2] if m >= 2 else np.zeros_like(best)
+    valid = np.ones((bsz, n), bool)
+    if rt > 0:
+        valid &= (best / (second + F32(1e-8))) >= F32(rt)
+    if dm >= 0:
+        valid &= (best - p[:, :n, m]) >= F32(dm)
+    vf = valid.astype(F32)[:, :, None]
+    p[:, :n, :m] = core * vf
+    p[:, :n, m:m + 1] = (F32(1) - vf) + vf * p[:, :n, m:m + 1]
+    return p, valid
+
+
+# --------------------------------------------------------------------------
+# orientation: reference pytorch_model/orientation/angle_estimation.py:86-172
+# --------------------------------------------------------------------------
+def moment_kernels(patch_size=15, sigma=2.5):
+    """angle_estimation.py:97-112: (2, ps, ps) fp32 weights x*G, y*G, G = exp(-(x^2+y^2)/(2 sigma^2))."""
+    if patch_size % 2 == 0:
+        raise ValueError(f"patch_size must be odd, got {patch_size}")
+    if sigma <= 0:
+        raise ValueError(f"sigma must be positive, got {sigma}")
+    c = np.arange(-(patch_size // 2), patch_size // 2 + 1, dtype=F32)
+    y, x = np.meshgrid(c, c, indexing="ij")
+    g = np.exp(-(x ** 2 + y ** 2) / F32(2 * sigma ** 2)).astype(F32)
+    return np.stack([x * g, y * g]).astype(F32)
+
+
+def angle_map(image, patch_size=15, sigma=2.5, return_moments=False):
+    """angle_estimation.py:155-170: zero-padded correlation with the two moment kernels, atan2(m01, m10).
+    Accumulated in float64 (the reference's fp32 conv order is oneDNN's: tolerance parity)."""
+    img = np.asarray(image, F32)[:, 0].astype(np.float64)
+    wk = moment_kernels(patch_size, sigma).astype(np.float64)
+    n, h, w = img.shape
+    half = patch_size // 2
+    e = np.pad(img, ((0, 0), (half, half), (half, half)))
+    m10 = np.zeros_like(img)
+    m01 = np.zeros_like(img)
+    for dy in range(patch_size):
+        for dx in range(patch_size):
+            win = e[:, dy:dy + h, dx:dx + w]
+            m10 += wk[0, dy, dx] * win
+            m01 += wk[1, dy, dx] * win
+    ang = np.arctan2(m01, m10).astype(F32)[:, None]
+    if return_moments:
+        return ang, m10, m01
+    return ang
+
+
+def sample_nearest(field, keypoints):
+    """descriptor/bad.py:490-500: grid_sample(nearest, border, align_corners) of a (B,1,H,W) map at the
+    clamped keypoints -> (B,K)."""
+    f = np.asarray(field, F32)
+    _, _, h, w = f.shape
+    kp = np.asarray(keypoints, F32)
+    cy = _nearest_centre(np.clip(kp[:, :, 0], F32(0), F32(h - 1)), h)
+    cx = _nearest_centre(np.clip(kp[:, :, 1], F32(0), F32(w - 1)), w)
+    return np.stack([f[b, 0, cy[b], cx[b]] for b in range(f.shape[0])])
+
+
+def sparse_bad_oriented(image, keypoints, theta, box_params, thresholds, binarize=False, soft_binarize=True,
+                        temperature=10.0, normalize_descriptors=True, return_aux=False):
+    """Oriented SparseBAD.forward (bad.py:487-574); theta (B,K) = orientation sampled at the keypoints.
+    rot_dy = ox*sin + oy*cos, rot_dx = ox*cos - oy*sin in fp32 (bad.py:505-509), then as sparse_bad."""
+    img = np.asarray(image, F32)
+    bsz, _, h, w = img.shape
+    kp = np.asarray(keypoints, F32)
+    th = np.asarray(theta, F32)
+    box = np.asarray(box_params).astype(np.int64)
+    thr = np.asarray(thresholds, F32).astype(np.float64)
+    rmax = int(box[:, 4].max())
+    pad = rmax
+    valid = kp[:, :, 0] >= 0
+    ky = np.clip(kp[:, :, 0], F32(0), F32(h - 1))
+    kx = np.clip(kp[:, :, 1], F32(0), F32(w - 1))
+    ox1, ox2, oy1, oy2 = [(box[:, i] - 16).astype(F32) for i in range(4)]
+    rad = box[:, 4]
+    area = ((2 * rad + 1) ** 2).astype(np.float64)
+    cos_t = np.cos(th).astype(F32)[:, :, None]
+    sin_t = np.sin(th).astype(F32)[:, :, None]
+    centered = np.empty((bsz, kp.shape[1], box.shape[0]), np.float64)
+    for b in range(bsz):
+        e = np.pad(img[b, 0].astype(np.float64), pad, mode="edge")
+        sat = np.zeros((e.shape[0] + 1, e.shape[1] + 1), np.float64)
+        sat[1:, 1:] = e.cumsum(0).cumsum(1)
+
+        def mean_box(cy, cx):
+            y0 = cy - rad[None, :] + pad
+            y1 = cy + rad[None, :] + pad + 1
+            x0 = cx - rad[None, :] + pad
+            x1 = cx + rad[None, :] + pad + 1
+            return (sat[y1, x1] - sat[y0, x1] - sat[y1, x0] + sat[y0, x0]) / area[None, :]
+
+        def centre(oxv, oyv):
+            dy = (oxv[None, :] * sin_t[b] + oyv[None, :] * cos_t[b]).astype(F32)
+            dx = (oxv[None, :] * cos_t[b] - oyv[None, :] * sin_t[b]).astype(F32)
+            return _nearest_centre(ky[b][:, None] + dy, h), _nearest_centre(kx[b][:, None] + dx, w)
+
+        c1y, c1x = centre(ox1, oy1)
+        c2y, c2x = centre(ox2, oy2)
+        centered[b] = mean_box(c1y, c1x) - mean_box(c2y, c2x) - thr[None, :]
+    bits = centered <= 0
+    if not binarize:
+        desc = centered.astype(F32)
+    elif soft_binarize:
+        z = (-(centered.astype(F32)) * F32(temperature)).astype(F32)
+        with np.errstate(over="ignore"):
+            desc = (F32(1) / (F32(1) + np.exp(-z))).astype(F32)
+    else:
+        desc = bits.astype(F32)
+    desc = desc * valid[:, :, None].astype(F32)
+    if normalize_descriptors:
+        nrm = np.sqrt((desc * desc).sum(-1, dtype=F32, keepdims=True)).astype(F32)
+        desc = (desc / np.maximum(nrm, F32(1e-12))).astype(F32)
+    if return_aux:
+        return desc, {"centered": centered, "bits": bits & valid[:, :, None], "valid": valid}
+    return desc
+
+
+def match_pair_angle(image1, image2, box_params, thresholds, max_keypoints, block_size=5, patch_size=15, sigma=2.5,
+                     binarize=False, soft_binarize=True, temperature=10.0, sinkhorn_iterations=20, epsilon=1.0,
+                     unused_score=1.0, distance_type="l2", ratio_threshold=None, dustbin_margin=None, nms_radius=3,
+                     score_threshold=0.0, normalize_descriptors=True, border_margin=None, with_filters=False,
+                     return_aux=False):
+    """ShiTomasiAngleSparseBADSinkhornMatcher[WithFilters].forward
+    (feature_detection/shi_tomasi_angle_sparse_bad_sinkhorn.py:148-180, :312-340)."""
+    if border_margin is None:
+        border_margin = int(np.asarray(box_params)[:, 4].max())
+    out, aux = [], {}
+    for tag, im in (("1", image1), ("2", image2)):
+        s = shi_tomasi_score(im, block_size)[:, 0]
+        kp, ksc, _ = select_topk_keypoints(s, nms_mask(s, nms_radius), max_keypoints, score_threshold, border_margin)
+        theta = sample_nearest(angle_map(im, patch_size, sigma), kp)
+        d, a = sparse_bad_oriented(im, kp, theta, box_params, thresholds, binarize, soft_binarize, temperature,
+                                   normalize_descriptors, return_aux=True)
+        out.append((kp, d))
+        aux["theta" + tag], aux["kscores" + tag], aux["bad" + tag] = theta, ksc, a
+    p = sinkhorn_match(out[0][1], out[1][1], sinkhorn_iterations, epsilon, unused_score, distance_type)
+    res = (out[0][0], out[1][0], p)
+    if with_filters:
+        p, valid = match_filters(p, ratio_threshold, dustbin_margin)
+        res = (out[0][0], out[1][0], p, valid)
+    if return_aux:
+        aux["desc1"], aux["desc2"] = out[0][1], out[1][1]
+        return res + (aux,)
+    return res

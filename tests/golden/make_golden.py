@@ -182,5 +182,80 @@ def main():
     save("sinkhorn_unit", **sk)
 
 
+def filters():
+    """SinkhornMatcherWithFilters unit vectors (reference matching/sinkhorn.py:262-465)."""
+    from pytorch_model.matching.sinkhorn import SinkhornMatcherWithFilters
+    g = torch.Generator().manual_seed(31)
+    base = torch.nn.functional.normalize(torch.randn(2, 48, 32, generator=g), dim=-1)
+    d1 = base.clone()
+    d2 = torch.nn.functional.normalize(base[:, torch.randperm(48, generator=g)][:, :40]
+                                       + 0.25 * torch.randn(2, 40, 32, generator=g), dim=-1)
+    out = dict(d1=d1.numpy(), d2=d2.numpy())
+    cfgs = [dict(iterations=20, epsilon=0.1, ratio_threshold=2.0, dustbin_margin=0.3),
+            dict(iterations=20, epsilon=0.1, ratio_threshold=5.0),
+            dict(iterations=20, epsilon=0.1, dustbin_margin=0.05),
+            dict(iterations=10, epsilon=0.3, unused_score=0.5),
+            dict(iterations=20, epsilon=0.1, ratio_threshold=0.0, dustbin_margin=0.0)]
+    with torch.no_grad():
+        for i, kw in enumerate(cfgs):
+            pf, valid = SinkhornMatcherWithFilters(**kw).eval()(d1, d2)
+            out[f"f{i}_cfg"] = np.array(repr(kw))
+            out[f"f{i}_P"] = pf.numpy()
+            out[f"f{i}_valid"] = valid.numpy()
+    save("filters_unit", **out)
+
+
+def angle():
+    """AngleEstimator + the rotation-aware matchers (orientation/angle_estimation.py,
+    feature_detection/shi_tomasi_angle*.py), incl. the reference's own smoke configuration
+    (test_filters_pytorch.py:9-57: K=128, 10 iterations, 256 pairs, ratio 2.0, margin 0.3, 240x320)."""
+    from pytorch_model.orientation.angle_estimation import AngleEstimator
+    from pytorch_model.feature_detection.shi_tomasi_angle import ShiTomasiAngleSparseBADDetector
+    from pytorch_model.feature_detection.shi_tomasi_angle_sparse_bad_sinkhorn import (
+        ShiTomasiAngleSparseBADSinkhornMatcher, ShiTomasiAngleSparseBADSinkhornMatcherWithFilters)
+    a, b = synth_batch(3100, 1, 120, 160)
+    # rotate the second image by 90 degrees about its centre crop so orientation matters
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    out = dict(seed=3100, h=120, w=160)
+    with torch.no_grad():
+        out["angle_map"] = AngleEstimator(15, 2.5).eval()(ta).numpy()
+        out["angle_map_p9"] = AngleEstimator(9, 1.5).eval()(ta).numpy()
+        cfgs = {"hard": dict(max_keypoints=64, num_pairs=512, binarize=True, soft_binarize=False, epsilon=0.05,
+                             nms_radius=3, block_size=5),
+                "soft": dict(max_keypoints=48, num_pairs=256, nms_radius=3, block_size=3, epsilon=1.0)}
+        for name, cfg in cfgs.items():
+            m = ShiTomasiAngleSparseBADSinkhornMatcher(**cfg).eval()
+            k1, k2, p = m(ta, tb)
+            out[name + "_cfg"] = np.array(repr(cfg))
+            out[name + "_k1"], out[name + "_k2"], out[name + "_P"] = k1.numpy(), k2.numpy(), p.numpy()
+            for tag, im, kp in (("1", ta, k1), ("2", tb, k2)):
+                sc, ang = m.detector(im)
+                _, ksc = select_topk_keypoints(sc.squeeze(1), apply_nms_maxpool(sc.squeeze(1), m.nms_radius),
+                                               cfg["max_keypoints"], m.score_threshold, m.border_margin)
+                out[f"{name}_kscores{tag}"] = ksc.numpy()
+                out[f"{name}_desc{tag}"] = m.descriptor(im, kp, ang).numpy()
+        det = ShiTomasiAngleSparseBADDetector(max_keypoints=40, num_pairs=256, binarize=True, soft_binarize=False).eval()
+        dk, ds, dd = det(ta)
+        out["det_k"], out["det_s"], out["det_d"] = dk.numpy(), ds.numpy(), dd.numpy()
+        # the reference's smoke configuration on uint8-valued synthetic input (its own test uses randn)
+        a2, b2 = synth_batch(3101, 1, 240, 320)
+        fcfg = dict(max_keypoints=128, ratio_threshold=2.0, dustbin_margin=0.3, sinkhorn_iterations=10, num_pairs=256)
+        fm = ShiTomasiAngleSparseBADSinkhornMatcherWithFilters(**fcfg).eval()
+        f1, f2, fp, fv = fm(torch.from_numpy(a2), torch.from_numpy(b2))
+        out.update(filt_cfg=np.array(repr(fcfg)), filt_seed=3101, filt_k1=f1.numpy(), filt_k2=f2.numpy(),
+                   filt_P=fp.numpy(), filt_valid=fv.numpy())
+        nf = ShiTomasiAngleSparseBADSinkhornMatcherWithFilters(
+            max_keypoints=128, ratio_threshold=None, dustbin_margin=None, sinkhorn_iterations=10, num_pairs=256).eval()
+        out["nofilt_all_valid"] = bool(nf(torch.from_numpy(a2), torch.from_numpy(b2))[3].all())
+    save("angle_pipeline", **out)
+
+
 if __name__ == "__main__":
-    main()
+    if "--filters-only" in sys.argv:
+        filters()
+    elif "--angle-only" in sys.argv:
+        angle()
+    else:
+        main()
+        filters()
+        angle()

@@ -229,6 +229,34 @@ def test_sinkhorn_with_scores(mods):
 
 
 # ------------------------------------------------------------------ K7
+def test_filters_golden_and_known_answers(mods):
+    from onnx_image_processing_amd.pytorch_model.matching import SinkhornMatcherWithFilters
+    from onnx_image_processing_amd import ops
+    from test_oracle_golden import KNOWN_RATIO, _augment
+    for core, thr, expect in KNOWN_RATIO:                      # reference test_vectorized_filter.py vectors
+        _, valid = ops.match_filters(gpu(_augment(core)), thr, -1.0)
+        assert valid[0].cpu().tolist() == expect
+    g = load_golden("filters_unit")
+    for i in range(5):
+        kw = cfg_of(g, f"f{i}_cfg")
+        pf, valid = SinkhornMatcherWithFilters(**kw)(gpu(g["d1"]), gpu(g["d2"]))
+        assert valid.dtype == torch.bool and np.array_equal(valid.cpu().numpy(), g[f"f{i}_valid"])
+        ok, worst = p_close(pf.cpu().numpy(), g[f"f{i}_P"], atol=3e-5)
+        assert ok, (i, worst)
+    # random P with exact duplicates (top-2 multiplicity) and M == 1
+    rng = np.random.default_rng(9)
+    p = rng.random((3, 70, 131)).astype(np.float32)
+    p[0, 5, 7] = p[0, 5, 90] = 2.0                               # best appears twice -> ratio 1
+    for rt, dm in ((1.5, None), (None, 0.2), (1.2, 0.0)):
+        ref_p, ref_v = O.match_filters(p, rt, dm)
+        got_p, got_v = ops.match_filters(gpu(p.copy()), -1.0 if rt is None else rt, -1.0 if dm is None else dm)
+        assert np.array_equal(got_v.cpu().numpy(), ref_v) and np.array_equal(got_p.cpu().numpy(), ref_p)
+    p1 = rng.random((1, 9, 2)).astype(np.float32)
+    ref_p, ref_v = O.match_filters(p1, 2.0, None)
+    got_p, got_v = ops.match_filters(gpu(p1.copy()), 2.0, -1.0)
+    assert np.array_equal(got_v.cpu().numpy(), ref_v) and np.array_equal(got_p.cpu().numpy(), ref_p)
+
+
 def test_mnn_vs_oracle(mods):
     rng = np.random.default_rng(5)
     for n, m, mx, thr in ((512, 512, 100, 0.1), (40, 56, 100, 0.01), (300, 77, 64, 0.0)):
@@ -350,3 +378,111 @@ def test_full_size_batch_properties(mods):
 def test_cpu_tensor_is_refused(mods):
     with pytest.raises(RuntimeError):
         mods["ShiTomasiScore"](3)(torch.zeros(1, 1, 16, 16))
+
+
+# ------------------------------------------------------------------ K8 orientation + oriented K4
+def _ang_diff(a, b):
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+    return np.minimum(d, 2 * np.pi - d)
+
+
+def test_angle_map_and_keypoint_angles(mods):
+    from onnx_image_processing_amd.pytorch_model.orientation import AngleEstimator
+    g = load_golden("angle_pipeline")
+    a, _ = synth_batch(int(g["seed"]), 1, int(g["h"]), int(g["w"]))
+    for ps, sg, key in ((15, 2.5, "angle_map"), (9, 1.5, "angle_map_p9")):
+        est = AngleEstimator(ps, sg).to(DEV)
+        got = est(gpu(a)).cpu().numpy()
+        assert _ang_diff(got, O.angle_map(a, ps, sg)).max() < 3e-4          # vs oracle (fp64 accumulation)
+        assert _ang_diff(got, g[key]).max() < 3e-4                           # vs the reference's map
+        rng = np.random.default_rng(ps)
+        kp = np.stack([rng.integers(0, 120, (1, 50)), rng.integers(0, 160, (1, 50))], -1).astype(np.float32)
+        kp[0, 0] = (-1, -1)
+        th = est.at_keypoints(gpu(a), gpu(kp)).cpu().numpy()
+        assert _ang_diff(th, O.sample_nearest(got, kp)).max() < 3e-4         # = the map sampled at the keypoints
+    with pytest.raises(ValueError):
+        AngleEstimator(14)
+    with pytest.raises(ValueError):
+        AngleEstimator(15, -1.0)
+
+
+def test_oriented_bad_vs_oracle(mods):
+    box, thr = bad_tables(512)
+    a, _ = synth_batch(920, 2, 120, 160)
+    rng = np.random.default_rng(6)
+    kp = np.stack([rng.integers(0, 120, (2, 80)), rng.integers(0, 160, (2, 80))], -1).astype(np.float32)
+    kp[0, 3] = (-1, -1)
+    kp[1, :4] = [(0, 0), (119, 159), (3, 150), (110, 2)]
+    theta = (rng.random((2, 80)).astype(np.float32) * 2 - 1) * np.float32(np.pi)
+    theta[0, :8] = [0.0, np.pi / 2, -np.pi / 2, np.pi, 0.3, -2.0, 1e-3, 3.0]
+    amap = np.zeros((2, 1, 120, 160), np.float32)                              # dense-map form of the same angles
+    for bi in range(2):
+        for j in range(80):
+            if kp[bi, j, 0] >= 0:
+                amap[bi, 0, int(kp[bi, j, 0]), int(kp[bi, j, 1])] = theta[bi, j]
+    amap[0, 0, 0, 0] = theta[0, 3]                                             # invalid keypoint samples (0,0)
+    for kw in (dict(binarize=True, soft_binarize=False), dict(binarize=False, normalize_descriptors=False),
+               dict(binarize=True, soft_binarize=True)):
+        mod = mods["SparseBAD"](512, **kw).to(DEV)
+        for ori in (theta, amap):
+            # dense-map form: the angle is whatever the map holds at the (clamped) keypoint pixel
+            th = theta if ori is theta else O.sample_nearest(amap, kp)
+            ref, aux = O.sparse_bad_oriented(a, kp, th, box, thr, return_aux=True, **kw)
+            got = mod(gpu(a), gpu(kp), gpu(ori)).cpu().numpy()
+            if kw.get("binarize") and not kw.get("soft_binarize", True):
+                # cosf/sinf on the GPU vs numpy can move a centre that sits within rounding of x.5
+                agree = ((got != 0) == aux["bits"]).mean()
+                assert agree >= 0.9995, agree
+            else:
+                bad = np.abs(got - ref) > (3e-5 if kw.get("normalize_descriptors", True) else 2e-4)
+                assert bad.mean() < 5e-4
+    mod = mods["SparseBAD"](512, binarize=True, soft_binarize=False).to(DEV)
+    bits = mod.forward_bits(gpu(a), gpu(kp), gpu(theta)).cpu().numpy().view(np.uint32)
+    d = mod(gpu(a), gpu(kp), gpu(theta)).cpu().numpy()
+    assert np.array_equal(unpack_bits(bits, 512), d != 0)
+
+
+@pytest.mark.parametrize("name", ["hard", "soft"])
+def test_angle_pipeline_vs_oracle_and_golden(mods, name):
+    from onnx_image_processing_amd.pytorch_model.feature_detection import ShiTomasiAngleSparseBADSinkhornMatcher
+    g = load_golden("angle_pipeline")
+    a, b = synth_batch(int(g["seed"]), 1, int(g["h"]), int(g["w"]))
+    cfg = cfg_of(g, name + "_cfg")
+    model = ShiTomasiAngleSparseBADSinkhornMatcher(**cfg).to(DEV)
+    k1, k2, p = [t.cpu().numpy() for t in model(gpu(a), gpu(b))]
+    box, thr = bad_tables(cfg["num_pairs"])
+    kw = {k: v for k, v in cfg.items() if k not in ("num_pairs", "max_keypoints")}
+    o1, o2, op = O.match_pair_angle(a, b, box, thr, cfg["max_keypoints"], **kw)
+    # block 5 scores are tolerance-only (sums above 2^24): the keypoint SETS must agree, order may not
+    if cfg["block_size"] == 3:
+        assert np.array_equal(k1, o1) and np.array_equal(k2, o2)
+    assert {tuple(x) for x in k1[0]} == {tuple(x) for x in o1[0]} == {tuple(x) for x in g[name + "_k1"][0]}
+    assert {tuple(x) for x in k2[0]} == {tuple(x) for x in o2[0]} == {tuple(x) for x in g[name + "_k2"][0]}
+    if np.array_equal(k1, o1) and np.array_equal(k2, o2):
+        ok, worst = p_close(p, op, atol=2e-4)
+        assert ok, worst
+
+
+def test_filters_model_reference_smoke_config(mods):
+    """reference test_filters_pytorch.py:9-57 (shapes/dtypes, filters on and off), plus values vs oracle."""
+    from onnx_image_processing_amd.pytorch_model.feature_detection import (
+        ShiTomasiAngleSparseBADDetector, ShiTomasiAngleSparseBADSinkhornMatcherWithFilters)
+    g = load_golden("angle_pipeline")
+    a, b = synth_batch(int(g["filt_seed"]), 1, 240, 320)
+    cfg = cfg_of(g, "filt_cfg")
+    model = ShiTomasiAngleSparseBADSinkhornMatcherWithFilters(**cfg).to(DEV)
+    k1, k2, p, valid = model(gpu(a), gpu(b))
+    assert k1.shape == (1, 128, 2) and p.shape == (1, 129, 129) and valid.shape == (1, 128) and valid.dtype == torch.bool
+    assert {tuple(x) for x in k1[0].cpu().numpy()} == {tuple(x) for x in g["filt_k1"][0]}
+    off = ShiTomasiAngleSparseBADSinkhornMatcherWithFilters(max_keypoints=128, ratio_threshold=None, dustbin_margin=None,
+                                                            sinkhorn_iterations=10, num_pairs=256).to(DEV)
+    assert bool(off(gpu(a), gpu(b))[3].all())
+    if np.array_equal(k1.cpu().numpy(), g["filt_k1"]) and np.array_equal(k2.cpu().numpy(), g["filt_k2"]):
+        assert (valid.cpu().numpy() == g["filt_valid"]).mean() >= 0.99
+    det = ShiTomasiAngleSparseBADDetector(max_keypoints=40, num_pairs=256, binarize=True, soft_binarize=False).to(DEV)
+    a0, _ = synth_batch(int(g["seed"]), 1, int(g["h"]), int(g["w"]))
+    dk, ds, dd = det(gpu(a0))
+    assert {tuple(x) for x in dk[0].cpu().numpy()} == {tuple(x) for x in g["det_k"][0]}
+    order = {tuple(x): i for i, x in enumerate(g["det_k"][0])}
+    idx = [order[tuple(x)] for x in dk[0].cpu().numpy()]
+    assert ((dd[0].cpu().numpy() != 0) == (g["det_d"][0][idx] != 0)).mean() >= 0.999

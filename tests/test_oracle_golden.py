@@ -164,3 +164,93 @@ def test_sinkhorn_validation():
         O.sinkhorn_match(d, d, epsilon=0.0)
     with pytest.raises(ValueError):
         O.sinkhorn_match(d, d, distance_type="cosine")
+
+
+# ---------------------------------------------------------------- outlier filters
+KNOWN_RATIO = [  # the reference's own known-answer vectors (test_vectorized_filter.py:9-22,24-32,57-69)
+    (np.array([[0.8, 0.1, 0.1], [0.05, 0.9, 0.05], [0.4, 0.35, 0.25]]), 2.0, [True, True, False]),
+    (np.array([[1.0]]), 2.0, [True]),
+    (np.array([[0.8, 0.1, 0.1], [0.6, 0.4, 0.0]]), 3.0, [True, False]),
+]
+
+
+def _augment(core):
+    """(N,M) core probabilities -> (1,N+1,M+1) with zero dustbin row/column."""
+    n, m = core.shape
+    p = np.zeros((1, n + 1, m + 1), np.float32)
+    p[0, :n, :m] = core
+    return p
+
+
+def test_ratio_filter_known_answers():
+    for core, thr, expect in KNOWN_RATIO:
+        _, valid = O.match_filters(_augment(core), ratio_threshold=thr, dustbin_margin=None)
+        assert valid[0].tolist() == expect
+
+
+def test_filters_unit_vectors():
+    g = load_golden("filters_unit")
+    for i in range(5):
+        kw = cfg_of(g, f"f{i}_cfg")
+        sk = {k: v for k, v in kw.items() if k in ("iterations", "epsilon", "unused_score")}
+        pf, valid = O.match_filters(O.sinkhorn_match(g["d1"], g["d2"], **sk), kw.get("ratio_threshold"),
+                                    kw.get("dustbin_margin"))
+        assert np.array_equal(valid, g[f"f{i}_valid"])
+        ok, worst = p_close(pf, g[f"f{i}_P"], atol=3e-5)
+        assert ok, (i, worst)
+
+
+# ---------------------------------------------------------------- orientation + rotation-aware matchers
+def _ang_diff(a, b):
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+    return np.minimum(d, 2 * np.pi - d)
+
+
+def test_angle_map_vs_reference():
+    g = load_golden("angle_pipeline")
+    a, _ = synth_batch(int(g["seed"]), 1, int(g["h"]), int(g["w"]))
+    # the reference sums 225 fp32 products in oneDNN's order; the oracle accumulates in fp64
+    assert _ang_diff(O.angle_map(a, 15, 2.5), g["angle_map"]).max() < 3e-4
+    assert _ang_diff(O.angle_map(a, 9, 1.5), g["angle_map_p9"]).max() < 3e-4
+    with pytest.raises(ValueError):
+        O.moment_kernels(14, 2.5)
+    with pytest.raises(ValueError):
+        O.moment_kernels(15, 0.0)
+
+
+@pytest.mark.parametrize("name", ["hard", "soft"])
+def test_angle_pipeline_vs_reference(name):
+    g = load_golden("angle_pipeline")
+    a, b = synth_batch(int(g["seed"]), 1, int(g["h"]), int(g["w"]))
+    cfg = cfg_of(g, name + "_cfg")
+    box, thr = bad_tables(cfg["num_pairs"])
+    kw = {k: v for k, v in cfg.items() if k not in ("num_pairs", "max_keypoints")}
+    k1, k2, p, aux = O.match_pair_angle(a, b, box, thr, cfg["max_keypoints"], return_aux=True, **kw)
+    perms = [tie_canonical_perm(g[f"{name}_k{t}"][0], g[f"{name}_kscores{t}"][0], int(g["w"])) for t in "12"]
+    assert np.array_equal(k1[0], g[name + "_k1"][0][perms[0]]) and np.array_equal(k2[0], g[name + "_k2"][0][perms[1]])
+    for t, pm in zip("12", perms):
+        dref, dmine = g[f"{name}_desc{t}"][0][pm], aux["desc" + t][0]
+        if name == "hard":
+            assert ((dref != 0) == (dmine != 0)).mean() >= 0.9999      # SURVEY.md §8c.4
+        else:
+            np.testing.assert_allclose(dmine, dref, rtol=0, atol=3e-5)
+    ok, worst = p_close(p[0], permute_p(g[name + "_P"][0], perms[0], perms[1]))
+    assert ok, worst
+
+
+def test_reference_smoke_configuration_with_filters():
+    """The reference's only model-level test (test_filters_pytorch.py) asserts nothing numeric; here its
+    configuration is pinned on synthetic uint8 input: keypoints, valid mask and P."""
+    g = load_golden("angle_pipeline")
+    a, b = synth_batch(int(g["filt_seed"]), 1, 240, 320)
+    cfg = cfg_of(g, "filt_cfg")
+    box, thr = bad_tables(cfg["num_pairs"])
+    kw = {k: v for k, v in cfg.items() if k not in ("num_pairs", "max_keypoints")}
+    k1, k2, p, valid = O.match_pair_angle(a, b, box, thr, cfg["max_keypoints"], with_filters=True, **kw)
+    assert {tuple(x) for x in k1[0]} == {tuple(x) for x in g["filt_k1"][0]}
+    assert {tuple(x) for x in k2[0]} == {tuple(x) for x in g["filt_k2"][0]}
+    assert bool(g["nofilt_all_valid"])
+    if np.array_equal(k1, g["filt_k1"]) and np.array_equal(k2, g["filt_k2"]):   # no tie reordering on this input
+        assert (valid == g["filt_valid"]).mean() >= 0.99
+        ok, worst = p_close(p, g["filt_P"], atol=2e-4)
+        assert ok or (valid != g["filt_valid"]).any(), worst
