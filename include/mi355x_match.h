@@ -103,6 +103,17 @@ int mi_sparse_bad(const float *image, int n, int h, int w, const float *keypoint
                   float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
                   uint8_t *status, mi_stream_t stream);
 
+/* ---- descriptor/bad.py:62-110,189-218  BADDescriptor.forward (dense, non-oriented) ------------
+ * out (n, num_pairs, h, w): the BAD response at every pixel, raw / sigmoid(-c*T) / (c <= 0),
+ * box centres clamped into the image, boxes over the replicate-padded image; exact fp64 box sums
+ * (the reference's fp32 integral image is itself inexact above 2^24).
+ * mi_gather_descriptors: descriptor/bad.py:221-333, (batch,d,h,w) map sampled at keypoints
+ * (batch,nk,2) -> (batch,nk,d); bilinear = 0: integer truncation, 1: grid_sample bilinear/border. */
+int mi_bad_dense(const float *image, int n, int h, int w, const uint32_t *pair_geom, const float *pair_thr,
+                 int num_pairs, int mode, float temperature, float *out, mi_stream_t stream);
+int mi_gather_descriptors(const float *descriptor_map, int batch, int d, int h, int w, const float *keypoints,
+                          int nk, int bilinear, float *out, mi_stream_t stream);
+
 /* ---- orientation/angle_estimation.py:86-172  AngleEstimator.forward --------------------------
  * angle = atan2(m01, m10) of the Gaussian-weighted first moments, conv with ZERO padding.
  * moment_kernels: the module's (2,1,ps,ps) weight buffer (x*G then y*G), patch_size odd <= 31.

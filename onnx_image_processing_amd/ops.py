@@ -121,6 +121,29 @@ def sparse_bad(image: torch.Tensor, keypoints: torch.Tensor, pair_geom: torch.Te
     return desc, bits
 
 
+def bad_dense(image: torch.Tensor, pair_geom: torch.Tensor, pair_thr: torch.Tensor, mode: int,
+              temperature: float) -> torch.Tensor:
+    img = _images(image, "x")
+    n, _, h, w = img.shape
+    p = pair_geom.numel()
+    out = torch.empty((n, p, h, w), dtype=F32, device=img.device)
+    N.call("mi_bad_dense", N.dev(img, F32, "x"), n, h, w, N.dev(pair_geom, torch.int32, "pair_geom"),
+           N.dev(pair_thr, F32, "pair_thr"), p, int(mode), float(temperature), out.data_ptr(), N.stream_ptr())
+    return out
+
+
+def gather_descriptors(descriptor_map: torch.Tensor, keypoints: torch.Tensor, bilinear: bool) -> torch.Tensor:
+    if descriptor_map.dim() != 4 or keypoints.dim() != 3 or keypoints.shape[0] != descriptor_map.shape[0]:
+        raise RuntimeError(f"expected (B,D,H,W) and (B,N,2), got {tuple(descriptor_map.shape)} {tuple(keypoints.shape)}")
+    dm = descriptor_map.float().contiguous()
+    kp = keypoints.float().contiguous()
+    b, d, h, w = dm.shape
+    out = torch.empty((b, kp.shape[1], d), dtype=F32, device=dm.device)
+    N.call("mi_gather_descriptors", N.dev(dm, F32, "descriptor_map"), b, d, h, w, N.dev(kp, F32, "keypoints"),
+           kp.shape[1], int(bool(bilinear)), out.data_ptr(), N.stream_ptr())
+    return out
+
+
 def angle_map(image: torch.Tensor, moment_kernels: torch.Tensor, patch_size: int) -> torch.Tensor:
     img = _images(image, "image")
     n, _, h, w = img.shape

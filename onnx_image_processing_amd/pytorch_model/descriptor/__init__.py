@@ -1,3 +1,3 @@
-from .bad import SparseBAD
+from .bad import BADDescriptor, SparseBAD
 
-__all__ = ["SparseBAD"]
+__all__ = ["BADDescriptor", "SparseBAD"]

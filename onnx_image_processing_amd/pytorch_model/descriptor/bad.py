@@ -112,3 +112,71 @@ class SparseBAD(nn.Module):
         _, bits = ops.sparse_bad(image, keypoints, self.pair_geom, self.pair_thr, N.MI_BAD_HARD, self.temperature,
                                  self.normalize_descriptors, want_desc=False, want_bits=True, plan=self._get_plan())
         return bits
+
+
+class BADDescriptor(nn.Module):
+    """Dense BAD descriptor map -- mirror of reference descriptor/bad.py:14-218.
+
+    forward(x (B,1,H,W), orientation=None) -> (B, num_pairs, H, W): the centred BAD response
+    at every pixel (raw / sigmoid(-c*T) / (c <= 0); no normalisation).  Buffer names follow
+    bad.py:31-60.  Box sums are exact (fp64 summed-area table per tile); the reference's fp32
+    integral image is off by up to ~1 intensity unit on large images, so parity with it is by
+    tolerance / bit-agreement rate.  The per-pixel oriented path (AKAZE) is not built.
+    """
+
+    def __init__(self, num_pairs: int = 256, binarize: bool = False, soft_binarize: bool = True,
+                 temperature: float = 10.0) -> None:
+        super().__init__()
+        self.num_pairs = num_pairs
+        self.binarize = binarize
+        self.soft_binarize = soft_binarize
+        self.temperature = temperature
+        box, thr = _get_bad_learned_params(num_pairs)
+        for name, col in (("offset_x1", 0), ("offset_x2", 1), ("offset_y1", 2), ("offset_y2", 3)):
+            self.register_buffer(name, box[:, col] - 16.0)
+        self.register_buffer("radii", box[:, 4].to(torch.int64))
+        self.register_buffer("thresholds", thr)
+        self.register_buffer("area", ((2.0 * self.radii.float() + 1.0) ** 2).view(-1, 1, 1))
+        self.max_radius = int(self.radii.max().item())
+        sel = torch.zeros(self.max_radius + 1, num_pairs)
+        sel[self.radii, torch.arange(num_pairs)] = 1.0
+        self.register_buffer("radius_select", sel)
+        r = torch.arange(self.max_radius + 1, dtype=torch.float32).view(-1, 1, 1)
+        c = torch.arange(-self.max_radius, self.max_radius + 1, dtype=torch.float32)
+        inside = ((c.abs().view(1, -1, 1) <= r) & (c.abs().view(1, 1, -1) <= r)).float()
+        self.register_buffer("box_kernel_bank", (inside / (2.0 * r + 1.0) ** 2).unsqueeze(1))
+        b = box.to(torch.int64)
+        geom = b[:, 0] | (b[:, 1] << 5) | (b[:, 2] << 10) | (b[:, 3] << 15) | (b[:, 4] << 20)
+        self.register_buffer("pair_geom", geom.to(torch.int32), persistent=False)
+        self.register_buffer("pair_thr", thr.clone(), persistent=False)
+
+    @property
+    def mode(self) -> int:
+        if not self.binarize:
+            return N.MI_BAD_RAW
+        return N.MI_BAD_SOFT if self.soft_binarize else N.MI_BAD_HARD
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, orientation: torch.Tensor | None = None) -> torch.Tensor:
+        if orientation is not None:
+            raise NotImplementedError("per-pixel oriented dense BAD (bad.py:112-187) is not built")
+        return ops.bad_dense(x, self.pair_geom, self.pair_thr, self.mode, self.temperature)
+
+    @torch.no_grad()
+    def at_keypoints(self, x: torch.Tensor, keypoints: torch.Tensor) -> torch.Tensor:
+        """forward(x) sampled at integer keypoints, without building the (B,P,H,W) map: (B,K,P).
+        Invalid keypoints (-1,-1) give zero rows (the matcher's masking, shi_tomasi_bad_sinkhorn.py:147)."""
+        desc, _ = ops.sparse_bad(x, keypoints, self.pair_geom, self.pair_thr, self.mode, self.temperature, False)
+        return desc
+
+
+@torch.no_grad()
+def extract_descriptors_at_keypoints(descriptor_map: torch.Tensor, keypoints: torch.Tensor) -> torch.Tensor:
+    """(B,D,H,W), integer keypoints (B,N,2) as (y,x) -> (B,N,D) (bad.py:221-274)."""
+    return ops.gather_descriptors(descriptor_map, keypoints, bilinear=False)
+
+
+@torch.no_grad()
+def extract_descriptors_at_keypoints_subpixel(descriptor_map: torch.Tensor, keypoints: torch.Tensor) -> torch.Tensor:
+    """(B,D,H,W), float keypoints (B,N,2) -> (B,N,D) by bilinear grid_sample (bad.py:277-333)."""
+    return ops.gather_descriptors(descriptor_map, keypoints, bilinear=True)

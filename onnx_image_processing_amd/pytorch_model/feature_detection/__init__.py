@@ -2,8 +2,10 @@ from .match_extraction_wrapper import MatchExtractionWrapper
 from .shi_tomasi_angle import ShiTomasiAngleSparseBAD, ShiTomasiAngleSparseBADDetector, ShiTomasiWithAngle
 from .shi_tomasi_angle_sparse_bad_sinkhorn import (ShiTomasiAngleSparseBADSinkhornMatcher,
                                                    ShiTomasiAngleSparseBADSinkhornMatcherWithFilters)
+from .shi_tomasi_bad import ShiTomasiBADDetector
+from .shi_tomasi_bad_sinkhorn import ShiTomasiBADSinkhornMatcher
 from .shi_tomasi_sparse_bad_sinkhorn import ShiTomasiSparseBADSinkhornMatcher
 
-__all__ = ["ShiTomasiSparseBADSinkhornMatcher", "MatchExtractionWrapper", "ShiTomasiWithAngle",
+__all__ = ["ShiTomasiBADDetector", "ShiTomasiBADSinkhornMatcher", "ShiTomasiSparseBADSinkhornMatcher", "MatchExtractionWrapper", "ShiTomasiWithAngle",
            "ShiTomasiAngleSparseBAD", "ShiTomasiAngleSparseBADDetector", "ShiTomasiAngleSparseBADSinkhornMatcher",
            "ShiTomasiAngleSparseBADSinkhornMatcherWithFilters"]

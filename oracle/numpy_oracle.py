@@ -519,3 +519,86 @@ def match_pair_angle(image1, image2, box_params, thresholds, max_keypoints, bloc
         aux["desc1"], aux["desc2"] = out[0][1], out[1][1]
         return res + (aux,)
     return res
+
+
+# --------------------------------------------------------------------------
+# dense BAD: reference pytorch_model/descriptor/bad.py:62-110,189-218,221-333
+# --------------------------------------------------------------------------
+def bad_dense(image, box_params, thresholds, binarize=False, soft_binarize=True, temperature=10.0):
+    """BADDescriptor.forward (non-oriented): (B,1,H,W) -> (B,P,H,W).  Exact box sums (fp64 summed-area
+    table) where the reference uses an fp32 integral image."""
+    img = np.asarray(image, F32)
+    bsz, _, h, w = img.shape
+    box = np.asarray(box_params).astype(np.int64)
+    thr = np.asarray(thresholds, F32).astype(np.float64)
+    rmax = int(box[:, 4].max())
+    rad = box[:, 4][:, None, None]
+    area = ((2 * rad + 1) ** 2).astype(np.float64)
+    yy = np.arange(h)[None, :, None]
+    xx = np.arange(w)[None, None, :]
+    out = np.empty((bsz, box.shape[0], h, w), np.float64)
+    for b in range(bsz):
+        e = np.pad(img[b, 0].astype(np.float64), rmax, mode="edge")
+        sat = np.zeros((e.shape[0] + 1, e.shape[1] + 1), np.float64)
+        sat[1:, 1:] = e.cumsum(0).cumsum(1)
+
+        def mean_box(oy, ox):
+            cy = np.clip(yy + oy[:, None, None], 0, h - 1) + rmax       # bad.py:81-82: centre clamped
+            cx = np.clip(xx + ox[:, None, None], 0, w - 1) + rmax
+            y0, y1, x0, x1 = cy - rad, cy + rad + 1, cx - rad, cx + rad + 1
+            return (sat[y1, x1] - sat[y0, x1] - sat[y1, x0] + sat[y0, x0]) / area
+
+        out[b] = mean_box(box[:, 2] - 16, box[:, 0] - 16) - mean_box(box[:, 3] - 16, box[:, 1] - 16) \
+            - thr[:, None, None]
+    if not binarize:
+        return out.astype(F32)
+    if soft_binarize:
+        z = (-(out.astype(F32)) * F32(temperature)).astype(F32)
+        with np.errstate(over="ignore"):
+            return (F32(1) / (F32(1) + np.exp(-z))).astype(F32)
+    return (out <= 0).astype(F32)
+
+
+def gather_descriptors(descriptor_map, keypoints, bilinear=False):
+    """bad.py:221-274 (integer truncation) / :277-333 (bilinear grid_sample, border, align_corners)."""
+    dm = np.asarray(descriptor_map, F32)
+    kp = np.asarray(keypoints, F32)
+    bsz, d, h, w = dm.shape
+    out = np.empty((bsz, kp.shape[1], d), F32)
+    for b in range(bsz):
+        if not bilinear:
+            yi, xi = kp[b, :, 0].astype(np.int64), kp[b, :, 1].astype(np.int64)
+            out[b] = dm[b][:, yi, xi].T
+            continue
+        gy = kp[b, :, 0] / F32(h - 1 + 1e-8) * F32(2) - F32(1)
+        gx = kp[b, :, 1] / F32(w - 1 + 1e-8) * F32(2) - F32(1)
+        fy = np.clip(((gy + F32(1)) / F32(2)) * F32(h - 1), F32(0), F32(h - 1))
+        fx = np.clip(((gx + F32(1)) / F32(2)) * F32(w - 1), F32(0), F32(w - 1))
+        y0, x0 = np.floor(fy), np.floor(fx)
+        wy1, wx1 = (fy - y0).astype(F32), (fx - x0).astype(F32)
+        wy0, wx0 = F32(1) - wy1, F32(1) - wx1
+        iy0, ix0 = y0.astype(np.int64), x0.astype(np.int64)
+        iy1, ix1 = iy0 + 1, ix0 + 1
+        y1ok, x1ok = iy1 <= h - 1, ix1 <= w - 1
+        iy1c, ix1c = np.minimum(iy1, h - 1), np.minimum(ix1, w - 1)
+        acc = dm[b][:, iy0, ix0] * (wy0 * wx0)
+        acc = acc + dm[b][:, iy0, ix1c] * (wy0 * wx1 * x1ok)
+        acc = acc + dm[b][:, iy1c, ix0] * (wy1 * wx0 * y1ok)
+        acc = acc + dm[b][:, iy1c, ix1c] * (wy1 * wx1 * (y1ok & x1ok))
+        out[b] = acc.T
+    return out
+
+
+def match_pair_dense(image1, image2, box_params, thresholds, max_keypoints, block_size=3, binarize=False,
+                     soft_binarize=True, temperature=10.0, sinkhorn_iterations=20, epsilon=1.0, unused_score=1.0,
+                     distance_type="l2", nms_radius=3, score_threshold=0.0, normalize_descriptors=True):
+    """ShiTomasiBADSinkhornMatcher.forward (feature_detection/shi_tomasi_bad_sinkhorn.py:190-219): no border
+    margin; descriptors = the dense response at the keypoints (here evaluated there directly, exactly)."""
+    out = []
+    for im in (image1, image2):
+        s = shi_tomasi_score(im, block_size)[:, 0]
+        kp, _, _ = select_topk_keypoints(s, nms_mask(s, nms_radius), max_keypoints, score_threshold, 0)
+        d = sparse_bad(im, kp, box_params, thresholds, binarize, soft_binarize, temperature, normalize_descriptors)
+        out.append((kp, d))
+    p = sinkhorn_match(out[0][1], out[1][1], sinkhorn_iterations, epsilon, unused_score, distance_type)
+    return out[0][0], out[1][0], p

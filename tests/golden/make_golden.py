@@ -250,8 +250,41 @@ def angle():
     save("angle_pipeline", **out)
 
 
+def dense():
+    """Dense BADDescriptor, the gather helpers and ShiTomasiBADSinkhornMatcher
+    (descriptor/bad.py:14-333, feature_detection/shi_tomasi_bad_sinkhorn.py)."""
+    from pytorch_model.descriptor.bad import (BADDescriptor, extract_descriptors_at_keypoints,
+                                              extract_descriptors_at_keypoints_subpixel)
+    from pytorch_model.feature_detection.shi_tomasi_bad_sinkhorn import ShiTomasiBADSinkhornMatcher
+    out = dict(seed=3200)
+    small = synth_image(3200, 20, 28)[None, None].astype(np.float32)       # sums < 2^24: fp32 integral is exact
+    with torch.no_grad():
+        ts = torch.from_numpy(small)
+        out["raw256"] = BADDescriptor(256).eval()(ts).numpy()
+        out["hard512"] = np.packbits(BADDescriptor(512, binarize=True, soft_binarize=False).eval()(ts).numpy() != 0)
+        out["soft256"] = BADDescriptor(256, binarize=True, soft_binarize=True, temperature=3.0).eval()(ts).numpy()[:, ::16]
+        g = torch.Generator().manual_seed(41)
+        dm = torch.randn(2, 7, 13, 17, generator=g)
+        ki = torch.stack([torch.randint(0, 13, (2, 9), generator=g), torch.randint(0, 17, (2, 9), generator=g)], -1).float()
+        kf = torch.stack([torch.rand(2, 9, generator=g) * 12, torch.rand(2, 9, generator=g) * 16], -1)
+        kf[0, 0] = torch.tensor([12.0, 16.0]); kf[0, 1] = torch.tensor([0.0, 0.0])
+        out.update(gather_map=dm.numpy(), gather_ki=ki.numpy(), gather_kf=kf.numpy(),
+                   gather_nearest=extract_descriptors_at_keypoints(dm, ki).numpy(),
+                   gather_bilinear=extract_descriptors_at_keypoints_subpixel(dm, kf).numpy())
+        a, b = synth_batch(3201, 1, 120, 160)
+        cfg = dict(max_keypoints=64, num_pairs=256, binarize=True, soft_binarize=False, epsilon=0.05, nms_radius=3)
+        k1, k2, p = ShiTomasiBADSinkhornMatcher(**cfg).eval()(torch.from_numpy(a), torch.from_numpy(b))
+        out.update(m_cfg=np.array(repr(cfg)), m_seed=3201, m_k1=k1.numpy(), m_k2=k2.numpy(), m_P=p.numpy())
+        cfg2 = dict(max_keypoints=48, num_pairs=256, nms_radius=3)
+        k1, k2, p = ShiTomasiBADSinkhornMatcher(**cfg2).eval()(torch.from_numpy(a), torch.from_numpy(b))
+        out.update(s_cfg=np.array(repr(cfg2)), s_k1=k1.numpy(), s_k2=k2.numpy(), s_P=p.numpy())
+    save("dense_bad", **out)
+
+
 if __name__ == "__main__":
-    if "--filters-only" in sys.argv:
+    if "--dense-only" in sys.argv:
+        dense()
+    elif "--filters-only" in sys.argv:
         filters()
     elif "--angle-only" in sys.argv:
         angle()
@@ -259,3 +292,4 @@ if __name__ == "__main__":
         main()
         filters()
         angle()
+        dense()

@@ -254,3 +254,30 @@ def test_reference_smoke_configuration_with_filters():
         assert (valid == g["filt_valid"]).mean() >= 0.99
         ok, worst = p_close(p, g["filt_P"], atol=2e-4)
         assert ok or (valid != g["filt_valid"]).any(), worst
+
+
+# ---------------------------------------------------------------- dense BAD variant (config 3 semantics)
+def test_dense_bad_and_gathers_vs_reference():
+    g = load_golden("dense_bad")
+    small = synth_image(int(g["seed"]), 20, 28)[None, None].astype(np.float32)
+    b256, b512 = bad_tables(256), bad_tables(512)
+    np.testing.assert_allclose(O.bad_dense(small, *b256), g["raw256"], rtol=0, atol=1e-4)
+    hard = O.bad_dense(small, *b512, binarize=True, soft_binarize=False)
+    assert np.array_equal(np.packbits(hard != 0), g["hard512"])          # small image: fp32 integral is exact
+    soft = O.bad_dense(small, *b256, binarize=True, soft_binarize=True, temperature=3.0)[:, ::16]
+    np.testing.assert_allclose(soft, g["soft256"], rtol=0, atol=5e-5)
+    assert np.array_equal(O.gather_descriptors(g["gather_map"], g["gather_ki"]), g["gather_nearest"])
+    np.testing.assert_allclose(O.gather_descriptors(g["gather_map"], g["gather_kf"], True), g["gather_bilinear"],
+                               rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["m", "s"])
+def test_dense_variant_matcher_vs_reference(tag):
+    g = load_golden("dense_bad")
+    a, b = synth_batch(int(g["m_seed"]), 1, 120, 160)
+    cfg = cfg_of(g, tag + "_cfg")
+    kw = {k: v for k, v in cfg.items() if k not in ("num_pairs", "max_keypoints")}
+    k1, k2, p = O.match_pair_dense(a, b, *bad_tables(cfg["num_pairs"]), cfg["max_keypoints"], **kw)
+    assert np.array_equal(k1, g[tag + "_k1"]) and np.array_equal(k2, g[tag + "_k2"])
+    ok, worst = p_close(p, g[tag + "_P"])
+    assert ok, worst
