@@ -196,6 +196,29 @@ int mi_mnn_extract(const float *p, int batch, int n, int m, const float *kpts1, 
                    float *mk1, float *mk2, float *scores, uint8_t *valid, int32_t *match_ij,
                    mi_stream_t stream);
 
+/* ---- detector/akaze.py  AKAZE (BASELINE config 4), all maps fp32 (n,1,h,w) ---------------------
+ * mi_akaze_diffuse: one explicit step of NonLinearDiffusion.forward (akaze.py:98-131):
+ *   g = sobel/8 gradients (zero pad), c = 1/(1+(|g|/kappa)^2) with |g| = sqrt(gx^2+gy^2+1e-8),
+ *   l_out = l_in + dt * div(c*g) (sobel/8 on the zero-padded flux).  l_out must not alias l_in.
+ * mi_akaze_hessian_scores: HessianDetector.forward (akaze.py:227-254): det of the 3x3-kernel
+ *   Hessian, kept where it equals the nms_size^2 window maximum (-inf outside the image) and
+ *   exceeds threshold, clamped >= 0.  nms_size odd <= 15.
+ * mi_akaze_combine: AKAZE.forward's scale selection (akaze.py:442-451) on stacked per-scale maps
+ *   (num_scales,n,h,w): scores = max over scales, orientations = mean of the orientations of the
+ *   scales attaining the max (orientations/scale_orientations may both be NULL: scores only).
+ * mi_akaze_orientation_at_keypoints: the same selection evaluated only at keypoints (n,k,2):
+ *   scale_theta (num_scales,n,k) from mi_angle_at_keypoints per scale -> theta (n,k); equal to
+ *   sampling the combined map the way descriptor/bad.py:487-500 does. */
+int mi_akaze_diffuse(const float *l_in, int n, int h, int w, float kappa, float dt, float *l_out,
+                     mi_stream_t stream);
+int mi_akaze_hessian_scores(const float *l, int n, int h, int w, float threshold, int nms_size, float *scores,
+                            mi_stream_t stream);
+int mi_akaze_combine(const float *scale_scores, const float *scale_orientations, int num_scales, int n, int h,
+                     int w, float *scores, float *orientations, mi_stream_t stream);
+int mi_akaze_orientation_at_keypoints(const float *scale_scores, const float *scale_theta, int num_scales,
+                                      int n, int h, int w, const float *keypoints, int k, float *theta,
+                                      mi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

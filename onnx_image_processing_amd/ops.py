@@ -294,3 +294,55 @@ def mnn_extract(p: torch.Tensor, kpts1: torch.Tensor, kpts2: torch.Tensor, max_m
            mk2.data_ptr(), sc.data_ptr(), valid.data_ptr(), ij.data_ptr(), N.stream_ptr())
     out = (mk1, mk2, sc, valid.bool())
     return out + (ij,) if return_indices else out
+
+
+# ---- AKAZE (detector/akaze.py) ------------------------------------------------------------------
+
+def akaze_diffuse(image: torch.Tensor, iterations: int, kappa: float, dt: float = 0.25) -> torch.Tensor:
+    """NonLinearDiffusion.forward: `iterations` explicit steps, ping-ponging two buffers."""
+    img = _images(image, "image")
+    n, _, h, w = img.shape
+    if iterations <= 0:
+        return img
+    bufs = [torch.empty_like(img), torch.empty_like(img) if iterations > 1 else None]
+    cur = img
+    for i in range(int(iterations)):
+        dst = bufs[i & 1]
+        N.call("mi_akaze_diffuse", N.dev(cur, F32, "image"), n, h, w, float(kappa), float(dt), dst.data_ptr(),
+               N.stream_ptr())
+        cur = dst
+    return cur
+
+
+def akaze_hessian_scores(image: torch.Tensor, threshold: float, nms_size: int,
+                         out: torch.Tensor | None = None) -> torch.Tensor:
+    img = _images(image, "image")
+    n, _, h, w = img.shape
+    if out is None:
+        out = torch.empty_like(img)
+    N.call("mi_akaze_hessian_scores", N.dev(img, F32, "image"), n, h, w, float(threshold), int(nms_size),
+           N.dev(out, F32, "scores"), N.stream_ptr())
+    return out
+
+
+def akaze_combine(scale_scores: torch.Tensor, scale_orientations: torch.Tensor | None):
+    """(S,N,1,H,W) stacks -> (scores, orientations) of AKAZE.forward; orientations None -> scores only."""
+    s, n, _, h, w = scale_scores.shape
+    scores = torch.empty((n, 1, h, w), dtype=F32, device=scale_scores.device)
+    oris = torch.empty_like(scores) if scale_orientations is not None else None
+    N.call("mi_akaze_combine", N.dev(scale_scores, F32, "scale_scores"),
+           N.dev(scale_orientations, F32, "scale_orientations") if scale_orientations is not None else None,
+           s, n, h, w, scores.data_ptr(), oris.data_ptr() if oris is not None else None, N.stream_ptr())
+    return scores, oris
+
+
+def akaze_orientation_at_keypoints(scale_scores: torch.Tensor, scale_theta: torch.Tensor,
+                                   keypoints: torch.Tensor) -> torch.Tensor:
+    s, n, _, h, w = scale_scores.shape
+    kp = keypoints.float().contiguous()
+    k = kp.shape[1]
+    theta = torch.empty((n, k), dtype=F32, device=scale_scores.device)
+    N.call("mi_akaze_orientation_at_keypoints", N.dev(scale_scores, F32, "scale_scores"),
+           N.dev(scale_theta, F32, "scale_theta"), s, n, h, w, N.dev(kp, F32, "keypoints"), k, theta.data_ptr(),
+           N.stream_ptr())
+    return theta

@@ -1,0 +1,124 @@
+"""AKAZE detector -- mirror of reference pytorch_model/detector/akaze.py:27-453.
+
+Same classes, constructor arguments, buffers (state_dict keys `diffusion_layers.{i}.sobel_xy`,
+`diffusion_layers.{i}.sobel_xy_grouped`, `detector.hessian_kernels`,
+`orientation_estimator.moment_kernels`) and forward signatures; the arithmetic runs in the K9 HIP
+kernels (csrc/akaze.hip) and K8 (csrc/orient.hip).  The 3x3 weights are structural constants of
+those kernels (the buffers exist for state_dict compatibility); the moment kernels are read from
+the buffer.
+"""
+import torch
+from torch import nn
+
+from ... import ops
+
+
+def _sobel_pair() -> torch.Tensor:
+    sx = torch.tensor([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], dtype=torch.float32).view(1, 1, 3, 3) / 8.0
+    sy = torch.tensor([[-1, -2, -1], [0, 0, 0], [1, 2, 1]], dtype=torch.float32).view(1, 1, 3, 3) / 8.0
+    return torch.cat([sx, sy], dim=0)
+
+
+class NonLinearDiffusion(nn.Module):
+    """forward(image (N,1,H,W)) -> diffused image, `num_iterations` explicit Perona-Malik (g2) steps
+    with dt = 0.25 (akaze.py:43-131)."""
+
+    def __init__(self, num_iterations: int = 3, kappa: float = 0.05):
+        super().__init__()
+        self.num_iterations = num_iterations
+        self.kappa = kappa
+        self.register_buffer("sobel_xy", _sobel_pair())
+        self.register_buffer("sobel_xy_grouped", _sobel_pair())
+        self.dt = 0.25
+
+    @torch.no_grad()
+    def forward(self, image: torch.Tensor) -> torch.Tensor:
+        return ops.akaze_diffuse(image, self.num_iterations, self.kappa, self.dt)
+
+
+class HessianDetector(nn.Module):
+    """forward(image) -> score map: Hessian determinant at nms_size^2 local maxima above
+    `threshold`, 0 elsewhere (akaze.py:146-254)."""
+
+    def __init__(self, threshold: float = 0.001, nms_size: int = 5):
+        super().__init__()
+        self.threshold = threshold
+        self.nms_size = nms_size
+        kxx = torch.tensor([[1, -2, 1], [2, -4, 2], [1, -2, 1]], dtype=torch.float32).view(1, 1, 3, 3) / 16.0
+        kyy = torch.tensor([[1, 2, 1], [-2, -4, -2], [1, 2, 1]], dtype=torch.float32).view(1, 1, 3, 3) / 16.0
+        kxy = torch.tensor([[1, 0, -1], [0, 0, 0], [-1, 0, 1]], dtype=torch.float32).view(1, 1, 3, 3) / 4.0
+        self.register_buffer("hessian_kernels", torch.cat([kxx, kyy, kxy], dim=0))
+
+    @torch.no_grad()
+    def forward(self, image: torch.Tensor) -> torch.Tensor:
+        return ops.akaze_hessian_scores(image, self.threshold, self.nms_size)
+
+
+class OrientationEstimator(nn.Module):
+    """forward(image) -> atan2(m01, m10) of Gaussian-weighted moments (akaze.py:256-314); the same
+    arithmetic as orientation.AngleEstimator, so it runs on the same K8 kernels."""
+
+    def __init__(self, patch_size: int = 15, sigma: float = 2.5):
+        super().__init__()
+        self.patch_size = patch_size
+        self.sigma = sigma
+        half = patch_size // 2
+        c = torch.arange(-half, half + 1, dtype=torch.float32)
+        y, x = torch.meshgrid(c, c, indexing="ij")
+        gaussian = torch.exp(-(x ** 2 + y ** 2) / (2 * sigma ** 2))
+        wx = (x * gaussian).view(1, 1, patch_size, patch_size)
+        wy = (y * gaussian).view(1, 1, patch_size, patch_size)
+        self.register_buffer("moment_kernels", torch.cat([wx, wy], dim=0))
+
+    @torch.no_grad()
+    def forward(self, image: torch.Tensor) -> torch.Tensor:
+        return ops.angle_map(image, self.moment_kernels, self.patch_size)
+
+    @torch.no_grad()
+    def at_keypoints(self, image: torch.Tensor, keypoints: torch.Tensor) -> torch.Tensor:
+        return ops.angle_at_keypoints(image, keypoints, self.moment_kernels, self.patch_size)
+
+
+class AKAZE(nn.Module):
+    """forward(image (N,1,H,W)) -> (scores, orientations), both (N,1,H,W) (akaze.py:317-453):
+    per scale i, L_i = diffusion_i(L_{i-1}); scores = max_i Hessian scores(L_i); orientations =
+    mean of the orientation maps of the scales attaining that max.
+
+    `detect(image)` (extension) returns (scores, scale_scores (S,N,1,H,W), scale_images) without
+    the S dense orientation maps, and `orientation_at_keypoints` evaluates the same selection at
+    keypoints only -- what the matcher needs."""
+
+    def __init__(self, num_scales: int = 3, diffusion_iterations: int = 3, kappa: float = 0.05,
+                 threshold: float = 0.001, nms_size: int = 5, orientation_patch_size: int = 15,
+                 orientation_sigma: float = 2.5):
+        super().__init__()
+        self.num_scales = num_scales
+        self.diffusion_layers = nn.ModuleList(
+            [NonLinearDiffusion(num_iterations=diffusion_iterations, kappa=kappa) for _ in range(num_scales)])
+        self.detector = HessianDetector(threshold=threshold, nms_size=nms_size)
+        self.orientation_estimator = OrientationEstimator(patch_size=orientation_patch_size, sigma=orientation_sigma)
+
+    @torch.no_grad()
+    def detect(self, image: torch.Tensor):
+        img = ops._images(image, "image")
+        n, _, h, w = img.shape
+        scale_scores = torch.empty((self.num_scales, n, 1, h, w), dtype=torch.float32, device=img.device)
+        scale_images = []
+        cur = img
+        for i in range(self.num_scales):
+            cur = self.diffusion_layers[i](cur)
+            ops.akaze_hessian_scores(cur, self.detector.threshold, self.detector.nms_size, out=scale_scores[i])
+            scale_images.append(cur)
+        scores, _ = ops.akaze_combine(scale_scores, None)
+        return scores, scale_scores, scale_images
+
+    @torch.no_grad()
+    def orientation_at_keypoints(self, scale_scores: torch.Tensor, scale_images, keypoints: torch.Tensor):
+        theta = torch.stack([self.orientation_estimator.at_keypoints(im, keypoints) for im in scale_images])
+        return ops.akaze_orientation_at_keypoints(scale_scores, theta.contiguous(), keypoints)
+
+    @torch.no_grad()
+    def forward(self, image: torch.Tensor):
+        _, scale_scores, scale_images = self.detect(image)
+        scale_oris = torch.stack([self.orientation_estimator(im) for im in scale_images])
+        return ops.akaze_combine(scale_scores, scale_oris.contiguous())

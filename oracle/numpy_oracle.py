@@ -602,3 +602,123 @@ def match_pair_dense(image1, image2, box_params, thresholds, max_keypoints, bloc
         out.append((kp, d))
     p = sinkhorn_match(out[0][1], out[1][1], sinkhorn_iterations, epsilon, unused_score, distance_type)
     return out[0][0], out[1][0], p
+
+
+# --------------------------------------------------------------------------
+# AKAZE (BASELINE config 4): reference pytorch_model/detector/akaze.py
+# --------------------------------------------------------------------------
+def _pad1(a, value=0.0):
+    return np.pad(a, ((0, 0), (1, 1), (1, 1)), constant_values=value)
+
+
+def _corr3(a, k):
+    """3x3 cross-correlation of (N,H,W) with zero padding, fp32, row-major tap order."""
+    e = _pad1(a)
+    n, h, w = a.shape
+    acc = np.zeros_like(a)
+    for dy in range(3):
+        for dx in range(3):
+            if k[dy][dx] != 0:
+                acc = acc + F32(k[dy][dx]) * e[:, dy:dy + h, dx:dx + w]
+    return acc
+
+
+_SOBEL_X = (np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], F32) / F32(8)).tolist()
+_SOBEL_Y = (np.array([[-1, -2, -1], [0, 0, 0], [1, 2, 1]], F32) / F32(8)).tolist()
+_HXX = (np.array([[1, -2, 1], [2, -4, 2], [1, -2, 1]], F32) / F32(16)).tolist()
+_HYY = (np.array([[1, 2, 1], [-2, -4, -2], [1, 2, 1]], F32) / F32(16)).tolist()
+_HXY = (np.array([[1, 0, -1], [0, 0, 0], [-1, 0, 1]], F32) / F32(4)).tolist()
+
+
+def akaze_diffuse(image, iterations=3, kappa=0.05, dt=0.25):
+    """NonLinearDiffusion.forward (akaze.py:98-131): (N,1,H,W) -> (N,1,H,W), fp32."""
+    cur = np.asarray(image, F32)[:, 0]
+    for _ in range(iterations):
+        gx, gy = _corr3(cur, _SOBEL_X), _corr3(cur, _SOBEL_Y)                    # :82
+        mag = np.sqrt(gx * gx + gy * gy + F32(1e-8))                             # :116
+        q = mag / F32(kappa)
+        c = F32(1) / (F32(1) + q * q)                                            # :96
+        div = _corr3(c * gx, _SOBEL_X) + _corr3(c * gy, _SOBEL_Y)                # :125-126
+        cur = (cur + F32(dt) * div).astype(F32)                                  # :129
+    return cur[:, None]
+
+
+def akaze_hessian_response(image):
+    """HessianDetector.compute_hessian_response (akaze.py:173-198)."""
+    a = np.asarray(image, F32)[:, 0]
+    lxx, lyy, lxy = _corr3(a, _HXX), _corr3(a, _HYY), _corr3(a, _HXY)
+    return (lxx * lyy - lxy * lxy).astype(F32)[:, None]
+
+
+def akaze_hessian_scores(image, threshold=0.001, nms_size=5):
+    """HessianDetector.forward (akaze.py:227-254)."""
+    resp = akaze_hessian_response(image)[:, 0]
+    n, h, w = resp.shape
+    half = nms_size // 2
+    e = np.pad(resp, ((0, 0), (half, half), (half, half)), constant_values=-np.inf)
+    mx = np.full_like(resp, -np.inf)
+    for dy in range(nms_size):
+        for dx in range(nms_size):
+            mx = np.maximum(mx, e[:, dy:dy + h, dx:dx + w])
+    keep = ((resp == mx) & (resp > F32(threshold))).astype(F32)                  # :223,:245-246
+    return np.maximum(resp * keep, F32(0))[:, None]                              # :249-252
+
+
+def akaze_select(scale_scores, scale_orientations):
+    """AKAZE.forward scale selection (akaze.py:442-451) on (S,N,1,H,W) stacks."""
+    ss = np.asarray(scale_scores, F32)
+    scores = ss.max(axis=0)
+    mask = (ss == scores[None]).astype(F32)
+    mask = mask / np.maximum(mask.sum(axis=0, keepdims=True), F32(1))
+    oris = (np.asarray(scale_orientations, F32) * mask).sum(axis=0, dtype=F32)
+    return scores, oris
+
+
+def akaze(image, num_scales=3, diffusion_iterations=3, kappa=0.05, threshold=0.001, nms_size=5,
+          orientation_patch_size=15, orientation_sigma=2.5, return_scales=False):
+    """AKAZE.forward (akaze.py:384-453): (N,1,H,W) -> (scores, orientations)."""
+    cur = np.asarray(image, F32)
+    ss, so, ls = [], [], []
+    for _ in range(num_scales):
+        cur = akaze_diffuse(cur, diffusion_iterations, kappa)
+        ss.append(akaze_hessian_scores(cur, threshold, nms_size))
+        so.append(angle_map(cur, orientation_patch_size, orientation_sigma))
+        ls.append(cur)
+    scores, oris = akaze_select(np.stack(ss), np.stack(so))
+    if return_scales:
+        return scores, oris, np.stack(ss), np.stack(so), np.stack(ls)
+    return scores, oris
+
+
+def match_pair_akaze(image1, image2, box_params, thresholds, max_keypoints, num_scales=3, diffusion_iterations=3,
+                     kappa=0.05, threshold=0.001, akaze_nms_size=5, orientation_patch_size=15,
+                     orientation_sigma=2.5, binarize=False, soft_binarize=True, temperature=10.0,
+                     sinkhorn_iterations=20, epsilon=1.0, unused_score=1.0, distance_type="l2", nms_radius=3,
+                     score_threshold=0.0, normalize_descriptors=True, border_margin=None, return_aux=False,
+                     scores_override=None):
+    """AKAZESparseBADSinkhornMatcher.forward (feature_detection/akaze_sparse_bad_sinkhorn.py:148-196).
+    scores_override: optional pair of (scores, orientations) maps to run the stages after the
+    detector from (tests use it to separate detector tolerance from selection order)."""
+    if border_margin is None:
+        border_margin = int(np.asarray(box_params)[:, 4].max())
+    out, aux = [], {}
+    for idx, im in enumerate((image1, image2)):
+        if scores_override is not None:
+            sc, ori = scores_override[idx]
+        else:
+            sc, ori = akaze(im, num_scales, diffusion_iterations, kappa, threshold, akaze_nms_size,
+                            orientation_patch_size, orientation_sigma)
+        s = np.asarray(sc, F32)[:, 0]
+        kp, ksc, _ = select_topk_keypoints(s, nms_mask(s, nms_radius), max_keypoints, score_threshold, border_margin)
+        theta = sample_nearest(ori, kp)
+        d = sparse_bad_oriented(im, kp, theta, box_params, thresholds, binarize, soft_binarize, temperature,
+                                normalize_descriptors)
+        out.append((kp, d))
+        aux[f"theta{idx + 1}"], aux[f"kscores{idx + 1}"] = theta, ksc
+        aux[f"scores{idx + 1}"], aux[f"ori{idx + 1}"] = sc, ori
+    p = sinkhorn_match(out[0][1], out[1][1], sinkhorn_iterations, epsilon, unused_score, distance_type)
+    res = (out[0][0], out[1][0], p)
+    if return_aux:
+        aux["desc1"], aux["desc2"] = out[0][1], out[1][1]
+        return res + (aux,)
+    return res

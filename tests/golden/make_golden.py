@@ -281,9 +281,56 @@ def dense():
     save("dense_bad", **out)
 
 
+def akaze():
+    """AKAZE detector and AKAZESparseBADSinkhornMatcher (detector/akaze.py,
+    feature_detection/akaze_sparse_bad_sinkhorn.py) -- BASELINE config 4."""
+    from pytorch_model.detector.akaze import AKAZE
+    from pytorch_model.feature_detection.akaze_sparse_bad_sinkhorn import AKAZESparseBADSinkhornMatcher
+    out = dict(seed=3300, h=96, w=128)
+    img = synth_image(3300, 96, 128)[None, None].astype(np.float32)
+    with torch.no_grad():
+        for tag, x in (("u8", torch.from_numpy(img)), ("unit", torch.from_numpy(img / np.float32(255.0)))):
+            m = AKAZE().eval()
+            l1 = m.diffusion_layers[0](x)
+            out[f"{tag}_diffused1"] = l1.numpy()
+            out[f"{tag}_response1"] = m.detector.compute_hessian_response(l1).numpy()
+            out[f"{tag}_scores1"] = m.detector(l1).numpy()
+            sc, ori = m(x)
+            out[f"{tag}_scores"], out[f"{tag}_orientations"] = sc.numpy(), ori.numpy()
+        m2 = AKAZE(num_scales=2, diffusion_iterations=2, kappa=0.2, threshold=0.0005, nms_size=3,
+                   orientation_patch_size=9, orientation_sigma=1.5).eval()
+        sc, ori = m2(torch.from_numpy(img / np.float32(255.0)))
+        out["alt_scores"], out["alt_orientations"] = sc.numpy(), ori.numpy()
+        a, b = synth_batch(3301, 1, 120, 160)
+        cfgs = {"soft": dict(max_keypoints=64), 
+                "hard": dict(max_keypoints=48, num_pairs=512, binarize=True, soft_binarize=False, epsilon=0.05)}
+        for scale_tag, div in (("u8", 1.0), ("unit", 255.0)):
+            ta, tb = torch.from_numpy(a / np.float32(div)), torch.from_numpy(b / np.float32(div))
+            for name, cfg in cfgs.items():
+                if scale_tag == "unit" and name == "hard":
+                    continue
+                key = f"{name}_{scale_tag}"
+                mm = AKAZESparseBADSinkhornMatcher(**cfg).eval()
+                k1, k2, p = mm(ta, tb)
+                out[key + "_cfg"] = np.array(repr(cfg))
+                out[key + "_k1"], out[key + "_k2"], out[key + "_P"] = k1.numpy(), k2.numpy(), p.numpy()
+                for t, im, kp in (("1", ta, k1), ("2", tb, k2)):
+                    sc, ori = mm.detector(im)
+                    _, ksc = select_topk_keypoints(sc.squeeze(1), apply_nms_maxpool(sc.squeeze(1), mm.nms_radius),
+                                                   cfg["max_keypoints"], mm.score_threshold, mm.border_margin)
+                    out[f"{key}_kscores{t}"] = ksc.numpy()
+                    out[f"{key}_scoremap{t}"] = sc.numpy()
+                    out[f"{key}_orimap{t}"] = ori.numpy()
+                    out[f"{key}_desc{t}"] = mm.descriptor(im, kp, ori).numpy()
+    out["pair_seed"] = 3301
+    save("akaze_pipeline", **out)
+
+
 if __name__ == "__main__":
     if "--dense-only" in sys.argv:
         dense()
+    elif "--akaze-only" in sys.argv:
+        akaze()
     elif "--filters-only" in sys.argv:
         filters()
     elif "--angle-only" in sys.argv:
@@ -293,3 +340,4 @@ if __name__ == "__main__":
         filters()
         angle()
         dense()
+        akaze()

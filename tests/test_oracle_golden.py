@@ -281,3 +281,42 @@ def test_dense_variant_matcher_vs_reference(tag):
     assert np.array_equal(k1, g[tag + "_k1"]) and np.array_equal(k2, g[tag + "_k2"])
     ok, worst = p_close(p, g[tag + "_P"])
     assert ok, worst
+
+
+# ------------------------------------------------------------------ AKAZE (config 4)
+def test_akaze_detector_vs_reference():
+    g = load_golden("akaze_pipeline")
+    img = synth_image(int(g["seed"]), int(g["h"]), int(g["w"]))[None, None].astype(np.float32)
+    for tag, x in (("u8", img), ("unit", img / np.float32(255.0))):
+        d1 = O.akaze_diffuse(x)
+        assert np.array_equal(d1, g[tag + "_diffused1"])                       # 3x3 stencils: bit-exact
+        assert np.array_equal(O.akaze_hessian_response(d1), g[tag + "_response1"])
+        assert np.array_equal(O.akaze_hessian_scores(d1), g[tag + "_scores1"])
+        sc, ori = O.akaze(x)
+        np.testing.assert_allclose(sc, g[tag + "_scores"], rtol=1e-6, atol=0)
+        assert np.array_equal(sc > 0, g[tag + "_scores"] > 0)
+        assert np.abs(ori - g[tag + "_orientations"]).max() < 3e-4              # 225-tap conv: tolerance
+    sc, ori = O.akaze(img / np.float32(255.0), 2, 2, 0.2, 0.0005, 3, 9, 1.5)
+    assert np.array_equal(sc, g["alt_scores"]) and (sc > 0).sum() > 100
+    assert np.abs(ori - g["alt_orientations"]).max() < 3e-4
+
+
+@pytest.mark.parametrize("key,div", [("soft_u8", 1.0), ("hard_u8", 1.0), ("soft_unit", 255.0)])
+def test_akaze_pipeline_vs_reference(key, div):
+    g = load_golden("akaze_pipeline")
+    a, b = synth_batch(int(g["pair_seed"]), 1, 120, 160)
+    a, b = a / np.float32(div), b / np.float32(div)
+    cfg = cfg_of(g, key + "_cfg")
+    box, thr = bad_tables(cfg.get("num_pairs", 256))
+    kw = {k: v for k, v in cfg.items() if k not in ("num_pairs", "max_keypoints")}
+    k1, k2, p, aux = O.match_pair_akaze(a, b, box, thr, cfg["max_keypoints"], return_aux=True, **kw)
+    assert np.array_equal(k1, g[key + "_k1"]) and np.array_equal(k2, g[key + "_k2"])
+    assert np.array_equal(aux["kscores1"], g[key + "_kscores1"])
+    np.testing.assert_allclose(aux["scores1"], g[key + "_scoremap1"], rtol=1e-6, atol=0)
+    assert np.abs(aux["ori2"] - g[key + "_orimap2"]).max() < 3e-4
+    if cfg.get("binarize") and not cfg.get("soft_binarize", True):
+        assert ((aux["desc1"] != 0) == (g[key + "_desc1"] != 0)).mean() >= 0.9995
+    else:
+        np.testing.assert_allclose(aux["desc1"], g[key + "_desc1"], rtol=0, atol=1e-4)
+    ok, worst = p_close(p, g[key + "_P"], atol=2e-4)
+    assert ok, worst
