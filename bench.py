@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the whole path (Shi-Tomasi -> NMS/top-k -> sparse BAD -> cost ->
-Sinkhorn -> mutual-NN match extraction) over a batch of B synthetic pairs per GPU that is
+Sinkhorn -> mutual-NN match extraction; the reference's MatchExtractionWrapper form) over a batch of B synthetic pairs per GPU that is
 already resident in HBM, followed (N > 1) by the RCCL gather of the match records to rank 0.
 Configuration = BASELINE.json configs[1] hyper-parameters (the export-CLI values, SURVEY.md
 §2.2) with K=512; pairs are independent, so ranks hold different pairs (weak scaling).
@@ -57,6 +57,64 @@ def cpu_baseline(pairs: int) -> dict:
                       f"at a time; BLAS matmul uses {threads} threads, the rest is single-threaded numpy"}
 
 
+def side_workload(args, rank, world, dev) -> None:
+    """BASELINE configs[2]/[3] through the same modules: an informational JSON line (value and per-call
+    times only), not the bench contract's line."""
+    from onnx_image_processing_amd import _native, distributed as D
+    from onnx_image_processing_amd.pytorch_model.feature_detection import (AKAZESparseBADSinkhornMatcher,
+                                                                           MatchExtractionWrapper,
+                                                                           ShiTomasiSparseBADSinkhornMatcher)
+    from onnx_image_processing_amd.synth import synth_batch
+    B = args.pairs_per_gpu
+    if args.workload == "c3":
+        h, w, k = 1080, 1920, 1024
+        base = ShiTomasiSparseBADSinkhornMatcher(max_keypoints=k, **CFG)
+        what = "Shi-Tomasi sparse pipeline, 1920x1080, K=1024 (BASELINE configs[2])"
+    else:
+        h, w, k = H, W, K
+        cfg = {kk: v for kk, v in CFG.items() if kk != "block_size"}
+        base = AKAZESparseBADSinkhornMatcher(max_keypoints=k, **cfg)
+        what = "AKAZE(3 scales x 3 steps) + oriented sparse BAD + Sinkhorn, 640x480, K=512 (BASELINE configs[3])"
+    begin, _ = D.shard_range(B * world, rank, world)
+    a, b = synth_batch(1000 + begin, B, h, w)
+    img1, img2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    del a, b
+    model = MatchExtractionWrapper(base, max_matches=MNN["max_matches"], match_threshold=MNN["threshold"]).to(dev)
+    model.fuse_extraction = not args.two_step
+
+    def step():
+        return D.gather_records(D.pack_records(*model(img1, img2)), dst=0)
+
+    for _ in range(args.warmup):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _native.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed_ms = D.barrier_max_ms((time.perf_counter() - t0) * 1e3, dev)
+    per_call = _native.timings_ms()
+    _native.enable_timing(False)
+    if rank == 0:
+        ms = elapsed_ms / args.steps
+        print(json.dumps({
+            "metric": f"image-pairs/sec ({w}x{h}, K={k})", "value": B * world / (ms * 1e-3), "unit": "image-pairs/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": what, "pairs_per_gpu_per_step": B,
+                       "mean_valid_matches_per_pair": float(out[..., 5].sum().item()) / (B * world)},
+            "kernels": {kk: {"ms_per_step": float(np.sum(v)) / args.steps, "calls_per_step": len(v) / args.steps}
+                        for kk, v in per_call.items()}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,11 +122,16 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-gpu", type=int, default=256)
     ap.add_argument("--cpu-pairs", type=int, default=24, help="oracle sample size for cpu_baseline (0 = skip)")
+    ap.add_argument("--two-step", action="store_true",
+                    help="materialise P and run the extractor on it (default: matches straight from the duals)")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
+                    help="c2 (default, the metric's configuration); c3 = 1080x1920 K=1024; c4 = AKAZE front end "
+                         "(informational lines: no roofline/cpu_baseline)")
     args = ap.parse_args()
 
     from onnx_image_processing_amd import _native, distributed as D
-    from onnx_image_processing_amd.pytorch_model.feature_detection import ShiTomasiSparseBADSinkhornMatcher
-    from onnx_image_processing_amd.pytorch_model.matching.match_extraction import MutualNearestNeighborMatcher
+    from onnx_image_processing_amd.pytorch_model.feature_detection import (MatchExtractionWrapper,
+                                                                           ShiTomasiSparseBADSinkhornMatcher)
     from onnx_image_processing_amd.synth import synth_batch
 
     rank, world, local = D.init()
@@ -81,16 +144,19 @@ def main() -> None:
     _native.load()
 
     B = args.pairs_per_gpu
+    if args.workload != "c2":
+        return side_workload(args, rank, world, dev)
     begin, _ = D.shard_range(B * world, rank, world)            # this rank's pairs in the global order
     a, b = synth_batch(1000 + begin, B, H, W)
     img1, img2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)   # resident in HBM before timing
     del a, b
-    model = ShiTomasiSparseBADSinkhornMatcher(max_keypoints=K, **CFG).to(dev)
-    extract = MutualNearestNeighborMatcher(**MNN)
+    # the reference's deployment form of "matcher + match extraction" (match_extraction_wrapper.py:82-113)
+    model = MatchExtractionWrapper(ShiTomasiSparseBADSinkhornMatcher(max_keypoints=K, **CFG),
+                                   max_matches=MNN["max_matches"], match_threshold=MNN["threshold"]).to(dev)
+    model.fuse_extraction = not args.two_step
 
     def step():
-        k1, k2, p = model(img1, img2)
-        rec = D.pack_records(*extract(p, k1, k2))
+        rec = D.pack_records(*model(img1, img2))
         return D.gather_records(rec, dst=0)
 
     for _ in range(args.warmup):

@@ -46,7 +46,8 @@ const char *mi_error_string(int code);
 /* Development/test hook: choose between equivalent kernel implementations (results are
  * identical).  key 1: corner response, 0 = streaming LDS-DMA kernel (default), 1 = register-
  * staged tile kernel.  key 2: rows per thread of the streaming corner kernel (4, 5 or 8).
- * key 4: Sinkhorn band partials, 0 = probability form (default), 1 = log-domain (max,sum) form. */
+ * key 4: Sinkhorn band kernel, 0 = probability form, lean instruction stream (default), 2 = first
+ * probability-form kernel, 1 = log-domain (max,sum) partials (results agree to fp32 rounding). */
 int mi_debug_set(int key, int value);
 
 /* ---- detector/shi_tomasi.py:66-112  ShiTomasiScore.forward ---------------------------------
@@ -153,7 +154,7 @@ int mi_cost_logscores_f32(const float *desc1, const float *desc2, int batch, int
  * z: core log-scores as above.  dustbin_logscore = fp32(-unused_score/epsilon).  u (batch*(n+1))
  * and v (batch*(m+1)) are workspace and return the final duals.  p (batch, n+1, m+1) dense =
  * exp(Z + u + v) over the augmented matrix; may be NULL (duals only).  iterations >= 1.
- * workspace: mi_sinkhorn_workspace_bytes(batch, n, m) bytes, 8-byte aligned, enables the fused
+ * workspace: mi_sinkhorn_workspace_bytes(batch, n, m) bytes, 16-byte aligned, enables the fused
  * iteration that reads Z once per iteration (per-band column partials); with workspace == NULL
  * (or m > 1024, for which the query returns 0) the two-pass form runs -- same results up to
  * fp32 summation order. */
@@ -195,6 +196,24 @@ int mi_mnn_extract(const float *p, int batch, int n, int m, const float *kpts1, 
                    int max_matches, float threshold, uint64_t *row_best, uint64_t *col_best,
                    float *mk1, float *mk2, float *scores, uint8_t *valid, int32_t *match_ij,
                    mi_stream_t stream);
+
+/* ---- MutualNearestNeighborMatcher.forward straight from the Sinkhorn duals ---------------------
+ * What feature_detection/match_extraction_wrapper.py:82-113 computes (matcher -> P -> mutual NN)
+ * without materialising P: P_ij = expf((z_ij + u_i) + v_j) is evaluated in registers exactly as
+ * mi_sinkhorn's final pass does, so the outputs are bit-identical to mi_sinkhorn(p != NULL) followed
+ * by mi_mnn_extract.  z/pitch (or dots/row_info/col_info/pitch/epsilon) and u, v are what was
+ * passed to / returned by mi_sinkhorn (mi_sinkhorn_dots) with p == NULL.  m <= 1024, n <= 4096.
+ * workspace: mi_mnn_duals_workspace_bytes(batch, n, m) bytes (0 = unsupported size), 8-byte aligned. */
+size_t mi_mnn_duals_workspace_bytes(int batch, int n, int m);
+int mi_mnn_from_duals(const float *z, int batch, int n, int m, int pitch, const float *u, const float *v,
+                      const float *kpts1, const float *kpts2, int max_matches, float threshold, void *workspace,
+                      size_t workspace_bytes, float *mk1, float *mk2, float *scores, uint8_t *valid,
+                      int32_t *match_ij, mi_stream_t stream);
+int mi_mnn_from_duals_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch, int n,
+                           int m, int pitch, double epsilon, const float *u, const float *v, const float *kpts1,
+                           const float *kpts2, int max_matches, float threshold, void *workspace,
+                           size_t workspace_bytes, float *mk1, float *mk2, float *scores, uint8_t *valid,
+                           int32_t *match_ij, mi_stream_t stream);
 
 /* ---- detector/akaze.py  AKAZE (BASELINE config 4), all maps fp32 (n,1,h,w) ---------------------
  * mi_akaze_diffuse: one explicit step of NonLinearDiffusion.forward (akaze.py:98-131):

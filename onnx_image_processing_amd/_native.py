@@ -49,6 +49,12 @@ SIGNATURES = {
     "mi_match_filters": [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p],
     "mi_mnn_extract": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mi_mnn_duals_workspace_bytes": [c_int, c_int, c_int],
+    "mi_mnn_from_duals": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                          c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mi_mnn_from_duals_dots": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_int, c_float, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p],
     "mi_akaze_diffuse": [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p],
     "mi_akaze_hessian_scores": [c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     "mi_akaze_combine": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
@@ -56,7 +62,7 @@ SIGNATURES = {
                                           c_void_p],
 }
 _RESTYPE = {"mi_error_string": c_char_p, "mi_sinkhorn_workspace_bytes": c_size_t, "mi_bad_plan_bytes": c_size_t,
-            "mi_sinkhorn_dots_workspace_bytes": c_size_t}
+            "mi_sinkhorn_dots_workspace_bytes": c_size_t, "mi_mnn_duals_workspace_bytes": c_size_t}
 
 MI_BAD_RAW, MI_BAD_SOFT, MI_BAD_HARD = 0, 1, 2
 MI_DIST_L2, MI_DIST_L1 = 0, 1

@@ -52,6 +52,14 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// log-score of the packed-descriptor (uint16 dot product) form, shared by K6 and K7 so that both
+// rebuild the same bits: z = nie*(na + nb) + dot*sb*(-2*nie*sa), nie = -1/epsilon, (scale, squared
+// norm) pairs per descriptor (reference matching/sinkhorn.py:101-103,178; the cost's clamp at 0 only
+// acts on rounding noise of identical descriptors and is dropped, see sinkhorn_dots.hip).
+__device__ __forceinline__ float mi_z_from_dot(float dot, float2 row, float2 col, float neg_inv_eps) {
+  return __builtin_fmaf(dot * col.x, -2.0f * neg_inv_eps * row.x, col.y * neg_inv_eps) + row.y * neg_inv_eps;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -130,7 +130,213 @@ __global__ __launch_bounds__(MX_THREADS) void mnn_select_kernel(
   }
 }
 
+// ---- mutual-NN straight from the Sinkhorn duals: P is never written ------------------------------
+// P_ij = expf((z_ij + u_i) + v_j) is evaluated in registers with the very expression K6's final pass
+// uses, so row/column winners (and their scores) are bit-identical to running mi_sinkhorn with a P
+// buffer followed by mi_mnn_extract.  One pass over the log-scores instead of a write and two reads
+// of P.  A workgroup owns a band of NW*RW rows (a wave holds RW whole rows, 8 consecutive columns
+// per lane per 512-column chunk): row winners by a wave reduction, per-band column winners merged
+// over the waves in LDS; a second tiny kernel merges the bands.
+struct ZSourceF32 {
+  const float *z;       // (batch, n, pitch)
+  int pitch;
+  __device__ __forceinline__ void load(int b, int n, int i, int j, int m, float (&out)[8]) const {
+    const float *src = z + ((size_t)b * n + i) * pitch + j;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+    if (j < m) a = *reinterpret_cast<const float4 *>(src);             // pitch % 4 == 0
+    if (j + 4 < m) c = *reinterpret_cast<const float4 *>(src + 4);
+    out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
+    out[4] = c.x; out[5] = c.y; out[6] = c.z; out[7] = c.w;
+  }
+  __device__ __forceinline__ void begin_row(int, int, int) {}
+  __device__ __forceinline__ float col(int, int) const { return 0.0f; }
+  __device__ __forceinline__ void finish(float (&)[8], const float2 (&)[8]) const {}
+};
+
+struct ZSourceDots {
+  const uint16_t *dots;  // (batch, n, pitch) uint16 dot products
+  int pitch;
+  const float2 *row_info, *col_info;
+  float neg_inv_eps;
+  float2 ri;
+  __device__ __forceinline__ void load(int b, int n, int i, int j, int m, float (&out)[8]) const {
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if (j < m) r = *reinterpret_cast<const uint4 *>(dots + ((size_t)b * n + i) * pitch + j);   // pitch % 8 == 0
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) out[q] = (float)((q & 1) ? (w[q >> 1] >> 16) : (w[q >> 1] & 0xFFFFu));
+  }
+  __device__ __forceinline__ void begin_row(int b, int n, int i) { ri = row_info[(size_t)b * n + i]; }
+  __device__ __forceinline__ void finish(float (&x)[8], const float2 (&ci)[8]) const {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = mi_z_from_dot(x[q], ri, ci[q], neg_inv_eps);
+  }
+};
+
+template <typename SRC, int E8, int RW, int NW>
+__global__ __launch_bounds__(64 * NW) void mnn_band_kernel(SRC src, int n, int m, const float *__restrict__ u,
+                                                           const float *__restrict__ v,
+                                                           const float2 *__restrict__ col_info,
+                                                           uint64_t *__restrict__ row_best,
+                                                           uint64_t *__restrict__ col_part) {
+  constexpr int BAND = NW * RW;
+  constexpr int NC = 512 * E8;
+  __shared__ uint64_t red[NW][NC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, band = blockIdx.x, nb = gridDim.x;
+  const int row0 = band * BAND + wave * RW;
+
+  float vv[E8][8];
+  float2 ci[E8][8];
+#pragma unroll
+  for (int e = 0; e < E8; ++e)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = e * 512 + lane * 8 + q;
+      vv[e][q] = j < m ? v[(size_t)b * (m + 1) + j] : 0.0f;
+      ci[e][q] = (col_info && j < m) ? col_info[(size_t)b * m + j] : make_float2(0.f, 0.f);
+    }
+
+  float cbest[E8][8];      // per-lane column winners over this wave's rows: rows ascend, strict > keeps the first
+  int cidx[E8][8];
+#pragma unroll
+  for (int e = 0; e < E8; ++e)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { cbest[e][q] = -1.0f; cidx[e][q] = 0; }
+
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int i = row0 + r;
+    const bool live = i < n;
+    const int ic = live ? i : n - 1;
+    const float ui = u[(size_t)b * (n + 1) + ic];
+    src.begin_row(b, n, ic);
+    float rbest = -1.0f;   // per-lane row winner: columns ascend within a lane
+    int rj = 0;
+#pragma unroll
+    for (int e = 0; e < E8; ++e) {
+      float x[8];
+      src.load(b, n, ic, e * 512 + lane * 8, m, x);
+      src.finish(x, ci[e]);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = e * 512 + lane * 8 + q;
+        float p = expf((x[q] + ui) + vv[e][q]);                         // sinkhorn.py:145,206
+        p = (live && j < m) ? p : -1.0f;
+        if (p > rbest) { rbest = p; rj = j; }
+        if (p > cbest[e][q]) { cbest[e][q] = p; cidx[e][q] = i; }
+      }
+    }
+    uint64_t key = rbest >= 0.0f ? best_key(rbest, (uint32_t)rj) : 0ull;
+    key = wave_max_u64(key);
+    if (lane == 0 && live) row_best[(size_t)b * n + i] = key;
+  }
+#pragma unroll
+  for (int e = 0; e < E8; ++e)
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      red[wave][e * 512 + lane * 8 + q] = cbest[e][q] >= 0.0f ? best_key(cbest[e][q], (uint32_t)cidx[e][q]) : 0ull;
+  __syncthreads();
+  for (int c = threadIdx.x; c < NC && c < m; c += 64 * NW) {
+    uint64_t k = red[0][c];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) k = red[w][c] > k ? red[w][c] : k;
+    col_part[((size_t)b * nb + band) * m + c] = k;
+  }
+}
+
+__global__ __launch_bounds__(256) void mnn_colmerge_kernel(const uint64_t *__restrict__ col_part, int nb, int m,
+                                                           uint64_t *__restrict__ col_best) {
+  const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  uint64_t k = 0ull;
+  for (int band = 0; band < nb; ++band) {
+    const uint64_t c = col_part[((size_t)b * nb + band) * m + j];
+    k = c > k ? c : k;
+  }
+  col_best[(size_t)b * m + j] = k;
+}
+
+constexpr int DUALS_BAND = 32;     // rows per workgroup of mnn_band_kernel (8 waves x 4, or 16 x 2)
+
+struct DualsWork {
+  uint64_t *row_best, *col_best, *col_part;
+};
+size_t duals_bytes(int batch, int n, int m) {
+  return ((size_t)batch * n + (size_t)batch * m + (size_t)batch * ceil_div(n, DUALS_BAND) * m) * sizeof(uint64_t);
+}
+DualsWork duals_carve(void *workspace, int batch, int n, int m) {
+  DualsWork w;
+  w.row_best = reinterpret_cast<uint64_t *>(workspace);
+  w.col_best = w.row_best + (size_t)batch * n;
+  w.col_part = w.col_best + (size_t)batch * m;
+  return w;
+}
+
+template <typename SRC>
+int mnn_from_source(SRC src, const float2 *col_info, int batch, int n, int m, const float *u, const float *v,
+                    const float *kpts1, const float *kpts2, int max_matches, float threshold, void *workspace,
+                    size_t workspace_bytes, float *mk1, float *mk2, float *scores, uint8_t *valid, int32_t *match_ij,
+                    hipStream_t s) {
+  if (!u || !v || !kpts1 || !kpts2 || !workspace || !mk1 || !mk2 || !scores || !valid) return MI_E_NULL;
+  if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
+  if (n > MX_MAX || m > 1024 || max_matches <= 0) return MI_E_PARAM;
+  if (((uintptr_t)workspace % 8) != 0) return MI_E_ALIGN;
+  if (workspace_bytes < duals_bytes(batch, n, m)) return MI_E_CAPACITY;
+  const DualsWork w = duals_carve(workspace, batch, n, m);
+  const int nb = ceil_div(n, DUALS_BAND);
+  if (m <= 512) {
+    hipLaunchKernelGGL((mnn_band_kernel<SRC, 1, 4, 8>), dim3(nb, batch), dim3(512), 0, s, src, n, m, u, v, col_info,
+                       w.row_best, w.col_part);
+  } else {
+    hipLaunchKernelGGL((mnn_band_kernel<SRC, 2, 4, 8>), dim3(nb, batch), dim3(512), 0, s, src, n, m, u, v, col_info,
+                       w.row_best, w.col_part);
+  }
+  hipLaunchKernelGGL(mnn_colmerge_kernel, dim3(ceil_div(m, 256), batch), dim3(256), 0, s, w.col_part, nb, m,
+                     w.col_best);
+  hipLaunchKernelGGL(mnn_select_kernel, dim3(batch), dim3(MX_THREADS), 0, s, n, m, w.row_best, w.col_best, kpts1,
+                     kpts2, max_matches, threshold, mk1, mk2, scores, valid, match_ij);
+  return mi_launch_status();
+}
+
 }  // namespace
+
+extern "C" size_t mi_mnn_duals_workspace_bytes(int batch, int n, int m) {
+  if (batch <= 0 || n <= 0 || m <= 0 || m > 1024 || n > MX_MAX) return 0;
+  return duals_bytes(batch, n, m);
+}
+
+extern "C" int mi_mnn_from_duals(const float *z, int batch, int n, int m, int pitch, const float *u, const float *v,
+                                 const float *kpts1, const float *kpts2, int max_matches, float threshold,
+                                 void *workspace, size_t workspace_bytes, float *mk1, float *mk2, float *scores,
+                                 uint8_t *valid, int32_t *match_ij, mi_stream_t stream) {
+  if (!z) return MI_E_NULL;
+  if (pitch < m || pitch % 4 != 0 || ((uintptr_t)z % 16) != 0) return MI_E_ALIGN;
+  ZSourceF32 src;
+  src.z = z;
+  src.pitch = pitch;
+  return mnn_from_source(src, nullptr, batch, n, m, u, v, kpts1, kpts2, max_matches, threshold, workspace,
+                         workspace_bytes, mk1, mk2, scores, valid, match_ij, (hipStream_t)stream);
+}
+
+extern "C" int mi_mnn_from_duals_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch,
+                                      int n, int m, int pitch, double epsilon, const float *u, const float *v,
+                                      const float *kpts1, const float *kpts2, int max_matches, float threshold,
+                                      void *workspace, size_t workspace_bytes, float *mk1, float *mk2,
+                                      float *scores, uint8_t *valid, int32_t *match_ij, mi_stream_t stream) {
+  if (!dots || !row_info || !col_info) return MI_E_NULL;
+  if (pitch < m || pitch % 8 != 0 || ((uintptr_t)dots % 16) != 0) return MI_E_ALIGN;
+  if (!(epsilon > 0.0)) return MI_E_PARAM;
+  ZSourceDots src;
+  src.dots = dots;
+  src.pitch = pitch;
+  src.row_info = reinterpret_cast<const float2 *>(row_info);
+  src.col_info = reinterpret_cast<const float2 *>(col_info);
+  src.neg_inv_eps = (float)(-1.0 / epsilon);
+  src.ri = make_float2(0.f, 0.f);
+  return mnn_from_source(src, src.col_info, batch, n, m, u, v, kpts1, kpts2, max_matches, threshold, workspace,
+                         workspace_bytes, mk1, mk2, scores, valid, match_ij, (hipStream_t)stream);
+}
 
 extern "C" int mi_mnn_extract(const float *p, int batch, int n, int m, const float *kpts1, const float *kpts2,
                               int max_matches, float threshold, uint64_t *row_best, uint64_t *col_best,

@@ -15,8 +15,8 @@
 
 #include <math.h>
 
-// test hook (mi_debug_set key 4): 1 = log-domain (max, sum) band partials with two exps per element,
-// 0 = probability-form partials with one exp per element (default)
+// test hook (mi_debug_set key 4): 0 = probability-form band kernel, lean instruction stream (default);
+// 2 = the first probability-form kernel; 1 = log-domain (max, sum) band partials, two exps per element
 int mi_g_sinkhorn_log_partials = 0;
 
 namespace {
@@ -383,6 +383,182 @@ __global__ __launch_bounds__(256) void sk_vcombine_p_kernel(const float *__restr
   v[(size_t)b * (m + 1) + j] = (vold + ((j == m) ? log_n : 0.0f)) - lse;
 }
 
+// ---- probability-form band kernel, lean instruction stream (the default) -------------------------
+// Same arithmetic plan as sk_band_p_kernel.  The loop is bound by vector-instruction ISSUE on
+// gfx950 (4 cycles per wave instruction, 8 for v_exp_f32), so what matters is the instruction
+// count per matrix element:
+//   * v lives in an aligned, padded copy (vp: -inf in the padding columns, the dustbin column at
+//     index NC) so the per-lane column data are 16-byte loads and the matrix edge needs no selects
+//     (x = z + -inf = -inf); rows past n run on row n-1 and get weight 0;
+//   * the shift and the 2^x scaling are one fma: e = exp2(fma(x, log2e, -mx*log2e)); u is taken
+//     from the same shift, so the row is exactly normalised by what was summed;
+//   * 1/s and log s by v_rcp_f32 / v_log_f32 (1 ulp) instead of the IEEE expansions.
+// Per element: add, max, fma, v_exp, add, fma.
+constexpr float SK_L2E = 1.4426950408889634f, SK_LN2 = 0.6931471805599453f;
+
+template <int E4, int RW, int NW>
+__global__ __launch_bounds__(64 * NW) void sk_band_p2_kernel(const float *__restrict__ z, int n, int m, int pitch,
+                                                             float dust, const float *__restrict__ vp, int vpitch,
+                                                             float *__restrict__ u, float *__restrict__ part,
+                                                             float log_m, int v_is_zero) {
+  constexpr int BAND = NW * RW;
+  constexpr int NT = 64 * NW;
+  constexpr int NC = 256 * E4;
+  __shared__ float red[NW][NC + 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, band = blockIdx.x, nb = gridDim.x - 1;
+  const float *vb = vp + (size_t)b * vpitch;
+  float *pb = part + ((size_t)b * (nb + 1) + band) * (size_t)(m + 1);
+  const float vd = v_is_zero ? 0.0f : vb[NC];
+
+  if (band == nb) {
+    // dustbin row: u_n = log m - LSE_j(dust + v_j); its log-probabilities B_j = dust + u_n + v_j
+    float mx = dust + vd;
+    for (int j = threadIdx.x; j < m; j += NT) mx = fmaxf(mx, dust + (v_is_zero ? 0.0f : vb[j]));
+    mx = wave_max_dpp(mx);
+    if (lane == 0) red[wave][0] = mx;
+    __syncthreads();
+    mx = red[0][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w][0]);
+    float s = 0.0f;
+    for (int j = threadIdx.x; j < m; j += NT) s += expf((dust + (v_is_zero ? 0.0f : vb[j])) - mx);
+    s = wave_sum_dpp(s);
+    if (lane == 0) red[wave][1] = s;
+    __syncthreads();
+    s = red[0][1];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s += red[w][1];
+    s += expf((dust + vd) - mx);
+    const float un = log_m - (logf(s) + mx);
+    if (threadIdx.x == 0) u[(size_t)b * (n + 1) + n] = un;
+    for (int j = threadIdx.x; j < m; j += NT) pb[j] = (dust + un) + (v_is_zero ? 0.0f : vb[j]);
+    if (threadIdx.x == 0) pb[m] = (dust + un) + vd;
+    return;
+  }
+
+  float4 vv[E4];
+#pragma unroll
+  for (int e = 0; e < E4; ++e) {
+    const int j = e * 256 + lane * 4;
+    if (v_is_zero) {
+      vv[e] = make_float4(j + 0 < m ? 0.0f : -INFINITY, j + 1 < m ? 0.0f : -INFINITY, j + 2 < m ? 0.0f : -INFINITY,
+                          j + 3 < m ? 0.0f : -INFINITY);
+    } else {
+      vv[e] = *reinterpret_cast<const float4 *>(vb + j);
+    }
+  }
+  const float xd = dust + vd;
+  const int row0 = band * BAND + wave * RW;
+
+  float4 x[RW][E4];              // Z_ij, then Z_ij + v_j, then e_ij in place
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int i = min(row0 + r, n - 1);
+    const float *src = z + ((size_t)b * n + i) * pitch;
+#pragma unroll
+    for (int e = 0; e < E4; ++e) {
+      const int j = e * 256 + lane * 4;
+      x[r][e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < m) x[r][e] = *reinterpret_cast<const float4 *>(src + j);      // j + 3 < pitch (pitch % 4 == 0)
+    }
+  }
+  if (m & 3) {
+    // the float4 that straddles column m holds row padding (arbitrary bits): clear it
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+      for (int e = 0; e < E4; ++e) {
+        const int j = e * 256 + lane * 4;
+        if (j + 1 >= m) x[r][e].y = 0.0f;
+        if (j + 2 >= m) x[r][e].z = 0.0f;
+        if (j + 3 >= m) x[r][e].w = 0.0f;
+      }
+  }
+
+  float4 colsum[E4];
+#pragma unroll
+  for (int e = 0; e < E4; ++e) colsum[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dustcol = 0.0f;          // sum of P_i,dustbin over this wave's rows (wave-uniform)
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    float mx = xd;
+#pragma unroll
+    for (int e = 0; e < E4; ++e) {
+      x[r][e].x += vv[e].x;
+      x[r][e].y += vv[e].y;
+      x[r][e].z += vv[e].z;
+      x[r][e].w += vv[e].w;
+      mx = fmaxf(fmaxf(mx, x[r][e].x), fmaxf(x[r][e].y, fmaxf(x[r][e].z, x[r][e].w)));
+    }
+    mx = wave_max_dpp(mx);
+    const float nm = -(mx * SK_L2E);
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < E4; ++e) {
+      x[r][e].x = __builtin_amdgcn_exp2f(__builtin_fmaf(x[r][e].x, SK_L2E, nm));   // exp2(-inf) = 0 outside
+      x[r][e].y = __builtin_amdgcn_exp2f(__builtin_fmaf(x[r][e].y, SK_L2E, nm));
+      x[r][e].z = __builtin_amdgcn_exp2f(__builtin_fmaf(x[r][e].z, SK_L2E, nm));
+      x[r][e].w = __builtin_amdgcn_exp2f(__builtin_fmaf(x[r][e].w, SK_L2E, nm));
+      s += (x[r][e].x + x[r][e].y) + (x[r][e].z + x[r][e].w);
+    }
+    const float ed = __builtin_amdgcn_exp2f(__builtin_fmaf(xd, SK_L2E, nm));       // dustbin column entry
+    s = wave_sum_dpp(s) + ed;
+    const bool live = row0 + r < n;
+    if (lane == 0 && live)                                                          // sinkhorn.py:139
+      u[(size_t)b * (n + 1) + row0 + r] = (nm - __builtin_amdgcn_logf(s)) * SK_LN2;
+    const float wgt = live ? __builtin_amdgcn_rcpf(s) : 0.0f;
+#pragma unroll
+    for (int e = 0; e < E4; ++e) {
+      colsum[e].x = __builtin_fmaf(x[r][e].x, wgt, colsum[e].x);                    // += P_ij
+      colsum[e].y = __builtin_fmaf(x[r][e].y, wgt, colsum[e].y);
+      colsum[e].z = __builtin_fmaf(x[r][e].z, wgt, colsum[e].z);
+      colsum[e].w = __builtin_fmaf(x[r][e].w, wgt, colsum[e].w);
+    }
+    dustcol = __builtin_fmaf(ed, wgt, dustcol);
+  }
+#pragma unroll
+  for (int e = 0; e < E4; ++e) *reinterpret_cast<float4 *>(&red[wave][e * 256 + lane * 4]) = colsum[e];
+  if (lane == 0) red[wave][NC] = dustcol;
+  __syncthreads();
+  for (int c = threadIdx.x; c <= NC; c += NT) {
+    const int j = (c == NC) ? m : c;
+    if (c < NC && j >= m) continue;
+    float t = red[0][c];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += red[w][c];
+    pb[j] = t;
+  }
+}
+
+// v_j <- v_j + log nu_j - log(sum of the bands' P_ij + exp(B_j)); writes the caller's v (pitch m+1)
+// and the padded copy the band kernel reads (columns m..NC-1 = -inf, dustbin column at NC)
+__global__ __launch_bounds__(256) void sk_vcombine_p2_kernel(const float *__restrict__ part, int m, int nparts,
+                                                             float *__restrict__ v, float *__restrict__ vp,
+                                                             int vpitch, int nc, float log_n, int v_is_zero) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c > nc) return;
+  float *vpb = vp + (size_t)b * vpitch;
+  if (c >= m && c < nc) {
+    vpb[c] = -INFINITY;
+    return;
+  }
+  const int j = (c == nc) ? m : c;
+  const float *p = part + (size_t)b * nparts * (size_t)(m + 1) + j;
+  float s = 0.0f;
+  for (int k = 0; k < nparts - 1; ++k) s += p[(size_t)k * (m + 1)];
+  const float bj = p[(size_t)(nparts - 1) * (m + 1)];
+  // log(s + exp(bj)) as a two-term log-sum-exp; s == 0 (everything underflowed) leaves bj
+  const float a = s > 0.0f ? logf(s) : -INFINITY;
+  const float hi = fmaxf(a, bj), lo = fminf(a, bj);
+  const float lse = hi + log1pf(expf(lo - hi));
+  const float vold = v_is_zero ? 0.0f : vpb[c];
+  const float vnew = (vold + ((j == m) ? log_n : 0.0f)) - lse;
+  vpb[c] = vnew;
+  v[(size_t)b * (m + 1) + j] = vnew;
+}
+
 // ---- fused iteration: Z is read ONCE per iteration ----------------------------------------------
 // A workgroup owns a band of 4*RW rows.  Each wave keeps RW whole rows of Z in registers
 // (RW * E4 float4 per lane, all loads issued up front), computes u for them (row pass), and
@@ -545,11 +721,18 @@ __global__ __launch_bounds__(256) void sk_vcombine_kernel(const float2 *__restri
 
 template <int E4, int RW, int NW>
 void launch_fused(const float *z, int batch, int n, int m, int pitch, float dust, int iterations, float *u,
-                  float *v, float2 *part, float log_m, float log_n, hipStream_t s) {
+                  float *v, float2 *part, float *vp, float log_m, float log_n, hipStream_t s) {
   const int nb = ceil_div(n, NW * RW);
+  constexpr int NC = 256 * E4;
   for (int it = 0; it < iterations; ++it) {
     const int vz = it == 0 ? 1 : 0;
-    if (mi_g_sinkhorn_log_partials) {
+    if (mi_g_sinkhorn_log_partials == 0) {
+      float *pf = reinterpret_cast<float *>(part);
+      hipLaunchKernelGGL((sk_band_p2_kernel<E4, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, z, n, m, pitch,
+                         dust, vp, NC + 4, u, pf, log_m, vz);
+      hipLaunchKernelGGL(sk_vcombine_p2_kernel, dim3(ceil_div(NC + 1, 256), batch), dim3(256), 0, s, pf, m, nb + 1, v,
+                         vp, NC + 4, NC, log_n, vz);
+    } else if (mi_g_sinkhorn_log_partials == 1) {
       hipLaunchKernelGGL((sk_band_kernel<E4, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, z, n, m, pitch, dust,
                          v, u, part, log_m, vz);
       hipLaunchKernelGGL(sk_vcombine_kernel, dim3(ceil_div(m + 1, 256), batch), dim3(256), 0, s, part, m, nb + 1,
@@ -571,12 +754,18 @@ int fused_rows_per_band(int m) {
   return 0;  // not supported by the fused kernels
 }
 
+// band partials (float2 per column per band), then the padded copy of v (256*E4 + 4 floats per matrix)
+size_t partials_bytes(int batch, int n, int m, int band) {
+  const size_t b = (size_t)batch * (size_t)(ceil_div(n, band) + 1) * (size_t)(m + 1) * sizeof(float2);
+  return (b + 15) & ~(size_t)15;
+}
+
 }  // namespace
 
 extern "C" size_t mi_sinkhorn_workspace_bytes(int batch, int n, int m) {
   const int band = fused_rows_per_band(m);
   if (batch <= 0 || n <= 0 || m <= 0 || band == 0) return 0;
-  return (size_t)batch * (size_t)(ceil_div(n, band) + 1) * (size_t)(m + 1) * sizeof(float2);
+  return partials_bytes(batch, n, m, band) + (size_t)batch * (size_t)(256 * ceil_div(m, 256) + 4) * sizeof(float);
 }
 
 extern "C" int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, float dustbin_logscore,
@@ -589,13 +778,15 @@ extern "C" int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, f
   hipStream_t s = (hipStream_t)stream;
   const float log_m = logf((float)m), log_n = logf((float)n);      // sinkhorn.py:197-198
   const size_t need = mi_sinkhorn_workspace_bytes(batch, n, m);
-  if (need > 0 && workspace && ((uintptr_t)workspace % 8) == 0) {
+  if (need > 0 && workspace && ((uintptr_t)workspace % 16) == 0) {
     if (workspace_bytes < need) return MI_E_CAPACITY;
     float2 *part = reinterpret_cast<float2 *>(workspace);
+    float *vp = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) +
+                                          partials_bytes(batch, n, m, fused_rows_per_band(m)));
     const int e4 = ceil_div(m, 256);
-    if (e4 == 1) launch_fused<1, 4, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, log_m, log_n, s);
-    else if (e4 == 2) launch_fused<2, 4, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, log_m, log_n, s);
-    else launch_fused<4, 2, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, log_m, log_n, s);
+    if (e4 == 1) launch_fused<1, 4, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, vp, log_m, log_n, s);
+    else if (e4 == 2) launch_fused<2, 4, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, vp, log_m, log_n, s);
+    else launch_fused<4, 2, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, vp, log_m, log_n, s);
     if (p) {
       hipLaunchKernelGGL(sk_exp_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, z, n, m, pitch,
                          dustbin_logscore, u, v, p);

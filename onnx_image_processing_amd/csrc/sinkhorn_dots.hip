@@ -5,8 +5,8 @@
 // K5 stores dot(a_i, b_j) = popcount(a_i & b_j) as uint16 (exact) plus one (scale, squared norm)
 // pair per descriptor.  Every pass rebuilds
 //     z_ij = -max((|a_i|^2 + |b_j|^2) - 2 * dot_ij * (s_i * s_j), 0) * (1/epsilon)
-// in registers, so an iteration streams 2 bytes per matrix element instead of 4.  z here differs
-// from the fp32 path only in the last rounding (multiply by 1/epsilon instead of divide: <= 1 ulp).
+// in registers, so an iteration streams 2 bytes per matrix element instead of 4.  z is evaluated in
+// the factored form c_i + d_j + dot*t_j*g_i (no clamp), a few ulp of |z| from the fp32 path.
 // The iteration is the probability-form band kernel of sinkhorn.hip (one exp per element: the
 // row pass leaves P_ij = e_ij / s_i in registers, the column update is v_j += log nu_j -
 // log(sum_i P_ij), the dustbin row is merged in the log domain).
@@ -24,9 +24,7 @@ struct ZParams {
 };
 
 __device__ __forceinline__ float z_of(float dot, float2 row, float2 col, float neg_inv_eps) {
-  const float cross = dot * (row.x * col.x);
-  const float cost = fmaxf((row.y + col.y) - 2.0f * cross, 0.0f);    // sinkhorn.py:101-103
-  return cost * neg_inv_eps;                                         // sinkhorn.py:178
+  return mi_z_from_dot(dot, row, col, neg_inv_eps);
 }
 
 // E8 = 16-byte (8 x uint16) loads per lane per row: covers m <= 512 * E8 columns.
@@ -36,7 +34,8 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
                                                                const float2 *__restrict__ col_info, ZParams zp,
                                                                const float *__restrict__ v, float *__restrict__ u,
                                                                float *__restrict__ part, float log_m,
-                                                               int v_is_zero) {
+                                                               int v_is_zero, const float *__restrict__ wp,
+                                                               const float *__restrict__ tp, int cpitch) {
   constexpr int BAND = NW * RW;   // NW waves x RW rows each
   constexpr int NT = 64 * NW;
   constexpr int NC = 512 * E8;    // columns covered by one wave
@@ -73,18 +72,28 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
     return;
   }
 
-  // per-lane column data: v_j and the column descriptor's (scale, norm)
-  float vv[E8][8];
-  float2 ci[E8][8];
+  // z_ij = -cost_ij/eps splits into a row constant, a column constant and one product:
+  //     z_ij = c_i + nie*nb_j + dot_ij * t_j * g_i,   c_i = nie*na_i,  g_i = -2*nie*sa_i,  t_j = sb_j
+  // (nie = -1/eps; the reference's clamp of the cost at 0 only acts on rounding noise of identical
+  // descriptors, |z| <= 1e-6/eps there).  The row constant shifts a row's log-sum-exp without changing
+  // its probabilities, so the element loop is convert, multiply, fma on top of the fp32 kernel's
+  // work; c_i re-enters in u_i and in the dustbin-column entry.
+  // per-column data come from aligned, padded arrays (16-byte loads): tp = t_j (0 in the padding),
+  // wp = nie*nb_j + v_j (-inf in the padding: no contribution anywhere), rebuilt by the combine kernel
+  float tq[E8][8], wq[E8][8];
 #pragma unroll
-  for (int e = 0; e < E8; ++e)
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int j = e * 512 + lane * 8 + q;
-      vv[e][q] = (j < m && !v_is_zero) ? vb[j] : 0.0f;
-      ci[e][q] = (j < m) ? col_info[(size_t)b * m + j] : make_float2(0.f, 0.f);
-    }
-  const float xd = dust + vd;
+  for (int e = 0; e < E8; ++e) {
+    const int j = e * 512 + lane * 8;
+    const float4 t0 = *reinterpret_cast<const float4 *>(tp + (size_t)b * cpitch + j);
+    const float4 t1 = *reinterpret_cast<const float4 *>(tp + (size_t)b * cpitch + j + 4);
+    const float4 w0 = *reinterpret_cast<const float4 *>(wp + (size_t)b * cpitch + j);
+    const float4 w1 = *reinterpret_cast<const float4 *>(wp + (size_t)b * cpitch + j + 4);
+    tq[e][0] = t0.x; tq[e][1] = t0.y; tq[e][2] = t0.z; tq[e][3] = t0.w;
+    tq[e][4] = t1.x; tq[e][5] = t1.y; tq[e][6] = t1.z; tq[e][7] = t1.w;
+    wq[e][0] = w0.x; wq[e][1] = w0.y; wq[e][2] = w0.z; wq[e][3] = w0.w;
+    wq[e][4] = w1.x; wq[e][5] = w1.y; wq[e][6] = w1.z; wq[e][7] = w1.w;
+  }
+  const float xd0 = dust + vd;
   const int row0 = band * BAND + wave * RW;
 
   uint4 raw[RW][E8];
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
     for (int e = 0; e < E8; ++e) {
       const int j = e * 512 + lane * 8;
       raw[r][e] = make_uint4(0u, 0u, 0u, 0u);
-      if (i < n && j < m) raw[r][e] = *reinterpret_cast<const uint4 *>(src + j);   // pitch >= round_up(m,8)
+      if (j < m) raw[r][e] = *reinterpret_cast<const uint4 *>(src + j);   // pitch >= round_up(m,8)
     }
   }
 
@@ -109,19 +118,19 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
     const int i = row0 + r;
-    const bool live = i < n;
+    const bool live = i < n;     // rows past n run on row 0's data and are given weight 0
     const float2 ri = row_info[(size_t)b * n + (live ? i : 0)];                    // wave-uniform
-    float x[E8][8];              // Z_ij + v_j, then e_ij in place
+    const float gi = -2.0f * zp.neg_inv_eps * ri.x, ci = ri.y * zp.neg_inv_eps;
+    const float xd = xd0 - ci;
+    float x[E8][8];              // (z_ij - c_i) + v_j, then e_ij in place
     float mx = xd;
 #pragma unroll
     for (int e = 0; e < E8; ++e) {
       const uint32_t w4[4] = {raw[r][e].x, raw[r][e].y, raw[r][e].z, raw[r][e].w};
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int j = e * 512 + lane * 8 + q;
         const float dot = (float)((q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu));
-        // outside the matrix (row padding, rows past n): -inf, i.e. no contribution anywhere
-        x[e][q] = (live && j < m) ? z_of(dot, ri, ci[e][q], zp.neg_inv_eps) + vv[e][q] : -INFINITY;
+        x[e][q] = __builtin_fmaf(dot * tq[e][q], gi, wq[e][q]);
         mx = fmaxf(mx, x[e][q]);
       }
     }
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
     const float ed = expf(xd - mx);                  // dustbin column entry of this row
     s = wave_sum_dpp(s) + ed;
     const float inv_s = 1.0f / s;
-    if (lane == 0 && live) u[(size_t)b * (n + 1) + i] = 0.0f - (logf(s) + mx);     // sinkhorn.py:139
+    if (lane == 0 && live) u[(size_t)b * (n + 1) + i] = (0.0f - (logf(s) + mx)) - ci;   // sinkhorn.py:139
     const float wgt = live ? inv_s : 0.0f;
 #pragma unroll
     for (int e = 0; e < E8; ++e)
@@ -164,7 +173,9 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
 // v_j <- v_j + log nu_j - log(sum of the bands' P_ij + exp(B_j))   (B_j: dustbin row, log domain)
 __global__ __launch_bounds__(256) void sk_vcombine_dots_kernel(const float *__restrict__ part, int m, int nparts,
                                                                float *__restrict__ v, float log_n,
-                                                               int v_is_zero) {
+                                                               int v_is_zero, const float2 *__restrict__ col_info,
+                                                               float neg_inv_eps, float *__restrict__ wp,
+                                                               int cpitch) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j > m) return;
@@ -176,7 +187,21 @@ __global__ __launch_bounds__(256) void sk_vcombine_dots_kernel(const float *__re
   const float hi = fmaxf(a, bj), lo = fminf(a, bj);
   const float lse = hi + log1pf(expf(lo - hi));
   const float vold = v_is_zero ? 0.0f : v[(size_t)b * (m + 1) + j];
-  v[(size_t)b * (m + 1) + j] = (vold + ((j == m) ? log_n : 0.0f)) - lse;
+  const float vnew = (vold + ((j == m) ? log_n : 0.0f)) - lse;
+  v[(size_t)b * (m + 1) + j] = vnew;
+  if (j < m) wp[(size_t)b * cpitch + j] = col_info[(size_t)b * m + j].y * neg_inv_eps + vnew;
+}
+
+// first-iteration column data: tp = column scale, wp = nie * squared norm (v = 0); padding 0 / -inf
+__global__ __launch_bounds__(256) void sk_dots_init_kernel(const float2 *__restrict__ col_info, int m, int cpitch,
+                                                           float neg_inv_eps, float *__restrict__ wp,
+                                                           float *__restrict__ tp) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= cpitch) return;
+  const float2 c = (j < m) ? col_info[(size_t)b * m + j] : make_float2(0.0f, 0.0f);
+  tp[(size_t)b * cpitch + j] = c.x;
+  wp[(size_t)b * cpitch + j] = (j < m) ? c.y * neg_inv_eps : -INFINITY;
 }
 
 // P = exp(Z + u + v) over the augmented matrix; one wave per row
@@ -203,26 +228,36 @@ __global__ __launch_bounds__(256) void sk_exp_dots_kernel(const uint16_t *__rest
 
 template <int E8, int RW, int NW>
 void launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int batch, int n, int m, int pitch,
-                 ZParams zp, int iterations, float *u, float *v, float *part, float log_m, float log_n,
-                 hipStream_t s) {
+                 ZParams zp, int iterations, float *u, float *v, float *part, float *wp, float *tp, float log_m,
+                 float log_n, hipStream_t s) {
   const int nb = ceil_div(n, NW * RW);
+  constexpr int CP = 512 * E8;    // padded column count of wp / tp
+  hipLaunchKernelGGL(sk_dots_init_kernel, dim3(ceil_div(CP, 256), batch), dim3(256), 0, s, ci, m, CP, zp.neg_inv_eps,
+                     wp, tp);
   for (int it = 0; it < iterations; ++it) {
     const int vz = it == 0 ? 1 : 0;
     hipLaunchKernelGGL((sk_band_dots_kernel<E8, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, dots, n, m, pitch,
-                       ri, ci, zp, v, u, part, log_m, vz);
+                       ri, ci, zp, v, u, part, log_m, vz, wp, tp, CP);
     hipLaunchKernelGGL(sk_vcombine_dots_kernel, dim3(ceil_div(m + 1, 256), batch), dim3(256), 0, s, part, m, nb + 1,
-                       v, log_n, vz);
+                       v, log_n, vz, ci, zp.neg_inv_eps, wp, CP);
   }
 }
 
 int dots_rows_per_band(int m) { return m <= 512 ? 32 : (m <= 1024 ? 16 : 0); }
+
+// band partials (one float per column per band), then the padded per-column arrays wp and tp
+size_t dots_partials_bytes(int batch, int n, int m, int band) {
+  const size_t b = (size_t)batch * (size_t)(ceil_div(n, band) + 1) * (size_t)(m + 1) * sizeof(float);
+  return (b + 15) & ~(size_t)15;
+}
+int dots_cpitch(int m) { return m <= 512 ? 512 : 1024; }
 
 }  // namespace
 
 extern "C" size_t mi_sinkhorn_dots_workspace_bytes(int batch, int n, int m) {
   const int band = dots_rows_per_band(m);
   if (batch <= 0 || n <= 0 || m <= 0 || band == 0) return 0;
-  return (size_t)batch * (size_t)(ceil_div(n, band) + 1) * (size_t)(m + 1) * sizeof(float);
+  return dots_partials_bytes(batch, n, m, band) + 2 * (size_t)batch * dots_cpitch(m) * sizeof(float);
 }
 
 extern "C" int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch,
@@ -231,7 +266,7 @@ extern "C" int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, con
                                 mi_stream_t stream) {
   if (!dots || !row_info || !col_info || !u || !v || !workspace) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
-  if (pitch < m || pitch % 8 != 0 || ((uintptr_t)dots % 16) != 0 || ((uintptr_t)workspace % 8) != 0) return MI_E_ALIGN;
+  if (pitch < m || pitch % 8 != 0 || ((uintptr_t)dots % 16) != 0 || ((uintptr_t)workspace % 16) != 0) return MI_E_ALIGN;
   if (iterations <= 0 || !(epsilon > 0.0)) return MI_E_PARAM;
   const size_t need = mi_sinkhorn_dots_workspace_bytes(batch, n, m);
   if (need == 0) return MI_E_PARAM;                 // m > 1024: use the fp32 form
@@ -244,8 +279,11 @@ extern "C" int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, con
   const float2 *ri = reinterpret_cast<const float2 *>(row_info);
   const float2 *ci = reinterpret_cast<const float2 *>(col_info);
   float *part = reinterpret_cast<float *>(workspace);
-  if (m <= 512) launch_dots<1, 4, 8>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, log_m, log_n, s);
-  else launch_dots<2, 2, 8>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, log_m, log_n, s);
+  float *wp = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) +
+                                        dots_partials_bytes(batch, n, m, dots_rows_per_band(m)));
+  float *tp = wp + (size_t)batch * dots_cpitch(m);
+  if (m <= 512) launch_dots<1, 4, 8>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, wp, tp, log_m, log_n, s);
+  else launch_dots<2, 2, 8>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, wp, tp, log_m, log_n, s);
   if (p) {
     hipLaunchKernelGGL(sk_exp_dots_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, dots, n, m, pitch, ri, ci,
                        zp, u, v, p);

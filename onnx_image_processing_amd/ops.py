@@ -221,28 +221,36 @@ def cost_logscores_f32(desc1: torch.Tensor, desc2: torch.Tensor, distance: int, 
 
 
 def sinkhorn(z: torch.Tensor, m: int, pitch: int, dustbin_logscore: float, iterations: int,
-             return_duals: bool = False, use_workspace: bool = True):
+             return_duals: bool = False, use_workspace: bool = True, want_p: bool = True):
+    """want_p=False: duals only (P is not written); returns (None, u, v)."""
     b, n, _ = z.shape
     u = torch.empty((b, n + 1), dtype=F32, device=z.device)
     v = torch.empty((b, m + 1), dtype=F32, device=z.device)
-    p = torch.empty((b, n + 1, m + 1), dtype=F32, device=z.device)
+    p = torch.empty((b, n + 1, m + 1), dtype=F32, device=z.device) if want_p else None
     wbytes = int(N.load().mi_sinkhorn_workspace_bytes(b, n, m))
     work = torch.empty((max(wbytes, 8) // 8,), dtype=torch.int64, device=z.device) if use_workspace else None
     N.call("mi_sinkhorn", N.dev(z, F32, "z"), b, n, m, pitch, float(dustbin_logscore), int(iterations),
-           u.data_ptr(), v.data_ptr(), p.data_ptr(), work.data_ptr() if work is not None else None,
-           wbytes if work is not None else 0, N.stream_ptr())
-    return (p, u, v) if return_duals else p
+           u.data_ptr(), v.data_ptr(), p.data_ptr() if p is not None else None,
+           work.data_ptr() if work is not None else None, wbytes if work is not None else 0, N.stream_ptr())
+    return (p, u, v) if (return_duals or not want_p) else p
+
+
+def dots_supported(b: int, n: int, m: int) -> bool:
+    return int(N.load().mi_sinkhorn_dots_workspace_bytes(b, n, m)) > 0
 
 
 def sinkhorn_bits(bits1: torch.Tensor, bits2: torch.Tensor, normalized: bool, epsilon: float, unused_score: float,
-                  iterations: int, return_duals: bool = False):
-    """Cost + Sinkhorn for packed hard-bit descriptors (B,N,D/32),(B,M,D/32) int32 -> P (B,N+1,M+1).
-    M <= 1024: the uint16 dot-product form (half the bytes per iteration); larger M: fp32 Z form."""
+                  iterations: int, return_duals: bool = False, want_p: bool = True, return_state: bool = False):
+    """Cost + Sinkhorn for packed hard-bit descriptors (B,N,D/32),(B,M,D/32) int32 -> P (B,N+1,M+1),
+    uint16 dot-product form (M <= 1024; half the bytes per iteration).  return_state: also the
+    (dots, row_info, col_info, pitch) the duals refer to (for mnn_from_duals_dots)."""
     b, n, words = bits1.shape
     m = bits2.shape[1]
     dev = bits1.device
     wbytes = int(N.load().mi_sinkhorn_dots_workspace_bytes(b, n, m))
     if wbytes == 0:
+        if return_state or not want_p:
+            raise RuntimeError(f"the dot-product Sinkhorn form supports M <= 1024, got M = {m}")
         z, pitch = cost_logscores_bits(bits1, bits2, normalized, epsilon)
         return sinkhorn(z, m, pitch, -unused_score / epsilon, iterations, return_duals=return_duals)
     pitch = (m + 7) // 8 * 8
@@ -254,12 +262,14 @@ def sinkhorn_bits(bits1: torch.Tensor, bits2: torch.Tensor, normalized: bool, ep
            N.stream_ptr())
     u = torch.empty((b, n + 1), dtype=F32, device=dev)
     v = torch.empty((b, m + 1), dtype=F32, device=dev)
-    p = torch.empty((b, n + 1, m + 1), dtype=F32, device=dev)
+    p = torch.empty((b, n + 1, m + 1), dtype=F32, device=dev) if want_p else None
     work = torch.empty(((wbytes + 7) // 8,), dtype=torch.int64, device=dev)
     N.call("mi_sinkhorn_dots", dots.data_ptr(), row_info.data_ptr(), col_info.data_ptr(), b, n, m, pitch,
-           float(epsilon), float(unused_score), int(iterations), u.data_ptr(), v.data_ptr(), p.data_ptr(),
-           work.data_ptr(), wbytes, N.stream_ptr())
-    return (p, u, v) if return_duals else p
+           float(epsilon), float(unused_score), int(iterations), u.data_ptr(), v.data_ptr(),
+           p.data_ptr() if p is not None else None, work.data_ptr(), wbytes, N.stream_ptr())
+    if return_state:
+        return p, u, v, (dots, row_info, col_info, pitch)
+    return (p, u, v) if (return_duals or not want_p) else p
 
 
 def match_filters(p: torch.Tensor, ratio_threshold: float, dustbin_margin: float):
@@ -291,6 +301,52 @@ def mnn_extract(p: torch.Tensor, kpts1: torch.Tensor, kpts2: torch.Tensor, max_m
     ij = torch.empty((b, max_matches, 2), dtype=torch.int32, device=dev)
     N.call("mi_mnn_extract", N.dev(pp, F32, "P"), b, n, m, N.dev(k1, F32, "keypoints1"), N.dev(k2, F32, "keypoints2"),
            int(max_matches), float(threshold), row_best.data_ptr(), col_best.data_ptr(), mk1.data_ptr(),
+           mk2.data_ptr(), sc.data_ptr(), valid.data_ptr(), ij.data_ptr(), N.stream_ptr())
+    out = (mk1, mk2, sc, valid.bool())
+    return out + (ij,) if return_indices else out
+
+
+def _mnn_outputs(b, max_matches, dev):
+    return (torch.empty((b, max_matches, 2), dtype=F32, device=dev), torch.empty((b, max_matches, 2), dtype=F32, device=dev),
+            torch.empty((b, max_matches), dtype=F32, device=dev), torch.empty((b, max_matches), dtype=torch.uint8, device=dev),
+            torch.empty((b, max_matches, 2), dtype=torch.int32, device=dev))
+
+
+def mnn_duals_supported(b: int, n: int, m: int) -> bool:
+    return int(N.load().mi_mnn_duals_workspace_bytes(b, n, m)) > 0
+
+
+def mnn_from_duals(z: torch.Tensor, m: int, pitch: int, u: torch.Tensor, v: torch.Tensor, kpts1: torch.Tensor,
+                   kpts2: torch.Tensor, max_matches: int, threshold: float, return_indices: bool = False):
+    """mnn_extract(P) with P = exp(Z + u + v) evaluated on the fly (P never written)."""
+    b, n, _ = z.shape
+    k1, k2 = kpts1.float().contiguous(), kpts2.float().contiguous()
+    wbytes = int(N.load().mi_mnn_duals_workspace_bytes(b, n, m))
+    if wbytes == 0:
+        raise RuntimeError(f"mnn_from_duals supports N <= 4096 and M <= 1024, got ({n}, {m})")
+    work = torch.empty((wbytes // 8,), dtype=torch.int64, device=z.device)
+    mk1, mk2, sc, valid, ij = _mnn_outputs(b, max_matches, z.device)
+    N.call("mi_mnn_from_duals", N.dev(z, F32, "z"), b, n, m, pitch, N.dev(u, F32, "u"), N.dev(v, F32, "v"),
+           N.dev(k1, F32, "keypoints1"), N.dev(k2, F32, "keypoints2"), int(max_matches), float(threshold),
+           work.data_ptr(), wbytes, mk1.data_ptr(), mk2.data_ptr(), sc.data_ptr(), valid.data_ptr(), ij.data_ptr(),
+           N.stream_ptr())
+    out = (mk1, mk2, sc, valid.bool())
+    return out + (ij,) if return_indices else out
+
+
+def mnn_from_duals_dots(state, m: int, epsilon: float, u: torch.Tensor, v: torch.Tensor, kpts1: torch.Tensor,
+                        kpts2: torch.Tensor, max_matches: int, threshold: float, return_indices: bool = False):
+    dots, row_info, col_info, pitch = state
+    b, n, _ = dots.shape
+    k1, k2 = kpts1.float().contiguous(), kpts2.float().contiguous()
+    wbytes = int(N.load().mi_mnn_duals_workspace_bytes(b, n, m))
+    if wbytes == 0:
+        raise RuntimeError(f"mnn_from_duals_dots supports N <= 4096 and M <= 1024, got ({n}, {m})")
+    work = torch.empty((wbytes // 8,), dtype=torch.int64, device=dots.device)
+    mk1, mk2, sc, valid, ij = _mnn_outputs(b, max_matches, dots.device)
+    N.call("mi_mnn_from_duals_dots", dots.data_ptr(), row_info.data_ptr(), col_info.data_ptr(), b, n, m, pitch,
+           float(epsilon), N.dev(u, F32, "u"), N.dev(v, F32, "v"), N.dev(k1, F32, "keypoints1"),
+           N.dev(k2, F32, "keypoints2"), int(max_matches), float(threshold), work.data_ptr(), wbytes, mk1.data_ptr(),
            mk2.data_ptr(), sc.data_ptr(), valid.data_ptr(), ij.data_ptr(), N.stream_ptr())
     out = (mk1, mk2, sc, valid.bool())
     return out + (ij,) if return_indices else out

@@ -67,6 +67,17 @@ class ShiTomasiAngleSparseBADSinkhornMatcher(_AngleMatcherBase):
     def forward(self, image1: torch.Tensor, image2: torch.Tensor):
         return self._match(image1, image2)
 
+    @torch.no_grad()
+    def match_solution(self, image1: torch.Tensor, image2: torch.Tensor):
+        """forward() up to the Sinkhorn duals (see MatchExtractionWrapper)."""
+        if image1.shape != image2.shape:
+            raise RuntimeError(f"image shapes differ: {tuple(image1.shape)} vs {tuple(image2.shape)}")
+        k1, d1, packed = self._detect_describe(image1)
+        k2, d2, _ = self._detect_describe(image2)
+        if packed:
+            return k1, k2, self.matcher.solve_bits(d1, d2, self.descriptor.normalize_descriptors)
+        return k1, k2, self.matcher.solve(d1, d2)
+
 
 class ShiTomasiAngleSparseBADSinkhornMatcherWithFilters(_AngleMatcherBase):
     """forward(image1, image2) -> (keypoints1, keypoints2, matching_probs, valid_mask (B,K) bool)

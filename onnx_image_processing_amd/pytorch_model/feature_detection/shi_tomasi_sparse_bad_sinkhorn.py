@@ -62,8 +62,7 @@ class ShiTomasiSparseBADSinkhornMatcher(nn.Module):
             distance_type=distance_type,
         )
 
-    @torch.no_grad()
-    def forward(self, image1: torch.Tensor, image2: torch.Tensor):
+    def _detect_describe(self, image1: torch.Tensor, image2: torch.Tensor):
         if image1.shape != image2.shape:
             raise RuntimeError(f"image shapes differ: {tuple(image1.shape)} vs {tuple(image2.shape)}")
         packed = self.descriptor.mode == N.MI_BAD_HARD and self.matcher.distance_type == "l2"
@@ -75,8 +74,24 @@ class ShiTomasiSparseBADSinkhornMatcher(nn.Module):
             del scores
             kpts.append(kp)
             descs.append(self.descriptor.forward_bits(image, kp) if packed else self.descriptor(image, kp))
+        return kpts, descs, packed
+
+    @torch.no_grad()
+    def forward(self, image1: torch.Tensor, image2: torch.Tensor):
+        kpts, descs, packed = self._detect_describe(image1, image2)
         if packed:
             probs = self.matcher.forward_bits(descs[0], descs[1], self.descriptor.normalize_descriptors)
         else:
             probs = self.matcher(descs[0], descs[1])
         return kpts[0], kpts[1], probs
+
+    @torch.no_grad()
+    def match_solution(self, image1: torch.Tensor, image2: torch.Tensor):
+        """forward() up to the Sinkhorn duals: (keypoints1, keypoints2, SinkhornSolution).  Used by
+        MatchExtractionWrapper, which only needs the mutual matches, so P is never written."""
+        kpts, descs, packed = self._detect_describe(image1, image2)
+        if packed:
+            sol = self.matcher.solve_bits(descs[0], descs[1], self.descriptor.normalize_descriptors)
+        else:
+            sol = self.matcher.solve(descs[0], descs[1])
+        return kpts[0], kpts[1], sol

@@ -6,6 +6,24 @@ from ... import _native as N
 from ... import ops
 
 
+class SinkhornSolution:
+    """Result of a Sinkhorn solve kept as duals: P = exp(Z + u + v) is defined by the log-score
+    source (fp32 Z, or uint16 dot products + per-descriptor scale/norm) and the duals u, v, all
+    resident on the GPU.  `mutual_matches` is MutualNearestNeighborMatcher.forward on that P
+    without writing it (bit-identical to forward() + the extractor)."""
+
+    def __init__(self, kind: str, source, m: int, pitch: int, epsilon: float, u: torch.Tensor, v: torch.Tensor):
+        self.kind, self.source, self.m, self.pitch, self.epsilon, self.u, self.v = kind, source, m, pitch, epsilon, u, v
+
+    def mutual_matches(self, keypoints1: torch.Tensor, keypoints2: torch.Tensor, max_matches: int, threshold: float,
+                       return_indices: bool = False):
+        if self.kind == "dots":
+            return ops.mnn_from_duals_dots(self.source, self.m, self.epsilon, self.u, self.v, keypoints1, keypoints2,
+                                           max_matches, threshold, return_indices)
+        return ops.mnn_from_duals(self.source, self.m, self.pitch, self.u, self.v, keypoints1, keypoints2,
+                                  max_matches, threshold, return_indices)
+
+
 class SinkhornMatcher(nn.Module):
     """Log-space Sinkhorn assignment with dustbins.
 
@@ -28,10 +46,10 @@ class SinkhornMatcher(nn.Module):
         self.distance_type = distance_type.lower()
         if self.distance_type not in ("l1", "l2"):
             raise ValueError(f"distance_type must be 'l1' or 'l2', got {distance_type}")
-        # forward_bits only: keep the K x K dot products as uint16 and rebuild Z every pass (half the
-        # bytes per iteration, more arithmetic).  Measured slower than the fp32-Z form on MI355X at
-        # K = 512 (the iteration is not bandwidth-bound there), so it is off by default.
-        self.use_dot_storage = False
+        # forward_bits / solve_bits: keep the K x K dot products as uint16 and rebuild Z in registers
+        # every pass (half the bytes per iteration; the fp32-Z iteration is HBM-bound on MI355X).
+        # Applies to M <= 1024; larger problems use the fp32-Z form.
+        self.use_dot_storage = True
 
     @property
     def dustbin_logscore(self) -> float:
@@ -49,10 +67,31 @@ class SinkhornMatcher(nn.Module):
         the dot products become exact integer popcounts (i8 MFMA).  L2 only."""
         if self.distance_type != "l2":
             raise RuntimeError("forward_bits implements the l2 cost only")
-        if self.use_dot_storage:
+        if self.use_dot_storage and ops.dots_supported(bits1.shape[0], bits1.shape[1], bits2.shape[1]):
             return ops.sinkhorn_bits(bits1, bits2, normalized, self.epsilon, self.unused_score, self.iterations)
         z, pitch = ops.cost_logscores_bits(bits1, bits2, normalized, self.epsilon)
         return ops.sinkhorn(z, bits2.shape[1], pitch, self.dustbin_logscore, self.iterations)
+
+    @torch.no_grad()
+    def solve(self, desc1: torch.Tensor, desc2: torch.Tensor) -> SinkhornSolution:
+        """forward() without the final exp: the duals (extension; see SinkhornSolution)."""
+        dist = N.MI_DIST_L2 if self.distance_type == "l2" else N.MI_DIST_L1
+        z, pitch = ops.cost_logscores_f32(desc1, desc2, dist, self.epsilon)
+        _, u, v = ops.sinkhorn(z, desc2.shape[1], pitch, self.dustbin_logscore, self.iterations, want_p=False)
+        return SinkhornSolution("z", z, desc2.shape[1], pitch, self.epsilon, u, v)
+
+    @torch.no_grad()
+    def solve_bits(self, bits1: torch.Tensor, bits2: torch.Tensor, normalized: bool) -> SinkhornSolution:
+        if self.distance_type != "l2":
+            raise RuntimeError("solve_bits implements the l2 cost only")
+        m = bits2.shape[1]
+        if self.use_dot_storage and ops.dots_supported(bits1.shape[0], bits1.shape[1], m):
+            _, u, v, state = ops.sinkhorn_bits(bits1, bits2, normalized, self.epsilon, self.unused_score,
+                                               self.iterations, want_p=False, return_state=True)
+            return SinkhornSolution("dots", state, m, state[3], self.epsilon, u, v)
+        z, pitch = ops.cost_logscores_bits(bits1, bits2, normalized, self.epsilon)
+        _, u, v = ops.sinkhorn(z, m, pitch, self.dustbin_logscore, self.iterations, want_p=False)
+        return SinkhornSolution("z", z, m, pitch, self.epsilon, u, v)
 
 
 class SinkhornMatcherWithScores(SinkhornMatcher):

@@ -53,7 +53,7 @@ def test_argument_validation_happens_before_any_launch(lib_path):
     assert lib.mi_corner_response(p, 0, 8, 8, 3, p, None) == -2                  # MI_E_SHAPE
     assert lib.mi_corner_response(p, 1, 8, 8, 4, p, None) == -3                  # MI_E_PARAM (even block)
     lib.mi_sinkhorn_workspace_bytes.restype = ctypes.c_size_t
-    assert lib.mi_sinkhorn_workspace_bytes(2, 512, 512) == 2 * 17 * 513 * 8
+    assert lib.mi_sinkhorn_workspace_bytes(2, 512, 512) == 2 * 17 * 513 * 8 + 2 * (512 + 4) * 4   # partials + padded v
     assert lib.mi_sinkhorn_workspace_bytes(2, 512, 5000) == 0
     seg, cap = ctypes.c_int(), ctypes.c_int()
     assert lib.mi_candidate_layout(480, 640, ctypes.byref(seg), ctypes.byref(cap)) == 0

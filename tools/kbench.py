@@ -94,7 +94,8 @@ def main():
         res["cost_f32(32 pairs)"] = (ms, 2.0 * 32 * K * K * 512 / ms / 1e9)
     z, pitch = ops.cost_logscores_bits(bits, b2, True, 0.05)
     if "sinkhorn" in args.which:
-        for mode, name in ((1, "sinkhorn_fused log-partials"), (0, "sinkhorn_fused prob-partials")):
+        for mode, name in ((1, "sinkhorn_fused log-partials"), (2, "sinkhorn_fused prob-partials v1"),
+                           (0, "sinkhorn_fused prob-partials lean")):
             N.load().mi_debug_set(4, mode)
             ms = timeit(lambda: ops.sinkhorn(z, K, pitch, -20.0, 20), args.iters)
             res[name] = (ms, (21.0 * 4 * n * K * K + 4.0 * n * (K + 1) ** 2) / ms / 1e6)
