@@ -546,8 +546,17 @@ __global__ __launch_bounds__(256) void sk_vcombine_p2_kernel(const float *__rest
   }
   const int j = (c == nc) ? m : c;
   const float *p = part + (size_t)b * nparts * (size_t)(m + 1) + j;
+  // band order, loads issued eight at a time (one L2 round trip instead of nparts)
   float s = 0.0f;
-  for (int k = 0; k < nparts - 1; ++k) s += p[(size_t)k * (m + 1)];
+  int k = 0;
+  for (; k + 8 <= nparts - 1; k += 8) {
+    float t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t[q] = p[(size_t)(k + q) * (m + 1)];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += t[q];
+  }
+  for (; k < nparts - 1; ++k) s += p[(size_t)k * (m + 1)];
   const float bj = p[(size_t)(nparts - 1) * (m + 1)];
   // log(s + exp(bj)) as a two-term log-sum-exp; s == 0 (everything underflowed) leaves bj
   const float a = s > 0.0f ? logf(s) : -INFINITY;

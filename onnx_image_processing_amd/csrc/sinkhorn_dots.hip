@@ -18,6 +18,8 @@ namespace {
 
 __device__ __forceinline__ float sk_exp(float d) { return __builtin_amdgcn_exp2f(d * 1.4426950408889634f); }
 
+constexpr float SKD_L2E = 1.4426950408889634f, SKD_LN2 = 0.6931471805599453f;
+
 struct ZParams {
   float neg_inv_eps;   // -1/epsilon
   float dust;          // -unused_score/epsilon
@@ -27,14 +29,52 @@ __device__ __forceinline__ float z_of(float dot, float2 row, float2 col, float n
   return mi_z_from_dot(dot, row, col, neg_inv_eps);
 }
 
-// E8 = 16-byte (8 x uint16) loads per lane per row: covers m <= 512 * E8 columns.
+// v_j <- v_j + log nu_j - log(sum of the bands' P_ij + exp(B_j))   (B_j: dustbin row, log domain)
+__device__ __forceinline__ float combine_column(const float *__restrict__ part_b, int nparts, int m, int j,
+                                                float vold, float log_n) {
+  const float *p = part_b + j;
+  const size_t stride = (size_t)(m + 1);
+  // the bands' sums, added in band order; loads issued eight at a time (one L2 round trip, not nparts)
+  float s = 0.0f;
+  int k = 0;
+  for (; k + 8 <= nparts - 1; k += 8) {
+    float t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t[q] = p[(size_t)(k + q) * stride];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += t[q];
+  }
+  for (; k < nparts - 1; ++k) s += p[(size_t)k * stride];
+  const float bj = p[(size_t)(nparts - 1) * stride];
+  // log(s + exp(bj)) as a two-term log-sum-exp; s == 0 (everything underflowed) leaves bj.
+  // v_log_f32 / v_exp_f32 (1 ulp): this runs at the head of every workgroup of the iteration kernel.
+  const float a = s > 0.0f ? __builtin_amdgcn_logf(s) * SKD_LN2 : -INFINITY;
+  const float hi = fmaxf(a, bj), lo = fminf(a, bj);
+  const float lse = hi + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f((lo - hi) * SKD_L2E)) * SKD_LN2;
+  return (vold + ((j == m) ? log_n : 0.0f)) - lse;
+}
+
+// Row half of one iteration.  A workgroup owns a band of NW*RW rows (band index nb = the dustbin
+// row): u for its rows, and the band's partial column sums of P for the column half
+// (sk_vcombine_dots_kernel).  E8 = 16-byte (8 x uint16) loads per lane per row: m <= 512 * E8.
+// (Folding the column half into the head of this kernel -- every workgroup recombining all columns --
+// was measured slower than the separate 4 us launch: it sits on every workgroup's critical path.)
+//
+// z_ij = -cost_ij/eps splits into a row constant, a column constant and one product:
+//     z_ij = c_i + nie*nb_j + dot_ij * t_j * g_i,   c_i = nie*na_i,  g_i = -2*nie*sa_i,  t_j = sb_j
+// (nie = -1/eps; the reference's clamp of the cost at 0 only acts on rounding noise of identical
+// descriptors, |z| <= 1e-6/eps there).  The row constant shifts a row's log-sum-exp without changing
+// its probabilities, so the element loop is convert, multiply, fma, max, fma, v_exp, add, fma; c_i
+// re-enters in u_i and in the dustbin-column entry.  Per-column data come from aligned, padded
+// arrays (16-byte loads): tp = t_j (0 in the padding), wp = nie*nb_j + v_j (-inf in the padding:
+// such a column contributes nowhere), the latter rebuilt by the combine kernel every iteration.
 template <int E8, int RW, int NW>
 __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *__restrict__ dots, int n, int m,
                                                                int pitch, const float2 *__restrict__ row_info,
-                                                               const float2 *__restrict__ col_info, ZParams zp,
-                                                               const float *__restrict__ v, float *__restrict__ u,
-                                                               float *__restrict__ part, float log_m,
-                                                               int v_is_zero, const float *__restrict__ wp,
+                                                               ZParams zp, const float *__restrict__ v,
+                                                               float *__restrict__ u, float *__restrict__ part,
+                                                               float log_m, int v_is_zero,
+                                                               const float *__restrict__ wp,
                                                                const float *__restrict__ tp, int cpitch) {
   constexpr int BAND = NW * RW;   // NW waves x RW rows each
   constexpr int NT = 64 * NW;
@@ -46,6 +86,7 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
   float *pb = part + ((size_t)b * (nb + 1) + band) * (size_t)(m + 1);
   const float vd = v_is_zero ? 0.0f : vb[m];
   const float dust = zp.dust;
+  const int row0 = band * BAND + wave * RW;
 
   if (band == nb) {
     // dustbin row: u_n = log m - LSE_j(dust + v_j); its log-probabilities B_j = dust + u_n + v_j
@@ -72,14 +113,19 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
     return;
   }
 
-  // z_ij = -cost_ij/eps splits into a row constant, a column constant and one product:
-  //     z_ij = c_i + nie*nb_j + dot_ij * t_j * g_i,   c_i = nie*na_i,  g_i = -2*nie*sa_i,  t_j = sb_j
-  // (nie = -1/eps; the reference's clamp of the cost at 0 only acts on rounding noise of identical
-  // descriptors, |z| <= 1e-6/eps there).  The row constant shifts a row's log-sum-exp without changing
-  // its probabilities, so the element loop is convert, multiply, fma on top of the fp32 kernel's
-  // work; c_i re-enters in u_i and in the dustbin-column entry.
-  // per-column data come from aligned, padded arrays (16-byte loads): tp = t_j (0 in the padding),
-  // wp = nie*nb_j + v_j (-inf in the padding: no contribution anywhere), rebuilt by the combine kernel
+  uint4 raw[RW][E8];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int i = min(row0 + r, n - 1);          // rows past n run on row n-1 and are given weight 0
+    const uint16_t *src = dots + ((size_t)b * n + i) * pitch;
+#pragma unroll
+    for (int e = 0; e < E8; ++e) {
+      const int j = e * 512 + lane * 8;
+      raw[r][e] = make_uint4(0u, 0u, 0u, 0u);
+      if (j < m) raw[r][e] = *reinterpret_cast<const uint4 *>(src + j);   // pitch >= round_up(m,8)
+    }
+  }
+
   float tq[E8][8], wq[E8][8];
 #pragma unroll
   for (int e = 0; e < E8; ++e) {
@@ -94,20 +140,6 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
     wq[e][4] = w1.x; wq[e][5] = w1.y; wq[e][6] = w1.z; wq[e][7] = w1.w;
   }
   const float xd0 = dust + vd;
-  const int row0 = band * BAND + wave * RW;
-
-  uint4 raw[RW][E8];
-#pragma unroll
-  for (int r = 0; r < RW; ++r) {
-    const int i = row0 + r;
-    const uint16_t *src = dots + ((size_t)b * n + (i < n ? i : 0)) * pitch;
-#pragma unroll
-    for (int e = 0; e < E8; ++e) {
-      const int j = e * 512 + lane * 8;
-      raw[r][e] = make_uint4(0u, 0u, 0u, 0u);
-      if (j < m) raw[r][e] = *reinterpret_cast<const uint4 *>(src + j);   // pitch >= round_up(m,8)
-    }
-  }
 
   float colsum[E8][8];
 #pragma unroll
@@ -118,8 +150,8 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
     const int i = row0 + r;
-    const bool live = i < n;     // rows past n run on row 0's data and are given weight 0
-    const float2 ri = row_info[(size_t)b * n + (live ? i : 0)];                    // wave-uniform
+    const bool live = i < n;
+    const float2 ri = row_info[(size_t)b * n + min(i, n - 1)];                     // wave-uniform
     const float gi = -2.0f * zp.neg_inv_eps * ri.x, ci = ri.y * zp.neg_inv_eps;
     const float xd = xd0 - ci;
     float x[E8][8];              // (z_ij - c_i) + v_j, then e_ij in place
@@ -131,28 +163,31 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
       for (int q = 0; q < 8; ++q) {
         const float dot = (float)((q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu));
         x[e][q] = __builtin_fmaf(dot * tq[e][q], gi, wq[e][q]);
-        mx = fmaxf(mx, x[e][q]);
       }
+      mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(x[e][0], x[e][1]), fmaxf(x[e][2], x[e][3])),
+                           fmaxf(fmaxf(x[e][4], x[e][5]), fmaxf(x[e][6], x[e][7]))));
     }
     mx = wave_max_dpp(mx);
+    // shift and 2^x scaling in one fma; u is taken from the same shift, so the row is normalised by
+    // exactly what was summed (same scheme as sk_band_p2_kernel)
+    const float nm = -(mx * SKD_L2E);
     float s = 0.0f;
 #pragma unroll
-    for (int e = 0; e < E8; ++e)
+    for (int e = 0; e < E8; ++e) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        x[e][q] = sk_exp(x[e][q] - mx);              // e_ij; exp(-inf) = 0 outside the matrix
-        s += x[e][q];
-      }
-    const float ed = expf(xd - mx);                  // dustbin column entry of this row
+      for (int q = 0; q < 8; ++q) x[e][q] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[e][q], SKD_L2E, nm));   // 0 outside
+      s += ((x[e][0] + x[e][1]) + (x[e][2] + x[e][3])) + ((x[e][4] + x[e][5]) + (x[e][6] + x[e][7]));
+    }
+    const float ed = __builtin_amdgcn_exp2f(__builtin_fmaf(xd, SKD_L2E, nm));      // dustbin column entry
     s = wave_sum_dpp(s) + ed;
-    const float inv_s = 1.0f / s;
-    if (lane == 0 && live) u[(size_t)b * (n + 1) + i] = (0.0f - (logf(s) + mx)) - ci;   // sinkhorn.py:139
-    const float wgt = live ? inv_s : 0.0f;
+    if (lane == 0 && live)                                                          // sinkhorn.py:139
+      u[(size_t)b * (n + 1) + i] = (nm - __builtin_amdgcn_logf(s)) * SKD_LN2 - ci;
+    const float wgt = live ? __builtin_amdgcn_rcpf(s) : 0.0f;
 #pragma unroll
     for (int e = 0; e < E8; ++e)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) colsum[e][q] += x[e][q] * wgt;                  // P_ij
-    dustcol += ed * wgt;
+      for (int q = 0; q < 8; ++q) colsum[e][q] = __builtin_fmaf(x[e][q], wgt, colsum[e][q]);   // += P_ij
+    dustcol = __builtin_fmaf(ed, wgt, dustcol);
   }
 #pragma unroll
   for (int e = 0; e < E8; ++e)
@@ -170,7 +205,7 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
   }
 }
 
-// v_j <- v_j + log nu_j - log(sum of the bands' P_ij + exp(B_j))   (B_j: dustbin row, log domain)
+// column half: v_j <- v_j + log nu_j - log(...), and wp_j = nie*nb_j + v_j for the next row half
 __global__ __launch_bounds__(256) void sk_vcombine_dots_kernel(const float *__restrict__ part, int m, int nparts,
                                                                float *__restrict__ v, float log_n,
                                                                int v_is_zero, const float2 *__restrict__ col_info,
@@ -179,15 +214,8 @@ __global__ __launch_bounds__(256) void sk_vcombine_dots_kernel(const float *__re
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j > m) return;
-  const float *p = part + (size_t)b * nparts * (size_t)(m + 1) + j;
-  float s = 0.0f;
-  for (int k = 0; k < nparts - 1; ++k) s += p[(size_t)k * (m + 1)];
-  const float bj = p[(size_t)(nparts - 1) * (m + 1)];
-  const float a = s > 0.0f ? logf(s) : -INFINITY;
-  const float hi = fmaxf(a, bj), lo = fminf(a, bj);
-  const float lse = hi + log1pf(expf(lo - hi));
   const float vold = v_is_zero ? 0.0f : v[(size_t)b * (m + 1) + j];
-  const float vnew = (vold + ((j == m) ? log_n : 0.0f)) - lse;
+  const float vnew = combine_column(part + (size_t)b * nparts * (size_t)(m + 1), nparts, m, j, vold, log_n);
   v[(size_t)b * (m + 1) + j] = vnew;
   if (j < m) wp[(size_t)b * cpitch + j] = col_info[(size_t)b * m + j].y * neg_inv_eps + vnew;
 }
@@ -237,7 +265,7 @@ void launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int b
   for (int it = 0; it < iterations; ++it) {
     const int vz = it == 0 ? 1 : 0;
     hipLaunchKernelGGL((sk_band_dots_kernel<E8, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, dots, n, m, pitch,
-                       ri, ci, zp, v, u, part, log_m, vz, wp, tp, CP);
+                       ri, zp, v, u, part, log_m, vz, wp, tp, CP);
     hipLaunchKernelGGL(sk_vcombine_dots_kernel, dim3(ceil_div(m + 1, 256), batch), dim3(256), 0, s, part, m, nb + 1,
                        v, log_n, vz, ci, zp.neg_inv_eps, wp, CP);
   }
@@ -245,7 +273,7 @@ void launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int b
 
 int dots_rows_per_band(int m) { return m <= 512 ? 32 : (m <= 1024 ? 16 : 0); }
 
-// band partials (one float per column per band), then the padded per-column arrays wp and tp
+// workspace: band partials (one float per column per band), then the padded per-column arrays wp, tp
 size_t dots_partials_bytes(int batch, int n, int m, int band) {
   const size_t b = (size_t)batch * (size_t)(ceil_div(n, band) + 1) * (size_t)(m + 1) * sizeof(float);
   return (b + 15) & ~(size_t)15;
