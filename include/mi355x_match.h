@@ -92,8 +92,8 @@ int mi_topk_keypoints(const uint64_t *cand, const uint32_t *count, int segments,
  * Box sums are exact (fp64 summed-area table over a replicate-clamped 34x34 window).
  * plan (optional, may be NULL): device buffer of mi_bad_plan_bytes(num_pairs) bytes, 16-byte
  * aligned, filled once per pair table by mi_bad_plan_build.  With a plan, HARD-mode keypoints
- * that are integer-valued, at least 15 px from the border and sit on an integer-valued (uint8)
- * patch take an int32 fast path with precomputed table corners; results are identical.
+ * with integer coordinates inside the image that sit on an integer-valued (uint8) patch take an
+ * int32 fast path (precomputed table corners when >= 15 px from the border); results are identical.
  * status (optional, required for the fast path): n*k bytes of workspace; the fast kernel marks
  * the keypoints it handled and the general kernel visits the rest. */
 size_t mi_bad_plan_bytes(int num_pairs);

@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void bad_fast_kernel(const float *__restrict__
                                                        const float *__restrict__ kpts, int k, int total,
                                                        int num_pairs, int normalize,
                                                        const BadPlan *__restrict__ plan,
+                                                       const uint32_t *__restrict__ geom,
                                                        float *__restrict__ desc, uint32_t *__restrict__ bits,
                                                        uint8_t *__restrict__ status) {
   __shared__ int sat_all[4][FW * FW];
@@ -81,12 +82,15 @@ __global__ __launch_bounds__(256) void bad_fast_kernel(const float *__restrict__
     if (lane == 0) status[flat] = 1;
     return;
   }
-  const bool interior = ky == floorf(ky) && kx == floorf(kx) && ky >= 15.0f && ky <= (float)(h - 15) &&
-                        kx >= 15.0f && kx <= (float)(w - 15);
-  if (!interior) {
+  // integer coordinates inside the image: the 32x32 replicate-clamped window [k-16, k+15] holds every
+  // box (a clamped centre only moves towards the keypoint).  >= 15 px from the border no centre is
+  // clamped and the precomputed corner offsets apply; closer, the corners are computed per pair.
+  const bool onpixel = ky == floorf(ky) && kx == floorf(kx) && ky <= (float)(h - 1) && kx <= (float)(w - 1);
+  if (!onpixel) {
     if (lane == 0) status[flat] = 0;
     return;
   }
+  const bool interior = ky >= 15.0f && ky <= (float)(h - 15) && kx >= 15.0f && kx <= (float)(w - 15);
   const int oy = (int)ky - 16, ox = (int)kx - 16;
   int *isat = sat_all[wave];
   const int half = lane >> 5, c = lane & 31;
@@ -136,11 +140,26 @@ __global__ __launch_bounds__(256) void bad_fast_kernel(const float *__restrict__
   for (int g = 0; g < 16; ++g) {
     wordv[g] = 0ull;
     if (g < groups) {
-      const uint4 o = plan_offs[g * 64 + lane];
       const int tint = plan_tint[g * 64 + lane];
-      auto at = [&](uint32_t byte_off) { return *reinterpret_cast<const int *>(sbase + byte_off); };
-      const int s1 = (at(o.x & 0xFFFFu) - at(o.x >> 16)) - (at(o.y & 0xFFFFu) - at(o.y >> 16));
-      const int s2 = (at(o.z & 0xFFFFu) - at(o.z >> 16)) - (at(o.w & 0xFFFFu) - at(o.w >> 16));
+      int s1, s2;
+      if (interior) {                                                      // wave-uniform
+        const uint4 o = plan_offs[g * 64 + lane];
+        auto at = [&](uint32_t byte_off) { return *reinterpret_cast<const int *>(sbase + byte_off); };
+        s1 = (at(o.x & 0xFFFFu) - at(o.x >> 16)) - (at(o.y & 0xFFFFu) - at(o.y >> 16));
+        s2 = (at(o.z & 0xFFFFu) - at(o.z >> 16)) - (at(o.w & 0xFFFFu) - at(o.w >> 16));
+      } else {
+        // box centre = clamp(keypoint + offset) into the image (bad.py:518-556 for integer positions),
+        // in window coordinates; rows a..b-1 / columns l..r-1 of the table with its leading zero row
+        const uint32_t q = geom[g * 64 + lane];
+        const int rad = (int)((q >> 20) & 15u);
+        auto box = [&](int offx, int offy) {
+          const int cx = clampi((int)kx + offx, 0, w - 1) - ox, cy = clampi((int)ky + offy, 0, h - 1) - oy;
+          const int a = cy - rad, b = cy + rad + 1, l = cx - rad, r = cx + rad + 1;
+          return (isat[b * FW + r] - isat[a * FW + r]) - (isat[b * FW + l] - isat[a * FW + l]);
+        };
+        s1 = box((int)(q & 31u) - 16, (int)((q >> 10) & 31u) - 16);
+        s2 = box((int)((q >> 5) & 31u) - 16, (int)((q >> 15) & 31u) - 16);
+      }
       const unsigned long long word = __ballot((s1 - s2) <= tint);   // bad.py:567
       wordv[g] = word;
       pop += (int)__popcll(word);
@@ -165,7 +184,9 @@ __global__ __launch_bounds__(256) void bad_fast_kernel(const float *__restrict__
 
 // ---- general kernel ----------------------------------------------------------------------------
 // status == nullptr: one workgroup (one wave) per keypoint.  status != nullptr: one workgroup per
-// 64 consecutive keypoints; it visits only those the fast kernel flagged (status == 0).
+// `chunk` (<= 64) consecutive keypoints; it visits only those the fast kernel flagged (status == 0).
+// Small chunks keep the serial depth per wave low: about 6 % of the keypoints are flagged at 640x480
+// (those within 15 px of the border), i.e. about one per 16.
 __global__ __launch_bounds__(64) void sparse_bad_kernel(const float *__restrict__ image, int h, int w,
                                                         const float *__restrict__ kpts, int k, int total,
                                                         const uint32_t *__restrict__ geom,
@@ -174,7 +195,7 @@ __global__ __launch_bounds__(64) void sparse_bad_kernel(const float *__restrict_
                                                         float scale_y, float scale_x,
                                                         float *__restrict__ desc,
                                                         uint32_t *__restrict__ bits,
-                                                        const uint8_t *__restrict__ status) {
+                                                        const uint8_t *__restrict__ status, int chunk) {
   __shared__ double sat[SP * SP];
   __shared__ float vals[1024];               // un-normalised descriptor row (num_pairs <= 1024)
   const int lane = threadIdx.x;
@@ -184,9 +205,10 @@ __global__ __launch_bounds__(64) void sparse_bad_kernel(const float *__restrict_
   unsigned long long todo = 1ull;
   int first = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);   // one image's keypoints share an XCD's L2
   if (status) {
-    first = (int)blockIdx.x * 64;
+    first = (int)blockIdx.x * chunk;
     const int mine = first + lane;
-    todo = __ballot(mine < total && status[mine] == 0);
+    todo = __ballot(lane < chunk && mine < total && status[mine] == 0);
+    if (!todo) return;                                         // nothing flagged in this chunk (the common case)
   }
   // pair table words of the first 8 groups: fetched once, reused for every keypoint of this wave
   uint32_t qg[8];
@@ -374,15 +396,16 @@ extern "C" int mi_sparse_bad(const float *image, int n, int h, int w, const floa
   if (fast) {
     const BadPlan *bp = reinterpret_cast<const BadPlan *>(plan);
     hipLaunchKernelGGL(bad_fast_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, s, image, h, w, keypoints,
-                       k, total, num_pairs, normalize, bp, desc, bits, status);
+                       k, total, num_pairs, normalize, bp, pair_geom, desc, bits, status);
     hipLaunchKernelGGL(bad_plan_gate_kernel, dim3(64), dim3(256), 0, s, bp, status, total);
-    hipLaunchKernelGGL(sparse_bad_kernel, dim3((unsigned)ceil_div(total, 64)), dim3(64), 0, s, image, h, w, keypoints,
-                       k, total, pair_geom, pair_thr, num_pairs, mode, temperature, normalize, scale_y, scale_x,
-                       desc, bits, status);
+    constexpr int CHUNK = 16;
+    hipLaunchKernelGGL(sparse_bad_kernel, dim3((unsigned)ceil_div(total, CHUNK)), dim3(64), 0, s, image, h, w,
+                       keypoints, k, total, pair_geom, pair_thr, num_pairs, mode, temperature, normalize, scale_y,
+                       scale_x, desc, bits, status, CHUNK);
   } else {
     hipLaunchKernelGGL(sparse_bad_kernel, dim3((unsigned)total), dim3(64), 0, s, image, h, w, keypoints, k, total,
                        pair_geom, pair_thr, num_pairs, mode, temperature, normalize, scale_y, scale_x, desc, bits,
-                       nullptr);
+                       nullptr, 1);
   }
   return mi_launch_status();
 }

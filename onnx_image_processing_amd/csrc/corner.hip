@@ -13,7 +13,7 @@
 
 #pragma clang fp contract(off)
 
-extern int mi_g_sinkhorn_log_partials;   // defined in sinkhorn.hip
+extern int mi_g_sinkhorn_log_partials;
 
 namespace {
 
