@@ -34,6 +34,26 @@ MNN = dict(max_matches=100, threshold=0.1)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
+def pmc_traffic(kernel_prefix: str, pairs_per_gpu: int):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
+    (profiles/*_bench_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
+    script at 256 pairs per GPU, reads doubled per the gfx950 note).  None when no matching profile exists."""
+    import glob
+    if pairs_per_gpu != 256:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        kernels = json.load(open(files[-1]))["kernels"]
+        for name, row in kernels.items():
+            if name.startswith(kernel_prefix):
+                return row["total_MB"] * 1e6, os.path.relpath(files[-1], ROOT)
+    except Exception:
+        pass
+    return None, None
+
+
 def cpu_baseline(pairs: int) -> dict:
     """The oracle (numpy port of the reference algorithm) on this host's cores, same workload."""
     from oracle import numpy_oracle as O
@@ -187,6 +207,7 @@ def main() -> None:
         k1_ms = float(np.mean(per_call["mi_corner_response"]))
         achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
         nvalid = float(out[..., 5].sum().item()) / pairs_per_step
+        traffic, traffic_src = pmc_traffic("corner_stream_kernel", B)
         line = {
             "metric": "image-pairs/sec (640x480, K=512)",
             "value": pairs_per_step / (ms_per_step * 1e-3),
@@ -207,7 +228,8 @@ def main() -> None:
                        "mean_valid_matches_per_pair": nvalid},
             "roofline": {"kernel": "corner_stream_kernel<3,4> (mi_corner_response)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "bytes_per_launch": k1_bytes, "ms_per_launch": k1_ms},
+                         "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": k1_bytes,
+                         "ms_per_launch": k1_ms},
             "kernels": kernels,
         }
         if world == 1 and args.cpu_pairs > 0:
