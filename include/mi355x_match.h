@@ -238,6 +238,19 @@ int mi_akaze_orientation_at_keypoints(const float *scale_scores, const float *sc
                                       int n, int h, int w, const float *keypoints, int k, float *theta,
                                       mi_stream_t stream);
 
+/* ---- geometry/essential_matrix_estimator.py:302-431  EssentialMatrixEstimator.forward and the
+ * composites' _estimate_essential_matrix (feature_detection/..._essential_matrix.py:184-271) -------
+ * Weighted 8-point algorithm on the assignment matrix p (batch, n+1, m+1): bidirectional top_k mask
+ * (k-th largest with multiplicity) AND p > 0.01 on the core (times valid1 x valid2 when given, both
+ * (batch, n) / (batch, m) bytes or both NULL), Hartley normalisation with the weights' row / column
+ * sums, Kronecker-factored normal equations, n_iter steps of shifted power iteration for the minimum
+ * eigenvector, denormalisation, projection onto singular values (s, s, 0) with n_iter_manifold steps.
+ * pts1 (batch, n, 2), pts2 (batch, m, 2): NORMALISED image coordinates (x, y) = K^-1 [px, py, 1].
+ * e (batch, 3, 3).  n, m <= 1024, 1 <= top_k <= min(8, n, m).  Deterministic. */
+int mi_essential_matrix(const float *p, int batch, int n, int m, const float *pts1, const float *pts2,
+                        const uint8_t *valid1, const uint8_t *valid2, int top_k, int n_iter,
+                        int n_iter_manifold, float *e, mi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,8 @@ SIGNATURES = {
     "mi_mnn_from_duals_dots": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_int, c_float, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p],
+    "mi_essential_matrix": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                            c_void_p, c_void_p],
     "mi_akaze_diffuse": [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p],
     "mi_akaze_hessian_scores": [c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     "mi_akaze_combine": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],

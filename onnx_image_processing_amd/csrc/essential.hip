@@ -1,0 +1,284 @@
+// K10: essential-matrix head on the Sinkhorn assignment matrix (weighted 8-point algorithm).
+// Semantics: reference pytorch_model/geometry/essential_matrix_estimator.py:302-431 (forward),
+// :150-173 (_min_eigvec9), :175-248 (_project_onto_E_manifold), :250-300 (_hartley_normalization) and
+// the composites' _estimate_essential_matrix with validity masking
+// (feature_detection/shi_tomasi_angle_sparse_bad_sinkhorn_essential_matrix.py:184-271):
+//   core = P[:n,:m] * valid1 * valid2;  weight_ij = core_ij where it is among the top_k of its row AND
+//   of its column (k-th largest with multiplicity, >=) AND > 0.01, else 0;  Hartley-normalise both
+//   point sets with the row / column sums of the weights;  M = sum_ij w_ij (f1_i (x) f2_j)(f1_i (x) f2_j)^T
+//   through the Kronecker factorisation F1^T (W F2);  minimum eigenvector by 30 steps of shifted power
+//   iteration from the all-ones vector;  denormalise;  project onto singular values (s, s, 0).
+// One 1024-thread workgroup per pair: the matrix (1 MB at K = 512) is streamed four times from L2/HBM
+// (row thresholds, column thresholds, weight sums, normal equations), everything else lives in LDS;
+// all reductions have a fixed order, so the result is deterministic.  fp32 throughout like the
+// reference; its GEMM / sum orders are BLAS's, so parity is by tolerance (|dE| ~ 1e-5 measured).
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int EM_T = 1024;       // threads per workgroup
+constexpr int EM_W = EM_T / 64;  // waves
+constexpr int EM_MAXK = 8;       // top_k <= 8
+constexpr int EM_MAXN = 1024;    // n, m <= 1024 (LDS-resident per-row / per-column state)
+
+// keep the EM_MAXK largest values seen, sorted descending (multiplicity kept)
+__device__ __forceinline__ void topk_insert(float (&top)[EM_MAXK], float x) {
+#pragma unroll
+  for (int q = 0; q < EM_MAXK; ++q) {
+    const float hi = fmaxf(top[q], x), lo = fminf(top[q], x);
+    top[q] = hi;
+    x = lo;
+  }
+}
+
+__device__ __forceinline__ float norm3(const float *v) { return sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
+__device__ __forceinline__ float det3(const float (*m)[3]) {
+  return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+         m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+}
+__device__ __forceinline__ float signf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+__device__ __forceinline__ void matvec3(const float (*a)[3], const float *v, float *out) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) out[r] = (a[r][0] * v[0] + a[r][1] * v[1]) + a[r][2] * v[2];
+}
+__device__ __forceinline__ void unit3(float *v) {
+  const float nn = norm3(v) + 1e-8f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) v[r] = v[r] / nn;
+}
+__device__ __forceinline__ void cross3(const float *a, const float *b, float *o) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// weighted centroid and scale of one point set by one wave (essential_matrix_estimator.py:270-283)
+__device__ __forceinline__ void hartley_wave(const float *__restrict__ pts, const float *wts, int cnt, int lane,
+                                             float *out /* cx, cy, s */) {
+  float sw = 0.0f, sx = 0.0f, sy = 0.0f;
+  for (int i = lane; i < cnt; i += 64) {
+    const float w = wts[i];
+    sw += w;
+    sx += w * pts[2 * i + 0];
+    sy += w * pts[2 * i + 1];
+  }
+  const float w_sum = wave_sum_dpp(sw) + 1e-8f;
+  const float cx = wave_sum_dpp(sx) / w_sum, cy = wave_sum_dpp(sy) / w_sum;
+  float sd = 0.0f;
+  for (int i = lane; i < cnt; i += 64) {
+    const float dx = pts[2 * i + 0] - cx, dy = pts[2 * i + 1] - cy;
+    sd += wts[i] * (dx * dx + dy * dy);
+  }
+  const float mean_dist = sqrtf(wave_sum_dpp(sd) / w_sum + 1e-8f);
+  if (lane == 0) {
+    out[0] = cx;
+    out[1] = cy;
+    out[2] = sqrtf(2.0f) / (mean_dist + 1e-8f);
+  }
+}
+
+__global__ __launch_bounds__(EM_T) void em_estimate_kernel(const float *__restrict__ p, int n, int m,
+                                                           const float *__restrict__ pts1,
+                                                           const float *__restrict__ pts2,
+                                                           const uint8_t *__restrict__ valid1,
+                                                           const uint8_t *__restrict__ valid2, int top_k, int n_iter,
+                                                           int n_iter_manifold, float *__restrict__ e_out) {
+  __shared__ float thr_row[EM_MAXN], thr_col[EM_MAXN], w1[EM_MAXN], w2[EM_MAXN], v1s[EM_MAXN], v2s[EM_MAXN];
+  __shared__ float f2x[EM_MAXN], f2y[EM_MAXN];
+  __shared__ float mpart[EM_W][81];
+  __shared__ float mflat[81];
+  __shared__ float hart[6];        // c1x, c1y, s1, c2x, c2y, s2
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int b = blockIdx.x;
+  const float *pb = p + (size_t)b * (n + 1) * (size_t)(m + 1);
+  const size_t pitch = (size_t)(m + 1);
+  const float *q1 = pts1 + (size_t)b * n * 2, *q2 = pts2 + (size_t)b * m * 2;
+
+  for (int i = t; i < n; i += EM_T) v1s[i] = valid1 ? (valid1[(size_t)b * n + i] ? 1.0f : 0.0f) : 1.0f;
+  for (int j = t; j < m; j += EM_T) v2s[j] = valid2 ? (valid2[(size_t)b * m + j] ? 1.0f : 0.0f) : 1.0f;
+  __syncthreads();
+  auto core = [&](int i, int j) { return (pb[(size_t)i * pitch + j] * v1s[i]) * v2s[j]; };
+
+  // ---- k-th largest per row (one wave per row) and per column (one thread per column)
+  for (int i = wave; i < n; i += EM_W) {
+    float top[EM_MAXK];
+#pragma unroll
+    for (int q = 0; q < EM_MAXK; ++q) top[q] = -INFINITY;
+    for (int j = lane; j < m; j += 64) topk_insert(top, core(i, j));
+    float kth = -INFINITY;
+    for (int s = 0; s < top_k; ++s) {            // pop the wave-wide maximum top_k times
+      kth = wave_max_dpp(top[0]);
+      const unsigned long long owners = __ballot(top[0] == kth);
+      if (lane == __ffsll((long long)owners) - 1) {
+#pragma unroll
+        for (int q = 0; q + 1 < EM_MAXK; ++q) top[q] = top[q + 1];
+        top[EM_MAXK - 1] = -INFINITY;
+      }
+    }
+    if (lane == 0) thr_row[i] = kth;
+  }
+  for (int j = t; j < m; j += EM_T) {
+    float top[EM_MAXK];
+#pragma unroll
+    for (int q = 0; q < EM_MAXK; ++q) top[q] = -INFINITY;
+    for (int i = 0; i < n; ++i) topk_insert(top, core(i, j));
+    float kth = top[0];
+#pragma unroll
+    for (int q = 1; q < EM_MAXK; ++q) kth = (q < top_k) ? top[q] : kth;
+    thr_col[j] = kth;
+  }
+  __syncthreads();
+  auto weight = [&](int i, int j) {
+    const float x = core(i, j);
+    return (x >= thr_row[i] && x >= thr_col[j] && x > 0.01f) ? x : 0.0f;      // :345-358
+  };
+
+  // ---- row and column sums of the weights
+  for (int i = wave; i < n; i += EM_W) {
+    float s = 0.0f;
+    for (int j = lane; j < m; j += 64) s += weight(i, j);
+    s = wave_sum_dpp(s);
+    if (lane == 0) w1[i] = s;
+  }
+  for (int j = t; j < m; j += EM_T) {
+    float s = 0.0f;
+    for (int i = 0; i < n; ++i) s += weight(i, j);
+    w2[j] = s;
+  }
+  __syncthreads();
+  if (wave == 0) hartley_wave(q1, w1, n, lane, hart);
+  if (wave == 1) hartley_wave(q2, w2, m, lane, hart + 3);
+  __syncthreads();
+  for (int j = t; j < m; j += EM_T) {
+    f2x[j] = (q2[2 * j + 0] - hart[3]) * hart[5];
+    f2y[j] = (q2[2 * j + 1] - hart[4]) * hart[5];
+  }
+  __syncthreads();
+
+  // ---- normal equations: M_flat[pr][qs] = sum_i F1[i][pr] * (sum_j w_ij F2[j][qs])   (:401-414)
+  float acc0 = 0.0f, acc1 = 0.0f;                 // lane holds entries `lane` and `64 + lane` (< 81)
+  for (int i = wave; i < n; i += EM_W) {
+    float sxx = 0.0f, sxy = 0.0f, sx = 0.0f, syy = 0.0f, sy = 0.0f, s1 = 0.0f;
+    for (int j = lane; j < m; j += 64) {
+      const float w = weight(i, j);
+      const float x = f2x[j], y = f2y[j];
+      sxx += w * (x * x);
+      sxy += w * (x * y);
+      sx += w * x;
+      syy += w * (y * y);
+      sy += w * y;
+      s1 += w;
+    }
+    sxx = wave_sum_dpp(sxx); sxy = wave_sum_dpp(sxy); sx = wave_sum_dpp(sx);
+    syy = wave_sum_dpp(syy); sy = wave_sum_dpp(sy); s1 = wave_sum_dpp(s1);
+    const float wf2[9] = {sxx, sxy, sx, sxy, syy, sy, sx, sy, s1};
+    const float f1[3] = {(q1[2 * i + 0] - hart[0]) * hart[2], (q1[2 * i + 1] - hart[1]) * hart[2], 1.0f};
+    {
+      const int e = lane, pr = e / 9, qs = e - pr * 9;
+      float wsel = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) wsel = (qs == c) ? wf2[c] : wsel;
+      acc0 += (f1[pr / 3] * f1[pr % 3]) * wsel;
+    }
+    if (lane < 81 - 64) {
+      const int e = 64 + lane, pr = e / 9, qs = e - pr * 9;
+      float wsel = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) wsel = (qs == c) ? wf2[c] : wsel;
+      acc1 += (f1[pr / 3] * f1[pr % 3]) * wsel;
+    }
+  }
+  mpart[wave][lane] = acc0;
+  if (lane < 81 - 64) mpart[wave][64 + lane] = acc1;
+  __syncthreads();
+  if (t < 81) {
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < EM_W; ++w) s += mpart[w][t];
+    mflat[t] = s;
+  }
+  __syncthreads();
+  if (t != 0) return;
+
+  // ---- 9x9 minimum eigenvector by shifted power iteration (:150-173)
+  float mm[9][9];
+  float lam = 0.0f;
+  for (int a = 0; a < 9; ++a)
+    for (int c = 0; c < 9; ++c) {
+      const int pp = a / 3, qq = a % 3, rr = c / 3, ss = c % 3;   // M_mat[3p+q][3r+s] = M_flat[3p+r][3q+s]  (:414)
+      mm[a][c] = mflat[(3 * pp + rr) * 9 + (3 * qq + ss)];
+    }
+  for (int a = 0; a < 9; ++a) lam += mm[a][a];
+  for (int a = 0; a < 9; ++a)
+    for (int c = 0; c < 9; ++c) mm[a][c] = (a == c ? lam : 0.0f) - mm[a][c];
+  float v[9], nv[9];
+  for (int a = 0; a < 9; ++a) v[a] = 1.0f / 3.0f;
+  for (int it = 0; it < n_iter; ++it) {
+    float ss = 0.0f;
+    for (int a = 0; a < 9; ++a) {
+      float s = 0.0f;
+      for (int c = 0; c < 9; ++c) s += mm[a][c] * v[c];
+      nv[a] = s;
+      ss += s * s;
+    }
+    const float nn = sqrtf(ss) + 1e-8f;
+    for (int a = 0; a < 9; ++a) v[a] = nv[a] / nn;
+  }
+  // ---- denormalise: E = T2^T E_raw T1 (:424)
+  const float t1[3][3] = {{hart[2], 0.0f, -hart[2] * hart[0]}, {0.0f, hart[2], -hart[2] * hart[1]}, {0.0f, 0.0f, 1.0f}};
+  const float t2[3][3] = {{hart[5], 0.0f, -hart[5] * hart[3]}, {0.0f, hart[5], -hart[5] * hart[4]}, {0.0f, 0.0f, 1.0f}};
+  float tmp[3][3], e[3][3];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) tmp[r][c] = (t2[0][r] * v[0 * 3 + c] + t2[1][r] * v[1 * 3 + c]) + t2[2][r] * v[2 * 3 + c];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) e[r][c] = (tmp[r][0] * t1[0][c] + tmp[r][1] * t1[1][c]) + tmp[r][2] * t1[2][c];
+  // ---- manifold projection (:175-248)
+  float bm[3][3], bs[3][3];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) bm[r][c] = (e[0][r] * e[0][c] + e[1][r] * e[1][c]) + e[2][r] * e[2][c];
+  const float lam3 = (bm[0][0] + bm[1][1]) + bm[2][2];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) bs[r][c] = (r == c ? lam3 : 0.0f) - bm[r][c];
+  const float inv_sqrt3 = 1.0f / sqrtf(3.0f);
+  float va[3] = {inv_sqrt3, inv_sqrt3, inv_sqrt3}, vc[3] = {inv_sqrt3, inv_sqrt3, inv_sqrt3}, vb[3], w3[3];
+  for (int it = 0; it < n_iter_manifold; ++it) { matvec3(bm, va, w3); va[0] = w3[0]; va[1] = w3[1]; va[2] = w3[2]; unit3(va); }
+  for (int it = 0; it < n_iter_manifold; ++it) { matvec3(bs, vc, w3); vc[0] = w3[0]; vc[1] = w3[1]; vc[2] = w3[2]; unit3(vc); }
+  cross3(vc, va, vb);
+  unit3(vb);
+  float vm[3][3] = {{va[0], vb[0], vc[0]}, {va[1], vb[1], vc[1]}, {va[2], vb[2], vc[2]}};   // columns v1 v2 v3
+  const float sgn_v = signf(det3(vm));
+  for (int r = 0; r < 3; ++r) vm[r][2] *= sgn_v;
+  const float c0[3] = {vm[0][0], vm[1][0], vm[2][0]}, c1[3] = {vm[0][1], vm[1][1], vm[2][1]};
+  float ev0[3], ev1[3], u3[3];
+  matvec3(e, c0, ev0);
+  matvec3(e, c1, ev1);
+  const float sg1 = norm3(ev0), sg2 = norm3(ev1);
+  const float s_avg = (sg1 + sg2) / 2.0f;
+  float u1[3], u2[3];
+  for (int r = 0; r < 3; ++r) { u1[r] = ev0[r] / (sg1 + 1e-8f); u2[r] = ev1[r] / (sg2 + 1e-8f); }
+  cross3(u1, u2, u3);
+  float um[3][3] = {{u1[0], u2[0], u3[0]}, {u1[1], u2[1], u3[1]}, {u1[2], u2[2], u3[2]}};
+  const float sgn_u = signf(det3(um));
+  for (int r = 0; r < 3; ++r) um[r][2] *= sgn_u;
+  // E = U diag(s, s, 0) V^T
+  float *out = e_out + (size_t)b * 9;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) out[r * 3 + c] = (um[r][0] * s_avg) * vm[c][0] + (um[r][1] * s_avg) * vm[c][1];
+}
+
+}  // namespace
+
+extern "C" int mi_essential_matrix(const float *p, int batch, int n, int m, const float *pts1, const float *pts2,
+                                   const uint8_t *valid1, const uint8_t *valid2, int top_k, int n_iter,
+                                   int n_iter_manifold, float *e, mi_stream_t stream) {
+  if (!p || !pts1 || !pts2 || !e) return MI_E_NULL;
+  if ((valid1 == nullptr) != (valid2 == nullptr)) return MI_E_NULL;
+  if (batch <= 0 || n <= 0 || m <= 0) return MI_E_SHAPE;
+  if (n > EM_MAXN || m > EM_MAXN) return MI_E_PARAM;
+  if (top_k <= 0 || top_k > EM_MAXK || top_k > n || top_k > m || n_iter < 0 || n_iter_manifold < 0) return MI_E_PARAM;
+  hipLaunchKernelGGL(em_estimate_kernel, dim3(batch), dim3(EM_T), 0, (hipStream_t)stream, p, n, m, pts1, pts2, valid1,
+                     valid2, top_k, n_iter, n_iter_manifold, e);
+  return mi_launch_status();
+}

@@ -402,3 +402,27 @@ def akaze_orientation_at_keypoints(scale_scores: torch.Tensor, scale_theta: torc
            N.dev(scale_theta, F32, "scale_theta"), s, n, h, w, N.dev(kp, F32, "keypoints"), k, theta.data_ptr(),
            N.stream_ptr())
     return theta
+
+
+# ---- essential-matrix head (geometry/essential_matrix_estimator.py) ---------------------------------
+
+def essential_matrix(p: torch.Tensor, pts1_n: torch.Tensor, pts2_n: torch.Tensor, valid1: torch.Tensor | None,
+                     valid2: torch.Tensor | None, top_k: int, n_iter: int, n_iter_manifold: int) -> torch.Tensor:
+    """P (B,N+1,M+1), normalised points (B,N,2)/(B,M,2) as (x,y), optional validity (B,N)/(B,M) -> E (B,3,3)."""
+    if p.dim() != 3:
+        raise RuntimeError(f"P must have shape (B, N+1, M+1), got {tuple(p.shape)}")
+    pp = p.float().contiguous()
+    b, n, m = pp.shape[0], pp.shape[1] - 1, pp.shape[2] - 1
+    q1, q2 = pts1_n.float().contiguous(), pts2_n.float().contiguous()
+    if tuple(q1.shape) != (b, n, 2) or tuple(q2.shape) != (b, m, 2):
+        raise RuntimeError(f"points must be ({b},{n},2) and ({b},{m},2), got {tuple(q1.shape)}, {tuple(q2.shape)}")
+    if (valid1 is None) != (valid2 is None):
+        raise RuntimeError("valid1 and valid2 must be given together")
+    v1 = valid1.to(torch.uint8).contiguous() if valid1 is not None else None
+    v2 = valid2.to(torch.uint8).contiguous() if valid2 is not None else None
+    e = torch.empty((b, 3, 3), dtype=F32, device=pp.device)
+    N.call("mi_essential_matrix", N.dev(pp, F32, "P"), b, n, m, N.dev(q1, F32, "pts1"), N.dev(q2, F32, "pts2"),
+           N.dev(v1, torch.uint8, "valid1") if v1 is not None else None,
+           N.dev(v2, torch.uint8, "valid2") if v2 is not None else None, int(top_k), int(n_iter), int(n_iter_manifold),
+           e.data_ptr(), N.stream_ptr())
+    return e

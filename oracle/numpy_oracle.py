@@ -722,3 +722,109 @@ def match_pair_akaze(image1, image2, box_params, thresholds, max_keypoints, num_
         aux["desc1"], aux["desc2"] = out[0][1], out[1][1]
         return res + (aux,)
     return res
+
+
+# --------------------------------------------------------------------------
+# Essential-matrix head: reference pytorch_model/geometry/essential_matrix_estimator.py and
+# feature_detection/shi_tomasi_angle_sparse_bad_sinkhorn_essential_matrix.py:184-271
+# --------------------------------------------------------------------------
+def _kth_largest(a, k, axis):
+    """values[k-1] of torch.topk(a, k, dim=axis, sorted=True): the k-th largest with multiplicity."""
+    return np.sort(a, axis=axis).take(-k, axis=axis)
+
+
+def essential_weights(p, valid1=None, valid2=None, top_k=3):
+    """Bidirectional top-k mask AND P > 0.01 on the core of P (essential_matrix_estimator.py:333-358;
+    validity masking of the composite, ..._essential_matrix.py:213-218).  (N+1,M+1) -> (N,M) fp32."""
+    core = np.asarray(p, F32)[:-1, :-1].copy()
+    if valid1 is not None:
+        core = core * np.asarray(valid1, F32)[:, None] * np.asarray(valid2, F32)[None, :]
+    tr = _kth_largest(core, top_k, 1)[:, None]
+    tc = _kth_largest(core, top_k, 0)[None, :]
+    mask = (core >= tr) & (core >= tc) & (core > F32(0.01))
+    return core * mask.astype(F32)
+
+
+def _hartley(pts, w):
+    """_hartley_normalization (essential_matrix_estimator.py:250-300)."""
+    w_sum = w.sum(dtype=F32) + F32(1e-8)
+    c = (w[:, None] * pts).sum(axis=0, dtype=F32) / w_sum
+    pc = pts - c
+    dist_sq = (pc ** 2).sum(axis=-1, dtype=F32)
+    mean_dist = np.sqrt((w * dist_sq).sum(dtype=F32) / w_sum + F32(1e-8))
+    s = np.sqrt(F32(2.0)) / (mean_dist + F32(1e-8))
+    t = np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1]], F32)
+    return t, F32(s), c.astype(F32)
+
+
+def _unit(v):
+    return (v / (np.sqrt((v * v).sum(dtype=F32)) + F32(1e-8))).astype(F32)
+
+
+def _det3(m):
+    return (m[0, 0] * (m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) - m[0, 1] * (m[1, 0] * m[2, 2] - m[1, 2] * m[2, 0])
+            + m[0, 2] * (m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0]))
+
+
+def essential_from_weights(weights, pts1_n, pts2_n, n_iter=30, n_iter_manifold=10, dtype=F32):
+    """Steps 5-10 of EssentialMatrixEstimator.forward (essential_matrix_estimator.py:369-431) /
+    _estimate_essential_matrix (:238-271): Hartley normalisation, Kronecker-factored normal equations,
+    shifted power iteration for the minimum eigenvector, denormalisation, manifold projection."""
+    w = np.asarray(weights, dtype)
+    p1, p2 = np.asarray(pts1_n, dtype), np.asarray(pts2_n, dtype)
+    n, m = w.shape
+    t1, s1, c1 = _hartley(p1, w.sum(axis=1, dtype=dtype))
+    t2, s2, c2 = _hartley(p2, w.sum(axis=0, dtype=dtype))
+    f1 = np.concatenate([(p1 - c1) * s1, np.ones((n, 1), dtype)], axis=-1)
+    f2 = np.concatenate([(p2 - c2) * s2, np.ones((m, 1), dtype)], axis=-1)
+    big1 = (f1[:, :, None] * f1[:, None, :]).reshape(n, 9)
+    big2 = (f2[:, :, None] * f2[:, None, :]).reshape(m, 9)
+    m_flat = big1.T @ (w @ big2)
+    m_mat = m_flat.reshape(3, 3, 3, 3).transpose(0, 2, 1, 3).reshape(9, 9).astype(dtype)
+    lam = np.trace(m_mat).astype(dtype)
+    m_s = (lam * np.eye(9, dtype=dtype) - m_mat).astype(dtype)
+    v = (np.ones(9, dtype) / dtype(3.0)).astype(dtype)
+    for _ in range(n_iter):
+        v = _unit((m_s @ v).astype(dtype))
+    e = (t2.T @ v.reshape(3, 3) @ t1).astype(dtype)
+    # manifold projection (:175-248)
+    b = (e.T @ e).astype(dtype)
+    lam = np.trace(b).astype(dtype)
+    v1 = (np.ones(3, dtype) / np.sqrt(dtype(3.0))).astype(dtype)
+    for _ in range(n_iter_manifold):
+        v1 = _unit((b @ v1).astype(dtype))
+    b_s = (lam * np.eye(3, dtype=dtype) - b).astype(dtype)
+    v3 = (np.ones(3, dtype) / np.sqrt(dtype(3.0))).astype(dtype)
+    for _ in range(n_iter_manifold):
+        v3 = _unit((b_s @ v3).astype(dtype))
+    v2 = _unit(np.cross(v3, v1).astype(dtype))
+    vm = np.stack([v1, v2, v3], axis=-1).astype(dtype)
+    vm = (vm @ np.diag(np.array([1, 1, np.sign(_det3(vm))], dtype))).astype(dtype)
+    ev0, ev1 = (e @ vm[:, 0]).astype(dtype), (e @ vm[:, 1]).astype(dtype)
+    sg1, sg2 = np.sqrt((ev0 * ev0).sum(dtype=dtype)), np.sqrt((ev1 * ev1).sum(dtype=dtype))
+    s_avg = (sg1 + sg2) / dtype(2.0)
+    u1, u2 = ev0 / (sg1 + dtype(1e-8)), ev1 / (sg2 + dtype(1e-8))
+    um = np.stack([u1, u2, np.cross(u1, u2)], axis=-1).astype(dtype)
+    um = (um @ np.diag(np.array([1, 1, np.sign(_det3(um))], dtype))).astype(dtype)
+    return (um @ np.diag(np.array([s_avg, s_avg, 0], dtype)) @ vm.T).astype(dtype)
+
+
+def essential_matrix_grid(p, k_mat, image_shape=(32, 32), top_k=3, n_iter=30, n_iter_manifold=10):
+    """EssentialMatrixEstimator.forward: feature i sits at pixel (i % W, i // W) (:103-118)."""
+    h, w = image_shape
+    idx = np.arange(h * w, dtype=F32)
+    ph = np.stack([idx % w, idx // w, np.ones(h * w, F32)], axis=-1).astype(F32)
+    pn = (ph @ np.linalg.inv(np.asarray(k_mat, F32)).astype(F32).T)[:, :2].astype(F32)
+    n, m = p.shape[0] - 1, p.shape[1] - 1
+    return essential_from_weights(essential_weights(p, None, None, top_k), pn[:n], pn[:m], n_iter, n_iter_manifold)
+
+
+def essential_matrix_keypoints(p, kpts1, kpts2, valid1, valid2, k_mat, top_k=3, n_iter=30, n_iter_manifold=10):
+    """The composites' head (..._essential_matrix.py:334-360): keypoints (K,2) as (y,x) pixels -> K^-1."""
+    kinv = np.linalg.inv(np.asarray(k_mat, F32)).astype(F32)
+    def norm(kp):
+        kp = np.asarray(kp, F32)
+        hom = np.stack([kp[:, 1], kp[:, 0], np.ones(len(kp), F32)], axis=-1)
+        return (hom @ kinv.T)[:, :2].astype(F32)
+    w = essential_weights(p, valid1, valid2, top_k)
+    return essential_from_weights(w, norm(kpts1), norm(kpts2), n_iter, n_iter_manifold)

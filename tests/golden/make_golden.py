@@ -326,9 +326,47 @@ def akaze():
     save("akaze_pipeline", **out)
 
 
+def essential():
+    """EssentialMatrixEstimator and the two matchers with the essential-matrix head
+    (geometry/essential_matrix_estimator.py, feature_detection/*_essential_matrix.py)."""
+    from pytorch_model.geometry import EssentialMatrixEstimator
+    from pytorch_model.feature_detection import (AKAZESparseBADSinkhornWithEssentialMatrix,
+                                                 ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix)
+    out = {}
+    kg = torch.tensor([[16.0, 0.0, 16.0], [0.0, 16.0, 16.0], [0.0, 0.0, 1.0]])
+    out["grid_K"] = kg.numpy()
+    est = EssentialMatrixEstimator(K=kg, image_shape=(32, 32)).eval()
+    est5 = EssentialMatrixEstimator(K=kg, image_shape=(32, 32), top_k=5, n_iter=12, n_iter_manifold=4).eval()
+    with torch.no_grad():
+        for i, (n1, m1) in enumerate([(513, 513), (201, 141), (65, 97)]):
+            g = torch.Generator().manual_seed(70 + i)
+            p = torch.rand(n1, m1, generator=g) ** 6                      # a few confident entries per row
+            out[f"grid{i}_P"] = p.numpy()
+            out[f"grid{i}_E"] = est(p).numpy()
+            out[f"grid{i}_E5"] = est5(p).numpy()
+        kc = torch.tensor([[140.0, 0.0, 80.0], [0.0, 140.0, 60.0], [0.0, 0.0, 1.0]])
+        out["cam_K"] = kc.numpy()
+        a, b = synth_batch(3400, 1, 120, 160)
+        ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+        cfgs = {"st": (ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix,
+                       dict(max_keypoints=64, num_pairs=512, binarize=True, soft_binarize=False, epsilon=0.05, block_size=3)),
+                "st_soft": (ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix, dict(max_keypoints=48, block_size=3)),
+                "ak": (AKAZESparseBADSinkhornWithEssentialMatrix,
+                       dict(max_keypoints=64, num_pairs=512, binarize=True, soft_binarize=False, epsilon=0.05))}
+        for name, (cls, cfg) in cfgs.items():
+            k1, k2, p, e = cls(K=kc, **cfg).eval()(ta, tb)
+            out[name + "_cfg"] = np.array(repr(cfg))
+            out[name + "_k1"], out[name + "_k2"], out[name + "_P"], out[name + "_E"] = (k1.numpy(), k2.numpy(),
+                                                                                         p.numpy(), e.numpy())
+    out["pair_seed"] = 3400
+    save("essential_matrix", **out)
+
+
 if __name__ == "__main__":
     if "--dense-only" in sys.argv:
         dense()
+    elif "--essential-only" in sys.argv:
+        essential()
     elif "--akaze-only" in sys.argv:
         akaze()
     elif "--filters-only" in sys.argv:
@@ -341,3 +379,4 @@ if __name__ == "__main__":
         angle()
         dense()
         akaze()
+        essential()

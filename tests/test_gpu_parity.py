@@ -673,3 +673,60 @@ def test_wrapper_fused_equals_two_step(mods, name):
     for x, y in zip(fused_z, wrap(gpu(a), gpu(b))):
         assert torch.equal(x, y)
     assert torch.equal(fused_z[3], fused[3])                                     # same match validity either way
+
+
+# ------------------------------------------------------------------ essential-matrix head
+def _e_close(e, ref, tol=1e-4):
+    return np.abs(np.asarray(e, np.float64) - np.asarray(ref, np.float64)).max() <= tol * max(1.0, np.abs(ref).max())
+
+
+def test_essential_matrix_estimator_vs_oracle_and_golden(mods):
+    from onnx_image_processing_amd.pytorch_model.geometry import EssentialMatrixEstimator
+    g = load_golden("essential_matrix")
+    kg = torch.from_numpy(g["grid_K"])
+    est = EssentialMatrixEstimator(K=kg, image_shape=(32, 32)).to(DEV)
+    est5 = EssentialMatrixEstimator(K=kg, image_shape=(32, 32), top_k=5, n_iter=12, n_iter_manifold=4).to(DEV)
+    assert set(est.state_dict()) == {"K", "K_inv", "pixel_coords", "pixel_coords_n"}
+    for i in range(3):
+        p = g[f"grid{i}_P"]
+        e = est(gpu(p)).cpu().numpy()
+        assert e.shape == (3, 3)
+        assert _e_close(e, g[f"grid{i}_E"]) and _e_close(e, O.essential_matrix_grid(p, g["grid_K"]))
+        assert _e_close(est5(gpu(p)).cpu().numpy(), g[f"grid{i}_E5"])
+    # batched (extension) == one by one; ties at the k-th value and an all-zero row / column
+    rng = np.random.default_rng(12)
+    p = (rng.random((3, 130, 97)).astype(np.float32)) ** 4
+    p[0, 5, :] = 0.0
+    p[0, :, 7] = 0.0
+    p[1, 9, 3:9] = 0.5                                                       # six equal values in one row
+    eb = est(gpu(p)).cpu().numpy()
+    for b in range(3):
+        assert _e_close(eb[b], O.essential_matrix_grid(p[b], g["grid_K"]))
+        assert np.array_equal(eb[b], est(gpu(p[b])).cpu().numpy())          # deterministic
+    with pytest.raises(RuntimeError):
+        est(gpu(np.zeros((1100, 20), np.float32)))                           # more features than grid points / N > 1024
+    with pytest.raises(RuntimeError):
+        EssentialMatrixEstimator(K=kg, image_shape=(32, 32), top_k=9).to(DEV)(gpu(p[0]))
+
+
+@pytest.mark.parametrize("name", ["st", "st_soft", "ak"])
+def test_essential_matrix_composites_vs_golden(mods, name):
+    from onnx_image_processing_amd.pytorch_model.feature_detection import (
+        AKAZESparseBADSinkhornWithEssentialMatrix, ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix)
+    g = load_golden("essential_matrix")
+    a, b = synth_batch(int(g["pair_seed"]), 1, 120, 160)
+    cfg = cfg_of(g, name + "_cfg")
+    cls = AKAZESparseBADSinkhornWithEssentialMatrix if name == "ak" else ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix
+    model = cls(K=torch.from_numpy(g["cam_K"]), **cfg).to(DEV)
+    k1, k2, p, e = [t.cpu().numpy() for t in model(gpu(a), gpu(b))]
+    assert e.shape == (3, 3) and p.shape == (1, cfg["max_keypoints"] + 1, cfg["max_keypoints"] + 1)
+    assert np.array_equal(k1, g[name + "_k1"]) and np.array_equal(k2, g[name + "_k2"])
+    # the head itself: E from OUR P and keypoints through the oracle (same inputs, so only K10 is compared)
+    eo = O.essential_matrix_keypoints(p[0], k1[0], k2[0], k1[0][:, 0] >= 0, k2[0][:, 0] >= 0, g["cam_K"])
+    assert _e_close(e, eo)
+    # end to end against the reference's E (P agrees to 1e-4, so the weight mask is the same here)
+    assert _e_close(e, g[name + "_E"], tol=2e-3), np.abs(e - g[name + "_E"]).max()
+    # two pairs at once (extension): (B,3,3), each equal to the single-pair result
+    a2, b2 = np.concatenate([a, b]), np.concatenate([b, a])
+    e2 = model(gpu(a2), gpu(b2))[3].cpu().numpy()
+    assert e2.shape == (2, 3, 3) and _e_close(e2[0], e)

@@ -320,3 +320,23 @@ def test_akaze_pipeline_vs_reference(key, div):
         np.testing.assert_allclose(aux["desc1"], g[key + "_desc1"], rtol=0, atol=1e-4)
     ok, worst = p_close(p, g[key + "_P"], atol=2e-4)
     assert ok, worst
+
+
+# ------------------------------------------------------------------ essential-matrix head
+def _e_close(e, ref, tol=1e-4):
+    return np.abs(np.asarray(e, np.float64) - ref).max() <= tol * max(1.0, np.abs(ref).max())
+
+
+def test_essential_matrix_oracle_vs_reference():
+    g = load_golden("essential_matrix")
+    for i in range(3):
+        p = g[f"grid{i}_P"]
+        assert _e_close(O.essential_matrix_grid(p, g["grid_K"]), g[f"grid{i}_E"])
+        assert _e_close(O.essential_matrix_grid(p, g["grid_K"], top_k=5, n_iter=12, n_iter_manifold=4), g[f"grid{i}_E5"])
+    for name in ("st", "st_soft", "ak"):
+        k1, k2, p = g[name + "_k1"][0], g[name + "_k2"][0], g[name + "_P"][0]
+        e = O.essential_matrix_keypoints(p, k1, k2, k1[:, 0] >= 0, k2[:, 0] >= 0, g["cam_K"])
+        assert _e_close(e, g[name + "_E"]), name
+        # an essential matrix: singular values (s, s, 0)
+        sv = np.linalg.svd(e.astype(np.float64), compute_uv=False)
+        assert abs(sv[0] - sv[1]) <= 1e-3 * sv[0] and sv[2] <= 1e-3 * sv[0]
