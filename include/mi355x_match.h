@@ -251,6 +251,19 @@ int mi_essential_matrix(const float *p, int batch, int n, int m, const float *pt
                         const uint8_t *valid1, const uint8_t *valid2, int top_k, int n_iter,
                         int n_iter_manifold, float *e, mi_stream_t stream);
 
+/* ---- detector/fast.py:198-239  FASTScore.forward (use_nms = False) ----------------------------------
+ * score (n,1,h,w) = 1.0 where 9 contiguous pixels of the radius-3 circle (replicate padding) are all
+ * >= centre + threshold or all <= centre - threshold, else 0.0.  Bit-identical to the reference.
+ * ---- detector/dog.py:100-142  DoGDetector.forward ---------------------------------------------------
+ * out (n, num_scales-1, h, w) = differences of consecutive Gaussian blurs of the replicate-padded
+ * image.  weights_1d (num_scales, kernel_size): the row sums of the module's normalised 2-D kernels
+ * (their exact 1-D factors).  2 <= num_scales <= 8, kernel_size odd <= 49.
+ * score (n,1,h,w), optional: max over scales of |DoG| (DoGDetectorWithScore.forward, dog.py:182-204);
+ * out or score may be NULL, not both. */
+int mi_fast_score(const float *image, int n, int h, int w, float threshold, float *score, mi_stream_t stream);
+int mi_dog_responses(const float *image, int n, int h, int w, const float *weights_1d, int num_scales,
+                     int kernel_size, float *out, float *score, mi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,8 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p],
     "mi_essential_matrix": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                             c_void_p, c_void_p],
+    "mi_fast_score": [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
+    "mi_dog_responses": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mi_akaze_diffuse": [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p],
     "mi_akaze_hessian_scores": [c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     "mi_akaze_combine": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],

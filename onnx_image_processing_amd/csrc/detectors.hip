@@ -1,0 +1,167 @@
+// K11: the remaining detectors of pytorch_model/detector -- FAST and Difference-of-Gaussians.
+//
+// FAST, reference pytorch_model/detector/fast.py:198-239: the 16 pixels of the radius-3 Bresenham
+// circle (replicate padding, :72) against the centre: dark bit i = (I_i - I_c >= t), bright bit
+// i = (I_i - I_c <= -t) (:128-129); score 1.0 where either 16-bit ring holds 9 consecutive set bits
+// (circularly, :139-196), else 0.0.  The reference finds the run with a 24-bit buffer and 16 modulo
+// tests; here the same predicate is x & x>>1 & ... on the 24-bit buffer (run length >= 9 <=> a bit
+// survives shifts by 1, 2, 4, 1).  Comparisons of fp32 differences exactly as the reference forms
+// them, so the output is bit-identical for any input.
+//
+// DoG, reference pytorch_model/detector/dog.py:100-142: replicate-pad by ks/2, blur with num_scales
+// normalised ks x ks Gaussians, difference of consecutive scales -> (N, S-1, H, W).  The normalised
+// 2-D Gaussian is exactly the outer product of its own row sums, so the blur runs as two 1-D passes
+// (2*ks instead of ks^2 multiply-adds per pixel per scale); fp32, tolerance parity (the reference's
+// own conv order is the backend's).
+#include "common.h"
+
+#include <math.h>
+
+namespace {
+
+__constant__ int FAST_DY[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};     // fast.py:47-52
+__constant__ int FAST_DX[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
+
+__device__ __forceinline__ bool run9(uint32_t bits16) {
+  uint32_t x = bits16 | ((bits16 & 0xFFu) << 16);      // 24-bit circular buffer (:160-165)
+  x &= x >> 1;
+  x &= x >> 2;
+  x &= x >> 4;
+  x &= x >> 1;                                         // bit s set <=> bits s..s+8 were all set
+  return (x & 0xFFFFu) != 0u;
+}
+
+constexpr int FT_W = 64, FT_H = 16;                    // tile; 3-pixel halo
+
+__global__ __launch_bounds__(256) void fast_kernel(const float *__restrict__ image, int h, int w, float thr,
+                                                   float *__restrict__ score, int tiles_x, int tiles_y) {
+  __shared__ float tile[FT_H + 6][FT_W + 6 + 2];
+  int bid = (int)blockIdx.x;
+  const int tx = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int img = bid / tiles_y;
+  const int x0 = tx * FT_W, y0 = ty * FT_H;
+  const float *im = image + (size_t)img * h * w;
+  for (int i = threadIdx.x; i < (FT_H + 6) * (FT_W + 6); i += 256) {
+    const int r = i / (FT_W + 6), c = i - r * (FT_W + 6);
+    tile[r][c] = im[(size_t)clampi(y0 - 3 + r, 0, h - 1) * w + clampi(x0 - 3 + c, 0, w - 1)];
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & 63, ly0 = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < FT_H / 4; ++k) {
+    const int ly = ly0 * (FT_H / 4) + k;
+    const int gx = x0 + lx, gy = y0 + ly;
+    if (gx >= w || gy >= h) continue;
+    const float centre = tile[ly + 3][lx + 3];
+    uint32_t dark = 0u, bright = 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float diff = tile[ly + 3 + FAST_DY[i]][lx + 3 + FAST_DX[i]] - centre;
+      dark |= (diff >= thr ? 1u : 0u) << i;
+      bright |= (diff <= -thr ? 1u : 0u) << i;
+    }
+    score[((size_t)img * h + gy) * w + gx] = (run9(dark) || run9(bright)) ? 1.0f : 0.0f;
+  }
+}
+
+// ---- DoG -------------------------------------------------------------------------------------------
+constexpr int DG_T = 32;          // output tile edge
+constexpr int DG_MAXH = 24;       // half kernel <= 24 (ks <= 49)
+constexpr int DG_MAXS = 8;        // scales <= 8
+
+__global__ __launch_bounds__(256) void dog_kernel(const float *__restrict__ image, int h, int w,
+                                                  const float *__restrict__ w1d, int num_scales, int ks,
+                                                  float *__restrict__ out, float *__restrict__ score,
+                                                  int tiles_x, int tiles_y) {
+  extern __shared__ float lds[];
+  const int half = ks / 2, ext = DG_T + 2 * half;
+  float *tile = lds;                       // [ext][ext + 1]   replicate-padded input
+  float *hrow = lds + ext * (ext + 1);     // [ext][DG_T + 1]  horizontally blurred rows of one scale
+  float *wt = hrow + ext * (DG_T + 1);     // [ks]             this scale's 1-D weights
+  int bid = (int)blockIdx.x;
+  const int tx = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int img = bid / tiles_y;
+  const int x0 = tx * DG_T, y0 = ty * DG_T;
+  const float *im = image + (size_t)img * h * w;
+  for (int i = threadIdx.x; i < ext * ext; i += 256) {
+    const int r = i / ext, c = i - r * ext;
+    tile[r * (ext + 1) + c] = im[(size_t)clampi(y0 - half + r, 0, h - 1) * w + clampi(x0 - half + c, 0, w - 1)];
+  }
+  const int lx = threadIdx.x & 31, lyb = threadIdx.x >> 5;      // thread = column lx, rows lyb, lyb+8, lyb+16, lyb+24
+  float prev[4] = {0.f, 0.f, 0.f, 0.f};
+  float best[4] = {0.f, 0.f, 0.f, 0.f};                          // max over scales of |DoG| (dog.py:197-203)
+  for (int s = 0; s < num_scales; ++s) {
+    __syncthreads();                                             // tile staged / previous scale's hrow consumed
+    for (int i = threadIdx.x; i < ks; i += 256) wt[i] = w1d[s * ks + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < ext * DG_T; i += 256) {        // horizontal pass
+      const int r = i / DG_T, c = i - r * DG_T;
+      const float *src = tile + r * (ext + 1) + c;
+      float acc = 0.0f;
+      for (int k = 0; k < ks; ++k) acc += wt[k] * src[k];
+      hrow[r * (DG_T + 1) + c] = acc;
+    }
+    __syncthreads();
+    float cur[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                                // vertical pass
+      const int ly = lyb + 8 * q;
+      float acc = 0.0f;
+      for (int k = 0; k < ks; ++k) acc += wt[k] * hrow[(ly + k) * (DG_T + 1) + lx];
+      cur[q] = acc;
+    }
+    if (s > 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int gx = x0 + lx, gy = y0 + lyb + 8 * q;
+        const float d = cur[q] - prev[q];                                                                               // dog.py:140
+        best[q] = fmaxf(best[q], fabsf(d));
+        if (out && gx < w && gy < h) out[(((size_t)img * (num_scales - 1) + (s - 1)) * h + gy) * w + gx] = d;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) prev[q] = cur[q];
+  }
+  if (score) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int gx = x0 + lx, gy = y0 + lyb + 8 * q;
+      if (gx < w && gy < h) score[((size_t)img * h + gy) * w + gx] = best[q];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mi_fast_score(const float *image, int n, int h, int w, float threshold, float *score,
+                             mi_stream_t stream) {
+  if (!image || !score) return MI_E_NULL;
+  if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
+  const int tiles_x = ceil_div(w, FT_W), tiles_y = ceil_div(h, FT_H);
+  const long long blocks = (long long)n * tiles_x * tiles_y;
+  if (blocks > 0x7fffffffLL) return MI_E_SHAPE;
+  hipLaunchKernelGGL(fast_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, image, h, w, threshold,
+                     score, tiles_x, tiles_y);
+  return mi_launch_status();
+}
+
+extern "C" int mi_dog_responses(const float *image, int n, int h, int w, const float *weights_1d, int num_scales,
+                                int kernel_size, float *out, float *score, mi_stream_t stream) {
+  if (!image || !weights_1d || (!out && !score)) return MI_E_NULL;
+  if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
+  if (num_scales < 2 || num_scales > DG_MAXS || kernel_size <= 0 || (kernel_size & 1) == 0 ||
+      kernel_size / 2 > DG_MAXH)
+    return MI_E_PARAM;
+  const int tiles_x = ceil_div(w, DG_T), tiles_y = ceil_div(h, DG_T);
+  const long long blocks = (long long)n * tiles_x * tiles_y;
+  if (blocks > 0x7fffffffLL) return MI_E_SHAPE;
+  const int ext = DG_T + 2 * (kernel_size / 2);
+  const size_t lds = ((size_t)ext * (ext + 1) + (size_t)ext * (DG_T + 1) + (size_t)kernel_size) * sizeof(float);
+  hipLaunchKernelGGL(dog_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, image, h, w, weights_1d,
+                     num_scales, kernel_size, out, score, tiles_x, tiles_y);
+  return mi_launch_status();
+}

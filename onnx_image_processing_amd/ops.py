@@ -426,3 +426,27 @@ def essential_matrix(p: torch.Tensor, pts1_n: torch.Tensor, pts2_n: torch.Tensor
            N.dev(v2, torch.uint8, "valid2") if v2 is not None else None, int(top_k), int(n_iter), int(n_iter_manifold),
            e.data_ptr(), N.stream_ptr())
     return e
+
+
+# ---- FAST / DoG detectors (detector/fast.py, detector/dog.py) -----------------------------------------
+
+def fast_score(image: torch.Tensor, threshold: float) -> torch.Tensor:
+    img = _images(image, "image")
+    n, _, h, w = img.shape
+    out = torch.empty_like(img)
+    N.call("mi_fast_score", N.dev(img, F32, "image"), n, h, w, float(threshold), out.data_ptr(), N.stream_ptr())
+    return out
+
+
+def dog_responses(image: torch.Tensor, weights_1d: torch.Tensor, want_maps: bool = True, want_score: bool = False):
+    """weights_1d (S, ks): 1-D factors of the normalised Gaussians -> DoG maps (N, S-1, H, W) and/or the
+    score map max_s |DoG_s| (N, 1, H, W)."""
+    img = _images(image, "image")
+    n, _, h, w = img.shape
+    s, ks = weights_1d.shape
+    out = torch.empty((n, s - 1, h, w), dtype=F32, device=img.device) if want_maps else None
+    score = torch.empty((n, 1, h, w), dtype=F32, device=img.device) if want_score else None
+    N.call("mi_dog_responses", N.dev(img, F32, "image"), n, h, w, N.dev(weights_1d.contiguous(), F32, "weights_1d"), s,
+           ks, out.data_ptr() if out is not None else None, score.data_ptr() if score is not None else None,
+           N.stream_ptr())
+    return out, score

@@ -828,3 +828,78 @@ def essential_matrix_keypoints(p, kpts1, kpts2, valid1, valid2, k_mat, top_k=3, 
         return (hom @ kinv.T)[:, :2].astype(F32)
     w = essential_weights(p, valid1, valid2, top_k)
     return essential_from_weights(w, norm(kpts1), norm(kpts2), n_iter, n_iter_manifold)
+
+
+# --------------------------------------------------------------------------
+# FAST and DoG detectors: reference pytorch_model/detector/fast.py, dog.py
+# --------------------------------------------------------------------------
+_FAST_OFFSETS = [(0, -3), (1, -3), (2, -2), (3, -1), (3, 0), (3, 1), (2, 2), (1, 3),
+                 (0, 3), (-1, 3), (-2, 2), (-3, 1), (-3, 0), (-3, -1), (-2, -2), (-1, -3)]     # (dy, dx), fast.py:47-52
+
+
+def fast_score(image, threshold=20):
+    """FASTScore.forward (fast.py:198-239): (N,1,H,W) -> {0,1} map, by the reference's own arithmetic
+    (24-bit buffer, 16 windows of 9 bits)."""
+    img = np.asarray(image, F32)[:, 0]
+    n, h, w = img.shape
+    e = np.pad(img, ((0, 0), (3, 3), (3, 3)), mode="edge")
+    dark = np.zeros((n, h, w), np.int64)
+    bright = np.zeros((n, h, w), np.int64)
+    t = F32(float(threshold))
+    for i, (dy, dx) in enumerate(_FAST_OFFSETS):
+        diff = e[:, 3 + dy:3 + dy + h, 3 + dx:3 + dx + w] - img
+        dark += (diff >= t).astype(np.int64) << i
+        bright += (diff <= -t).astype(np.int64) << i
+
+    def nine(bits):
+        buf = bits + (bits % 256) * 65536
+        hit = np.zeros(bits.shape, bool)
+        for s in range(16):
+            hit |= ((buf // (1 << s)) % 512) == 511
+        return hit
+    return (nine(dark) | nine(bright)).astype(F32)[:, None]
+
+
+def gaussian_kernels_2d(num_scales=5, sigma_base=1.6, sigma_ratio=2 ** 0.5, kernel_size=None):
+    """DoGDetector.__init__ (dog.py:54-98): (S, ks, ks) fp32 normalised Gaussians."""
+    sigmas = [sigma_base * (sigma_ratio ** i) for i in range(num_scales)]
+    if kernel_size is None:
+        kernel_size = int(6 * sigmas[-1] + 1)
+        if kernel_size % 2 == 0:
+            kernel_size += 1
+    half = kernel_size // 2
+    c = np.arange(-half, half + 1, dtype=F32)
+    yy, xx = np.meshgrid(c, c, indexing="ij")
+    out = []
+    for s in sigmas:
+        k = np.exp(-(xx ** 2 + yy ** 2) / F32(2 * s ** 2)).astype(F32)
+        out.append((k / k.sum(dtype=F32)).astype(F32))
+    return np.stack(out)
+
+
+def dog_responses(image, num_scales=5, sigma_base=1.6, sigma_ratio=2 ** 0.5, kernel_size=None):
+    """DoGDetector.forward (dog.py:100-142), accumulated in float64 (separable: the normalised 2-D kernel is
+    the outer product of its row sums)."""
+    img = np.asarray(image, F32)[:, 0].astype(np.float64)
+    k2 = gaussian_kernels_2d(num_scales, sigma_base, sigma_ratio, kernel_size).astype(np.float64)
+    ks = k2.shape[-1]
+    half = ks // 2
+    n, h, w = img.shape
+    e = np.pad(img, ((0, 0), (half, half), (half, half)), mode="edge")
+    pyr = []
+    for s in range(num_scales):
+        w1 = k2[s].sum(axis=-1)
+        tmp = np.zeros((n, h + 2 * half, w))
+        for k in range(ks):
+            tmp += w1[k] * e[:, :, k:k + w]
+        acc = np.zeros((n, h, w))
+        for k in range(ks):
+            acc += w1[k] * tmp[:, k:k + h, :]
+        pyr.append(acc)
+    pyr = np.stack(pyr, axis=1)
+    return (pyr[:, 1:] - pyr[:, :-1]).astype(F32)
+
+
+def dog_score(image, **kw):
+    """DoGDetectorWithScore.forward (dog.py:182-204)."""
+    return np.abs(dog_responses(image, **kw)).max(axis=1, keepdims=True)

@@ -362,9 +362,28 @@ def essential():
     save("essential_matrix", **out)
 
 
+def detectors():
+    """FASTScore and DoGDetector[WithScore] (detector/fast.py, detector/dog.py)."""
+    from pytorch_model.detector import DoGDetector, DoGDetectorWithScore, FASTScore
+    img = np.stack([synth_image(3500 + i, 61, 83) for i in range(2)])[:, None].astype(np.float32)
+    img[1] += np.float32(0.37)                                   # non-integer intensities too
+    t = torch.from_numpy(img)
+    out = dict(seed=3500, h=61, w=83)
+    with torch.no_grad():
+        for thr in (20, 7):
+            out[f"fast_t{thr}"] = np.packbits(FASTScore(threshold=thr).eval()(t).numpy() != 0)
+        out["fast_nms"] = np.packbits(FASTScore(threshold=20, use_nms=True, nms_radius=3).eval()(t).numpy() != 0)
+        out["dog_default"] = DoGDetector().eval()(t).numpy()[:, :, ::3, ::3]
+        out["dog_small"] = DoGDetector(num_scales=3, sigma_base=1.0, sigma_ratio=1.5, kernel_size=9).eval()(t).numpy()
+        out["dog_score"] = DoGDetectorWithScore().eval()(t).numpy()
+    save("detectors", **out)
+
+
 if __name__ == "__main__":
     if "--dense-only" in sys.argv:
         dense()
+    elif "--detectors-only" in sys.argv:
+        detectors()
     elif "--essential-only" in sys.argv:
         essential()
     elif "--akaze-only" in sys.argv:
@@ -380,3 +399,4 @@ if __name__ == "__main__":
         dense()
         akaze()
         essential()
+        detectors()

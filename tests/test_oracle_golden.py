@@ -340,3 +340,21 @@ def test_essential_matrix_oracle_vs_reference():
         # an essential matrix: singular values (s, s, 0)
         sv = np.linalg.svd(e.astype(np.float64), compute_uv=False)
         assert abs(sv[0] - sv[1]) <= 1e-3 * sv[0] and sv[2] <= 1e-3 * sv[0]
+
+
+# ------------------------------------------------------------------ FAST / DoG detectors
+def _detector_images(g):
+    img = np.stack([synth_image(int(g["seed"]) + i, int(g["h"]), int(g["w"])) for i in range(2)])[:, None].astype(np.float32)
+    img[1] += np.float32(0.37)
+    return img
+
+
+def test_fast_and_dog_oracle_vs_reference():
+    g = load_golden("detectors")
+    img = _detector_images(g)
+    for thr in (20, 7):
+        assert np.array_equal(np.packbits(O.fast_score(img, thr) != 0), g[f"fast_t{thr}"])        # bit-exact
+    assert np.array_equal(g["fast_nms"], g["fast_t20"])          # the reference's NMS is the identity on a {0,1} map
+    np.testing.assert_allclose(O.dog_responses(img)[:, :, ::3, ::3], g["dog_default"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(O.dog_responses(img, 3, 1.0, 1.5, 9), g["dog_small"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(O.dog_score(img), g["dog_score"], rtol=0, atol=2e-3)
