@@ -2,7 +2,7 @@
 // Semantics: reference pytorch_model/utils/keypoint_utils.py:12-44 (mask) and :71-92 (masking,
 // border, threshold).  HBM traffic: 4 B/pixel read; candidates are ~1 % of pixels.
 //
-// One 256-thread workgroup owns a 128x32 tile.  The score tile (+r halo, -inf outside the
+// One workgroup (512 threads on the fast path, 256 on the generic one) owns a 128x32 tile.  The score tile (+r halo, -inf outside the
 // image) is staged in LDS, a separable max (row pass into a second LDS plane, column pass in
 // registers) gives the (2r+1)^2 window maximum.  Survivors are packed into 64-bit keys
 // (score bits high, inverted linear index low) and written to the tile's OWN segment of the
@@ -17,16 +17,18 @@ namespace {
 
 constexpr int NT_W = 128, NT_H = 32;
 constexpr int SEG_CAP = NT_W * NT_H;  // slots per tile segment
+constexpr int NMS_THREADS = 512;      // fast kernel: 8 waves share the tile's 46 KB of LDS (3 workgroups per CU)
 
 __device__ __forceinline__ uint64_t make_key(float m, uint32_t lin) {
   return ((uint64_t)__float_as_uint(m) << 32) | (uint64_t)(0xFFFFFFFFu - lin);
 }
 
-// Workgroup-wide compaction of up to 16 survivors per thread into one segment.
-// kidx[q] == 0xFFFFFFFF marks "not a survivor".  Must be called by all 256 threads.
-__device__ __forceinline__ void compact_tile(uint32_t nkeep, const float (&kval)[16], const uint32_t (&kidx)[16],
+// Workgroup-wide compaction of up to NQ survivors per thread into one segment.
+// kidx[q] == 0xFFFFFFFF marks "not a survivor".  Must be called by all NWV * 64 threads.
+template <int NQ, int NWV>
+__device__ __forceinline__ void compact_tile(uint32_t nkeep, const float (&kval)[NQ], const uint32_t (&kidx)[NQ],
                                              uint64_t *__restrict__ seg, uint32_t *__restrict__ seg_count) {
-  __shared__ uint32_t wave_total[4];
+  __shared__ uint32_t wave_total[NWV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t incl = nkeep;
 #pragma unroll
@@ -38,7 +40,7 @@ __device__ __forceinline__ void compact_tile(uint32_t nkeep, const float (&kval)
   __syncthreads();
   uint32_t base = 0, total = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < NWV; ++w) {
     const uint32_t c = wave_total[w];
     base += (w < wave) ? c : 0u;
     total += c;
@@ -46,7 +48,7 @@ __device__ __forceinline__ void compact_tile(uint32_t nkeep, const float (&kval)
   if (threadIdx.x == 0) *seg_count = total;
   uint32_t slot = base + incl - nkeep;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     if (kidx[q] != 0xFFFFFFFFu) seg[slot++] = make_key(kval[q], kidx[q]);
   }
 }
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float *__restrict__ scor
       nkeep += keep ? 1u : 0u;
     }
   }
-  if (MODE == 1) compact_tile(nkeep, kval, kidx, cand + (size_t)seg_id * SEG_CAP, count + seg_id);
+  if (MODE == 1) compact_tile<16, 4>(nkeep, kval, kidx, cand + (size_t)seg_id * SEG_CAP, count + seg_id);
 }
 
 // Explicit-mask form (the reference's separate select_topk_keypoints call), same tiling.
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void select_kernel(const float *__restrict__ s
     kidx[k] = keep ? (uint32_t)(gy * w + gx) : 0xFFFFFFFFu;
     nkeep += keep ? 1u : 0u;
   }
-  compact_tile(nkeep, kval, kidx, cand + (size_t)seg_id * SEG_CAP, count + seg_id);
+  compact_tile<16, 4>(nkeep, kval, kidx, cand + (size_t)seg_id * SEG_CAP, count + seg_id);
 }
 
 // ---- fast path: w % 4 == 0, radius 1..8 -----------------------------------------------------
@@ -168,18 +170,20 @@ __device__ __forceinline__ float4 max4(float4 a, float4 b) {
   return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
 }
 
-template <int MODE, int R>
-__global__ __launch_bounds__(256) void nms_fast_kernel(const float *__restrict__ score, int h, int w,
+template <int MODE, int R, int NTH>
+__global__ __launch_bounds__(NTH) void nms_fast_kernel(const float *__restrict__ score, int h, int w,
                                                        int tiles_x, int tiles_y, float *__restrict__ mask,
                                                        float thr_eff, int margin,
                                                        uint64_t *__restrict__ cand, uint32_t *__restrict__ count) {
   constexpr int PC = (R + 3) / 4;              // padding chunks each side
   constexpr int AW4 = NT_W / 4 + 2 * PC;       // staged row, in float4
   constexpr int LH = NT_H + 2 * R;             // staged rows
-  constexpr int NCH = (LH * AW4 + 255) / 256;  // staging chunks per thread
-  constexpr int NRP = (LH * (NT_W / 4) + 255) / 256;  // row-pass items per thread
+  constexpr int NCH = (LH * AW4 + NTH - 1) / NTH;            // staging chunks per thread
+  constexpr int NRP = (LH * (NT_W / 4) + NTH - 1) / NTH;     // row-pass items per thread
   constexpr int NV = 4 * (1 + 2 * PC);         // floats a thread reads per row in the row pass
   constexpr int B0 = 4 * PC;                   // index of output column 0 inside those floats
+  constexpr int RPT = NT_H / (NTH / 32);       // rows per thread in the column pass (4 or 2)
+  static_assert(2 * R >= RPT - 1, "the RPT windows of a thread must share rows");
   __shared__ float4 pa[LH][AW4];               // scores (+halo), -inf outside the image
   __shared__ float4 pb[LH][NT_W / 4];          // horizontal window maxima
 
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256) void nms_fast_kernel(const float *__restrict__
     float4 v[NCH];
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
-      const int i = t + q * 256;
+      const int i = t + q * NTH;
       const int rr = i / AW4, cc = i - rr * AW4;
       const int gy = y0 - R + rr, gx = x0 - 4 * PC + 4 * cc;
       v[q] = make_float4(ninf, ninf, ninf, ninf);
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256) void nms_fast_kernel(const float *__restrict__
     }
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
-      const int i = t + q * 256;
+      const int i = t + q * NTH;
       if (i < LH * AW4) (&pa[0][0])[i] = v[q];
     }
   }
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void nms_fast_kernel(const float *__restrict__
   // row pass: LH rows x 32 column groups
 #pragma unroll
   for (int it = 0; it < NRP; ++it) {
-    const int i = t + it * 256;
+    const int i = t + it * NTH;
     if (i >= LH * (NT_W / 4)) break;
     const int rr = i >> 5, cg = i & 31;
     float v[NV];
@@ -248,33 +252,26 @@ __global__ __launch_bounds__(256) void nms_fast_kernel(const float *__restrict__
   }
   __syncthreads();
 
-  // column pass: thread = 4 columns x 4 rows
+  // column pass: thread = 4 columns x RPT rows; window k covers rows [k, k + 2R], all sharing [RPT-1, 2R]
   const int tx = t & 31, ty = t >> 5;
-  float4 rows[4 + 2 * R];
+  float4 rows[RPT + 2 * R];
 #pragma unroll
-  for (int q = 0; q < 4 + 2 * R; ++q) rows[q] = pb[ty * 4 + q][tx];
-  float4 core = rows[3];                       // rows [3, 2R] are common to the 4 windows (R >= 2)
-  if constexpr (R >= 2) {
+  for (int q = 0; q < RPT + 2 * R; ++q) rows[q] = pb[ty * RPT + q][tx];
+  float4 core = rows[RPT - 1];
 #pragma unroll
-    for (int q = 4; q <= 2 * R; ++q) core = max4(core, rows[q]);
-  }
+  for (int q = RPT; q <= 2 * R; ++q) core = max4(core, rows[q]);
   const int gx = x0 + 4 * tx;
   uint32_t nkeep = 0;
-  float kval[16];
-  uint32_t kidx[16];
+  float kval[RPT * 4];
+  uint32_t kidx[RPT * 4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    float4 m;
-    if constexpr (R >= 2) {
-      m = core;
+  for (int k = 0; k < RPT; ++k) {
+    float4 m = core;
 #pragma unroll
-      for (int q = k; q < 3; ++q) m = max4(m, rows[q]);
+    for (int q = k; q < RPT - 1; ++q) m = max4(m, rows[q]);
 #pragma unroll
-      for (int q = 2 * R + 1; q <= k + 2 * R; ++q) m = max4(m, rows[q]);
-    } else {
-      m = max4(max4(rows[k], rows[k + 1]), rows[k + 2]);
-    }
-    const int ly = ty * 4 + k, gy = y0 + ly;
+    for (int q = 2 * R + 1; q <= k + 2 * R; ++q) m = max4(m, rows[q]);
+    const int ly = ty * RPT + k, gy = y0 + ly;
     const float4 s = pa[ly + R][tx + PC];
     const bool in_img = (gx < w) && (gy < h);
     const float sv[4] = {s.x, s.y, s.z, s.w};
@@ -294,7 +291,7 @@ __global__ __launch_bounds__(256) void nms_fast_kernel(const float *__restrict__
     if (MODE == 0 && in_img)
       *reinterpret_cast<float4 *>(mask + ((size_t)img * h + gy) * w + gx) = make_float4(outv[0], outv[1], outv[2], outv[3]);
   }
-  if (MODE == 1) compact_tile(nkeep, kval, kidx, cand + (size_t)seg_id * SEG_CAP, count + seg_id);
+  if (MODE == 1) compact_tile<RPT * 4, NTH / 64>(nkeep, kval, kidx, cand + (size_t)seg_id * SEG_CAP, count + seg_id);
 }
 
 template <int MODE>
@@ -306,8 +303,8 @@ bool launch_fast(const float *score, int n, int h, int w, int radius, float *mas
   const dim3 grid((unsigned)(n * tiles_x * tiles_y));
 #define MI_NMS_CASE(RR)                                                                                      \
   case RR:                                                                                                   \
-    hipLaunchKernelGGL((nms_fast_kernel<MODE, RR>), grid, dim3(256), 0, s, score, h, w, tiles_x, tiles_y,   \
-                       mask, thr_eff, margin, cand, count);                                                  \
+    hipLaunchKernelGGL((nms_fast_kernel<MODE, RR, NMS_THREADS>), grid, dim3(NMS_THREADS), 0, s, score, h, w,   \
+                       tiles_x, tiles_y, mask, thr_eff, margin, cand, count);                                     \
     break;
   switch (radius) {
     MI_NMS_CASE(1) MI_NMS_CASE(2) MI_NMS_CASE(3) MI_NMS_CASE(4)
