@@ -125,13 +125,16 @@ int mi_angle_map(const float *image, int n, int h, int w, int patch_size, const 
 int mi_angle_at_keypoints(const float *image, int n, int h, int w, const float *keypoints, int k,
                           int patch_size, const float *moment_kernels, float *theta, mi_stream_t stream);
 
-/* ---- descriptor/bad.py:487-517  SparseBAD.forward, oriented branch (sampling "nearest") -------
+/* ---- descriptor/bad.py:487-517  SparseBAD.forward, oriented branch; and sampling_mode "bilinear" --
  * Pair offsets rotated by the keypoint's angle, which comes either from a dense orientation map
- * (n,1,h,w) sampled at the keypoint, or from a per-keypoint array (n,k): exactly one non-NULL. */
+ * (n,1,h,w) sampled at the keypoint, or from a per-keypoint array (n,k): exactly one non-NULL.
+ * bilinear = 0: box centre = nearest pixel (grid_sample "nearest"); 1: the box means of the four
+ * neighbouring centres interpolated as grid_sample "bilinear" does (bad.py:535-549), response and
+ * sign test in fp32.  The non-oriented bilinear case is angle 0 for every keypoint. */
 int mi_sparse_bad_oriented(const float *image, int n, int h, int w, const float *keypoints, int k,
                            const float *orientation_map, const float *keypoint_angles,
                            const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
-                           float temperature, int normalize, float *desc, uint32_t *bits,
+                           float temperature, int normalize, int bilinear, float *desc, uint32_t *bits,
                            mi_stream_t stream);
 
 /* ---- matching/sinkhorn.py:79-110,178  cost matrix -> core log-score matrix --------------------

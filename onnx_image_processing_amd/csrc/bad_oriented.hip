@@ -6,8 +6,11 @@
 //   replicate-extended image ; response = mean1 - mean2 - thr ; raw / sigmoid / hard bit.
 // Rotated offsets reach sqrt(15^2+15^2) = 21.2 px; with the box radius (<= 7) and the rounding
 // of the centre every box lies in the 60x60 window [f-29, f+30] around f = floor(keypoint)
-// (same clamping argument as the non-oriented kernel).  One wave per keypoint, fp64 summed-area
-// table in LDS (exact for integer images): lane c owns window column c, then row c.
+// (same clamping argument as the non-oriented kernel); the extra neighbour of the bilinear mode
+// (floor(pos) + 1) still lies inside it.  One wave per keypoint, fp64 summed-area table in LDS
+// (exact for integer images): lane c owns window column c, then row c.  sampling_mode="bilinear"
+// interpolates the box means of the four neighbouring centres with ATen's grid_sampler weights; the
+// non-oriented bilinear case is this kernel with angle 0 (cos = 1, sin = 0: the offsets unchanged).
 #include "common.h"
 
 #include <math.h>
@@ -32,7 +35,8 @@ __global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restric
                                                           const uint32_t *__restrict__ geom,
                                                           const float *__restrict__ thr, int num_pairs, int mode,
                                                           float temperature, int normalize, float scale_y,
-                                                          float scale_x, float *__restrict__ desc,
+                                                          float scale_x, int bilinear,
+                                                          float *__restrict__ desc,
                                                           uint32_t *__restrict__ bits) {
   __shared__ double sat[OSP * OSP];
   __shared__ float vals[1024];
@@ -100,15 +104,51 @@ __global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restric
     // bad.py:505-517: rot_dy = ox*sin + oy*cos ; rot_dx = ox*cos - oy*sin ; pos = kp + rot
     const float p1y = ky + (ox1 * sin_t + oy1 * cos_t), p1x = kx + (ox1 * cos_t - oy1 * sin_t);
     const float p2y = ky + (ox2 * sin_t + oy2 * cos_t), p2x = kx + (ox2 * cos_t - oy2 * sin_t);
-    const int c1y = nearest_centre_o(p1y, scale_y, h) - oy, c1x = nearest_centre_o(p1x, scale_x, w) - ox;
-    const int c2y = nearest_centre_o(p2y, scale_y, h) - oy, c2x = nearest_centre_o(p2x, scale_x, w) - ox;
-    const int a1 = clampi(c1y - r, 0, OW), b1 = clampi(c1y + r + 1, 0, OW);
-    const int l1 = clampi(c1x - r, 0, OW), r1 = clampi(c1x + r + 1, 0, OW);
-    const int a2 = clampi(c2y - r, 0, OW), b2 = clampi(c2y + r + 1, 0, OW);
-    const int l2 = clampi(c2x - r, 0, OW), r2 = clampi(c2x + r + 1, 0, OW);
-    const double s1 = (sat[b1 * OSP + r1] - sat[a1 * OSP + r1]) - (sat[b1 * OSP + l1] - sat[a1 * OSP + l1]);
-    const double s2 = (sat[b2 * OSP + r2] - sat[a2 * OSP + r2]) - (sat[b2 * OSP + l2] - sat[a2 * OSP + l2]);
+    // sum of the (2r+1)^2 box centred on image pixel (cy, cx), replicate-extended, from the window's table
+    auto box_sum = [&](int cy, int cx) {
+      const int wy = cy - oy, wx = cx - ox;
+      const int a = clampi(wy - r, 0, OW), b = clampi(wy + r + 1, 0, OW);
+      const int l = clampi(wx - r, 0, OW), rr = clampi(wx + r + 1, 0, OW);
+      return (sat[b * OSP + rr] - sat[a * OSP + rr]) - (sat[b * OSP + l] - sat[a * OSP + l]);
+    };
     const double area = (double)((2 * r + 1) * (2 * r + 1));
+    if (bilinear) {
+      // sampling_mode="bilinear" (bad.py:535-549): ATen grid_sampler_2d, align_corners, border padding, on the
+      // box-mean maps: un-normalise, clip, four neighbours weighted nw/ne/sw/se, out-of-range corners skipped
+      auto sample = [&](float py, float px) {
+        float iy = (((py * scale_y - 1.0f) + 1.0f) / 2.0f) * (float)(h - 1);
+        float ix = (((px * scale_x - 1.0f) + 1.0f) / 2.0f) * (float)(w - 1);
+        iy = fminf(fmaxf(iy, 0.0f), (float)(h - 1));
+        ix = fminf(fmaxf(ix, 0.0f), (float)(w - 1));
+        const float y0f = floorf(iy), x0f = floorf(ix);
+        const int y0 = (int)y0f, x0 = (int)x0f;
+        const float wy1 = iy - y0f, wx1 = ix - x0f, wy0 = (y0f + 1.0f) - iy, wx0 = (x0f + 1.0f) - ix;
+        const bool y1ok = y0 + 1 <= h - 1, x1ok = x0 + 1 <= w - 1;
+        float acc = (float)(box_sum(y0, x0) / area) * (wx0 * wy0);
+        if (x1ok) acc += (float)(box_sum(y0, x0 + 1) / area) * (wx1 * wy0);
+        if (y1ok) acc += (float)(box_sum(y0 + 1, x0) / area) * (wx0 * wy1);
+        if (y1ok && x1ok) acc += (float)(box_sum(y0 + 1, x0 + 1) / area) * (wx1 * wy1);
+        return acc;
+      };
+      const float c = (sample(p1y, p1x) - sample(p2y, p2x)) - thr[p];   // bad.py:556-559
+      float v = c;
+      if (mode == MI_BAD_SOFT) v = 1.0f / (1.0f + expf(c * temperature));
+      else if (mode == MI_BAD_HARD) v = (c <= 0.0f) ? 1.0f : 0.0f;
+      v = valid ? v : 0.0f;
+      if (mode == MI_BAD_HARD) {
+        const unsigned long long word = __ballot(v != 0.0f);
+        pop += (int)__popcll(word);
+        if (brow && lane == 0) {
+          brow[2 * g] = (uint32_t)word;
+          brow[2 * g + 1] = (uint32_t)(word >> 32);
+        }
+      }
+      sumsq += v * v;
+      if (desc) vals[p] = v;
+      continue;
+    }
+    const double s1 = box_sum(nearest_centre_o(p1y, scale_y, h), nearest_centre_o(p1x, scale_x, w));
+    const double s2 = box_sum(nearest_centre_o(p2y, scale_y, h), nearest_centre_o(p2x, scale_x, w));
     const double t = (double)thr[p];
     if (mode == MI_BAD_HARD) {
       const bool bitv = valid && ((s1 - s2) <= t * area);               // bad.py:567,570
@@ -145,8 +185,8 @@ __global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restric
 extern "C" int mi_sparse_bad_oriented(const float *image, int n, int h, int w, const float *keypoints, int k,
                                       const float *orientation_map, const float *keypoint_angles,
                                       const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
-                                      float temperature, int normalize, float *desc, uint32_t *bits,
-                                      mi_stream_t stream) {
+                                      float temperature, int normalize, int bilinear, float *desc,
+                                      uint32_t *bits, mi_stream_t stream) {
   if (!image || !keypoints || !pair_geom || !pair_thr) return MI_E_NULL;
   if (!orientation_map == !keypoint_angles) return MI_E_NULL;          // exactly one angle source
   if (!desc && !bits) return MI_E_NULL;
@@ -158,6 +198,6 @@ extern "C" int mi_sparse_bad_oriented(const float *image, int n, int h, int w, c
   const float scale_x = (float)(2.0 / ((double)(w - 1) + 1e-8));
   hipLaunchKernelGGL(bad_oriented_kernel, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, image, h, w,
                      keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, num_pairs, mode, temperature,
-                     normalize, scale_y, scale_x, desc, bits);
+                     normalize, scale_y, scale_x, bilinear ? 1 : 0, desc, bits);
   return mi_launch_status();
 }

@@ -167,8 +167,9 @@ def angle_at_keypoints(image: torch.Tensor, keypoints: torch.Tensor, moment_kern
 
 def sparse_bad_oriented(image: torch.Tensor, keypoints: torch.Tensor, orientation: torch.Tensor,
                         pair_geom: torch.Tensor, pair_thr: torch.Tensor, mode: int, temperature: float,
-                        normalize: bool, want_desc: bool = True, want_bits: bool = False):
-    """orientation: dense map (B,1,H,W) -- the reference's argument -- or per-keypoint angles (B,K)."""
+                        normalize: bool, want_desc: bool = True, want_bits: bool = False, bilinear: bool = False):
+    """orientation: dense map (B,1,H,W) -- the reference's argument -- or per-keypoint angles (B,K).
+    bilinear: sampling_mode="bilinear" of the box-mean maps instead of "nearest"."""
     img = _images(image, "image")
     n, _, h, w = img.shape
     if keypoints.dim() != 3 or keypoints.shape[0] != n or keypoints.shape[2] != 2:
@@ -187,7 +188,7 @@ def sparse_bad_oriented(image: torch.Tensor, keypoints: torch.Tensor, orientatio
     bits = torch.empty((n, k, p // 32), dtype=torch.int32, device=img.device) if want_bits else None
     N.call("mi_sparse_bad_oriented", N.dev(img, F32, "image"), n, h, w, N.dev(kp, F32, "keypoints"), k, amap, akp,
            N.dev(pair_geom, torch.int32, "pair_geom"), N.dev(pair_thr, F32, "pair_thr"), p, int(mode),
-           float(temperature), int(bool(normalize)), desc.data_ptr() if want_desc else None,
+           float(temperature), int(bool(normalize)), int(bool(bilinear)), desc.data_ptr() if want_desc else None,
            bits.data_ptr() if want_bits else None, N.stream_ptr())
     return desc, bits
 

@@ -68,8 +68,6 @@ class SparseBAD(nn.Module):
         return N.MI_BAD_SOFT if self.soft_binarize else N.MI_BAD_HARD
 
     def _check(self, image: torch.Tensor, orientation):
-        if self.sampling_mode != "nearest":
-            raise NotImplementedError("sampling_mode='bilinear' is not built yet in this round")
         if self.pair_geom.device != image.device:
             raise RuntimeError(
                 f"SparseBAD buffers are on {self.pair_geom.device} but the image is on {image.device}; "
@@ -88,9 +86,12 @@ class SparseBAD(nn.Module):
         """orientation: None (non-oriented), the reference's dense angle map (B,1,H,W) in radians, or --
         an extension -- the angles at the keypoints themselves (B,K)."""
         self._check(image, orientation)
+        bilinear = self.sampling_mode == "bilinear"
+        if orientation is None and bilinear:             # bilinear, non-oriented: angle 0 leaves the offsets as they are
+            orientation = torch.zeros(keypoints.shape[:2], dtype=torch.float32, device=image.device)
         if orientation is not None:                      # oriented branch, bad.py:487-517
             desc, _ = ops.sparse_bad_oriented(image, keypoints, orientation, self.pair_geom, self.pair_thr, self.mode,
-                                              self.temperature, self.normalize_descriptors)
+                                              self.temperature, self.normalize_descriptors, bilinear=bilinear)
             return desc
         desc, _ = ops.sparse_bad(image, keypoints, self.pair_geom, self.pair_thr, self.mode, self.temperature,
                                  self.normalize_descriptors, want_desc=True, want_bits=False, plan=self._get_plan())
@@ -104,10 +105,13 @@ class SparseBAD(nn.Module):
         if self.mode != N.MI_BAD_HARD:
             raise RuntimeError("forward_bits needs binarize=True, soft_binarize=False")
         self._check(image, orientation)
+        bilinear = self.sampling_mode == "bilinear"
+        if orientation is None and bilinear:
+            orientation = torch.zeros(keypoints.shape[:2], dtype=torch.float32, device=image.device)
         if orientation is not None:
             _, bits = ops.sparse_bad_oriented(image, keypoints, orientation, self.pair_geom, self.pair_thr,
                                               N.MI_BAD_HARD, self.temperature, self.normalize_descriptors,
-                                              want_desc=False, want_bits=True)
+                                              want_desc=False, want_bits=True, bilinear=bilinear)
             return bits
         _, bits = ops.sparse_bad(image, keypoints, self.pair_geom, self.pair_thr, N.MI_BAD_HARD, self.temperature,
                                  self.normalize_descriptors, want_desc=False, want_bits=True, plan=self._get_plan())

@@ -434,9 +434,11 @@ def sample_nearest(field, keypoints):
 
 
 def sparse_bad_oriented(image, keypoints, theta, box_params, thresholds, binarize=False, soft_binarize=True,
-                        temperature=10.0, normalize_descriptors=True, return_aux=False):
+                        temperature=10.0, normalize_descriptors=True, return_aux=False, sampling_mode="nearest"):
     """Oriented SparseBAD.forward (bad.py:487-574); theta (B,K) = orientation sampled at the keypoints.
-    rot_dy = ox*sin + oy*cos, rot_dx = ox*cos - oy*sin in fp32 (bad.py:505-509), then as sparse_bad."""
+    rot_dy = ox*sin + oy*cos, rot_dx = ox*cos - oy*sin in fp32 (bad.py:505-509), then as sparse_bad.
+    sampling_mode="bilinear": the box-mean maps are interpolated as ATen's grid_sampler_2d does
+    (align_corners, border padding); theta = 0 gives the non-oriented bilinear descriptor."""
     img = np.asarray(image, F32)
     bsz, _, h, w = img.shape
     kp = np.asarray(keypoints, F32)
@@ -471,6 +473,27 @@ def sparse_bad_oriented(image, keypoints, theta, box_params, thresholds, binariz
             dx = (oxv[None, :] * cos_t[b] - oyv[None, :] * sin_t[b]).astype(F32)
             return _nearest_centre(ky[b][:, None] + dy, h), _nearest_centre(kx[b][:, None] + dx, w)
 
+        def bilinear(oxv, oyv):
+            dy = (oxv[None, :] * sin_t[b] + oyv[None, :] * cos_t[b]).astype(F32)
+            dx = (oxv[None, :] * cos_t[b] - oyv[None, :] * sin_t[b]).astype(F32)
+            sy, sx = F32(2.0 / (h - 1 + 1e-8)), F32(2.0 / (w - 1 + 1e-8))
+            iy = np.clip(((((ky[b][:, None] + dy) * sy - F32(1)) + F32(1)) / F32(2)) * F32(h - 1), F32(0), F32(h - 1))
+            ix = np.clip(((((kx[b][:, None] + dx) * sx - F32(1)) + F32(1)) / F32(2)) * F32(w - 1), F32(0), F32(w - 1))
+            y0f, x0f = np.floor(iy), np.floor(ix)
+            y0, x0 = y0f.astype(np.int64), x0f.astype(np.int64)
+            wy1, wx1 = (iy - y0f).astype(F32), (ix - x0f).astype(F32)
+            wy0, wx0 = ((y0f + F32(1)) - iy).astype(F32), ((x0f + F32(1)) - ix).astype(F32)
+            y1ok, x1ok = y0 + 1 <= h - 1, x0 + 1 <= w - 1
+            y1, x1 = np.minimum(y0 + 1, h - 1), np.minimum(x0 + 1, w - 1)
+            acc = mean_box(y0, x0).astype(F32) * (wx0 * wy0)
+            acc = acc + mean_box(y0, x1).astype(F32) * (wx1 * wy0) * x1ok
+            acc = acc + mean_box(y1, x0).astype(F32) * (wx0 * wy1) * y1ok
+            acc = acc + mean_box(y1, x1).astype(F32) * (wx1 * wy1) * (y1ok & x1ok)
+            return acc.astype(F32)
+
+        if sampling_mode == "bilinear":
+            centered[b] = ((bilinear(ox1, oy1) - bilinear(ox2, oy2)).astype(F32) - thr[None, :].astype(F32)).astype(F32)
+            continue
         c1y, c1x = centre(ox1, oy1)
         c2y, c2x = centre(ox2, oy2)
         centered[b] = mean_box(c1y, c1x) - mean_box(c2y, c2x) - thr[None, :]

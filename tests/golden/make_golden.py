@@ -379,9 +379,34 @@ def detectors():
     save("detectors", **out)
 
 
+def bilinear():
+    """SparseBAD(sampling_mode="bilinear") (descriptor/bad.py:535-549), non-oriented and oriented."""
+    a, _ = synth_batch(3700, 2, 96, 128)
+    rng = np.random.default_rng(37)
+    kp = np.stack([rng.integers(0, 96, (2, 40)), rng.integers(0, 128, (2, 40))], -1).astype(np.float32)
+    kp[0, 0] = (-1, -1)
+    kp[1, :4] = [(0, 0), (95, 127), (3, 120), (90, 2)]
+    kf = kp.copy()
+    kf[:, 5:] += rng.random((2, 35, 2)).astype(np.float32) * 0.9          # sub-pixel keypoints
+    ang = ((rng.random((2, 1, 96, 128)).astype(np.float32)) * 2 - 1) * np.float32(np.pi)
+    out = dict(seed=3700, kp=kp, kf=kf, ang=ang)
+    ta = torch.from_numpy(a)
+    with torch.no_grad():
+        for name, kw in (("raw", dict(num_pairs=256, normalize_descriptors=False)),
+                         ("soft", dict(num_pairs=256, binarize=True, soft_binarize=True)),
+                         ("hard", dict(num_pairs=512, binarize=True, soft_binarize=False))):
+            m = SparseBAD(sampling_mode="bilinear", **kw).eval()
+            out[name + "_int"] = m(ta, torch.from_numpy(kp)).numpy()
+            out[name + "_frac"] = m(ta, torch.from_numpy(kf)).numpy()
+            out[name + "_ori"] = m(ta, torch.from_numpy(kf), torch.from_numpy(ang)).numpy()
+    save("bad_bilinear", **out)
+
+
 if __name__ == "__main__":
     if "--dense-only" in sys.argv:
         dense()
+    elif "--bilinear-only" in sys.argv:
+        bilinear()
     elif "--detectors-only" in sys.argv:
         detectors()
     elif "--essential-only" in sys.argv:
@@ -400,3 +425,4 @@ if __name__ == "__main__":
         akaze()
         essential()
         detectors()
+        bilinear()

@@ -358,3 +358,24 @@ def test_fast_and_dog_oracle_vs_reference():
     np.testing.assert_allclose(O.dog_responses(img)[:, :, ::3, ::3], g["dog_default"], rtol=0, atol=2e-3)
     np.testing.assert_allclose(O.dog_responses(img, 3, 1.0, 1.5, 9), g["dog_small"], rtol=0, atol=2e-3)
     np.testing.assert_allclose(O.dog_score(img), g["dog_score"], rtol=0, atol=2e-3)
+
+
+# ------------------------------------------------------------------ SparseBAD(sampling_mode="bilinear")
+BILINEAR_CASES = (("raw", dict(normalize_descriptors=False), 256), ("soft", dict(binarize=True, soft_binarize=True), 256),
+                  ("hard", dict(binarize=True, soft_binarize=False), 512))
+
+
+def test_sparse_bad_bilinear_oracle_vs_reference():
+    g = load_golden("bad_bilinear")
+    a, _ = synth_batch(int(g["seed"]), 2, 96, 128)
+    zero = np.zeros((2, 40), np.float32)
+    for name, kw, pairs in BILINEAR_CASES:
+        box, thr = bad_tables(pairs)
+        for tag, kpts, th in (("int", g["kp"], zero), ("frac", g["kf"], zero),
+                              ("ori", g["kf"], O.sample_nearest(g["ang"], g["kf"]))):
+            d = O.sparse_bad_oriented(a, kpts, th, box, thr, sampling_mode="bilinear", **kw)
+            ref = g[f"{name}_{tag}"]
+            if name == "hard":
+                assert ((d != 0) == (ref != 0)).mean() >= 0.9995
+            else:                               # the reference's fp32 box means are off by up to 2e-4 each
+                np.testing.assert_allclose(d, ref, rtol=0, atol=1e-3 if name == "raw" else 1e-4)
