@@ -112,6 +112,11 @@ int mi_sparse_bad(const float *image, int n, int h, int w, const float *keypoint
  * (batch,nk,2) -> (batch,nk,d); bilinear = 0: integer truncation, 1: grid_sample bilinear/border. */
 int mi_bad_dense(const float *image, int n, int h, int w, const uint32_t *pair_geom, const float *pair_thr,
                  int num_pairs, int mode, float temperature, float *out, mi_stream_t stream);
+/* descriptor/bad.py:112-187 (_compute_diff_map_oriented): the same map with every pixel's pair offsets
+ * rotated by orientation (n,1,h,w) there and the box means sampled bilinearly (exact box sums). */
+int mi_bad_dense_oriented(const float *image, const float *orientation, int n, int h, int w,
+                          const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
+                          float temperature, float *out, mi_stream_t stream);
 int mi_gather_descriptors(const float *descriptor_map, int batch, int d, int h, int w, const float *keypoints,
                           int nk, int bilinear, float *out, mi_stream_t stream);
 

@@ -31,6 +31,8 @@ SIGNATURES = {
     "mi_sparse_bad": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mi_bad_dense": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p],
+    "mi_bad_dense_oriented": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
+                              c_void_p],
     "mi_gather_descriptors": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "mi_angle_map": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mi_angle_at_keypoints": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],

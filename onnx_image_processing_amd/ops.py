@@ -132,6 +132,21 @@ def bad_dense(image: torch.Tensor, pair_geom: torch.Tensor, pair_thr: torch.Tens
     return out
 
 
+def bad_dense_oriented(image: torch.Tensor, orientation: torch.Tensor, pair_geom: torch.Tensor, pair_thr: torch.Tensor,
+                       mode: int, temperature: float) -> torch.Tensor:
+    img = _images(image, "x")
+    n, _, h, w = img.shape
+    ori = orientation.float().contiguous()
+    if tuple(ori.shape) != (n, 1, h, w):
+        raise RuntimeError(f"orientation must have shape ({n}, 1, {h}, {w}), got {tuple(ori.shape)}")
+    p = pair_geom.numel()
+    out = torch.empty((n, p, h, w), dtype=F32, device=img.device)
+    N.call("mi_bad_dense_oriented", N.dev(img, F32, "x"), N.dev(ori, F32, "orientation"), n, h, w,
+           N.dev(pair_geom, torch.int32, "pair_geom"), N.dev(pair_thr, F32, "pair_thr"), p, int(mode),
+           float(temperature), out.data_ptr(), N.stream_ptr())
+    return out
+
+
 def gather_descriptors(descriptor_map: torch.Tensor, keypoints: torch.Tensor, bilinear: bool) -> torch.Tensor:
     if descriptor_map.dim() != 4 or keypoints.dim() != 3 or keypoints.shape[0] != descriptor_map.shape[0]:
         raise RuntimeError(f"expected (B,D,H,W) and (B,N,2), got {tuple(descriptor_map.shape)} {tuple(keypoints.shape)}")

@@ -125,7 +125,8 @@ class BADDescriptor(nn.Module):
     at every pixel (raw / sigmoid(-c*T) / (c <= 0); no normalisation).  Buffer names follow
     bad.py:31-60.  Box sums are exact (fp64 summed-area table per tile); the reference's fp32
     integral image is off by up to ~1 intensity unit on large images, so parity with it is by
-    tolerance / bit-agreement rate.  The per-pixel oriented path (AKAZE) is not built.
+    tolerance / bit-agreement rate.  With an orientation map every pixel's offsets are rotated and the
+    box means sampled bilinearly (bad.py:112-187).
     """
 
     def __init__(self, num_pairs: int = 256, binarize: bool = False, soft_binarize: bool = True,
@@ -162,8 +163,8 @@ class BADDescriptor(nn.Module):
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor, orientation: torch.Tensor | None = None) -> torch.Tensor:
-        if orientation is not None:
-            raise NotImplementedError("per-pixel oriented dense BAD (bad.py:112-187) is not built")
+        if orientation is not None:                      # per-pixel rotation + bilinear sampling, bad.py:112-187
+            return ops.bad_dense_oriented(x, orientation, self.pair_geom, self.pair_thr, self.mode, self.temperature)
         return ops.bad_dense(x, self.pair_geom, self.pair_thr, self.mode, self.temperature)
 
     @torch.no_grad()

@@ -926,3 +926,16 @@ def dog_responses(image, num_scales=5, sigma_base=1.6, sigma_ratio=2 ** 0.5, ker
 def dog_score(image, **kw):
     """DoGDetectorWithScore.forward (dog.py:182-204)."""
     return np.abs(dog_responses(image, **kw)).max(axis=1, keepdims=True)
+
+
+def bad_dense_oriented(image, orientation, box_params, thresholds, binarize=False, soft_binarize=True, temperature=10.0):
+    """BADDescriptor.forward(x, orientation) (bad.py:112-218): every pixel is a keypoint whose angle is the
+    orientation map's value there, box means sampled bilinearly: the sparse bilinear oracle over the pixel grid."""
+    img = np.asarray(image, F32)
+    bsz, _, h, w = img.shape
+    yy, xx = np.meshgrid(np.arange(h, dtype=F32), np.arange(w, dtype=F32), indexing="ij")
+    kp = np.broadcast_to(np.stack([yy.ravel(), xx.ravel()], -1)[None], (bsz, h * w, 2)).astype(F32)
+    theta = np.asarray(orientation, F32).reshape(bsz, h * w)
+    d = sparse_bad_oriented(img, kp, theta, box_params, thresholds, binarize, soft_binarize, temperature,
+                            normalize_descriptors=False, sampling_mode="bilinear")
+    return d.reshape(bsz, h, w, -1).transpose(0, 3, 1, 2).copy()

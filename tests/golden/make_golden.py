@@ -399,6 +399,14 @@ def bilinear():
             out[name + "_int"] = m(ta, torch.from_numpy(kp)).numpy()
             out[name + "_frac"] = m(ta, torch.from_numpy(kf)).numpy()
             out[name + "_ori"] = m(ta, torch.from_numpy(kf), torch.from_numpy(ang)).numpy()
+        # dense per-pixel oriented map (BADDescriptor.forward(x, orientation), bad.py:112-187) on a small image
+        from pytorch_model.descriptor.bad import BADDescriptor
+        small = synth_image(3701, 21, 30)[None, None].astype(np.float32)
+        sang = ((rng.random((1, 1, 21, 30)).astype(np.float32)) * 2 - 1) * np.float32(np.pi)
+        out["dense_ang"] = sang
+        out["dense_raw"] = BADDescriptor(256).eval()(torch.from_numpy(small), torch.from_numpy(sang)).numpy()
+        out["dense_hard"] = np.packbits(BADDescriptor(512, binarize=True, soft_binarize=False).eval()(
+            torch.from_numpy(small), torch.from_numpy(sang)).numpy() != 0)
     save("bad_bilinear", **out)
 
 

@@ -379,3 +379,14 @@ def test_sparse_bad_bilinear_oracle_vs_reference():
                 assert ((d != 0) == (ref != 0)).mean() >= 0.9995
             else:                               # the reference's fp32 box means are off by up to 2e-4 each
                 np.testing.assert_allclose(d, ref, rtol=0, atol=1e-3 if name == "raw" else 1e-4)
+
+
+def test_dense_oriented_bad_oracle_vs_reference():
+    g = load_golden("bad_bilinear")
+    small = synth_image(3701, 21, 30)[None, None].astype(np.float32)
+    box, thr = bad_tables(256)
+    np.testing.assert_allclose(O.bad_dense_oriented(small, g["dense_ang"], box, thr), g["dense_raw"], rtol=0, atol=1e-3)
+    box, thr = bad_tables(512)
+    hard = O.bad_dense_oriented(small, g["dense_ang"], box, thr, binarize=True, soft_binarize=False)
+    ref = np.unpackbits(g["dense_hard"])[: hard.size].reshape(hard.shape)
+    assert (ref == (hard != 0)).mean() >= 0.9995
