@@ -821,3 +821,24 @@ def test_dense_oriented_bad(mods):
     got = BADDescriptor(256, binarize=True, soft_binarize=True).to(DEV)(gpu(img), gpu(ang)).cpu().numpy()
     np.testing.assert_allclose(got, O.bad_dense_oriented(img, ang, box, thr, binarize=True, soft_binarize=True),
                                rtol=0, atol=2e-3)
+
+
+def test_hipgraph_replay_equals_eager(mods):
+    """graph.GraphedModule: the whole wrapper forward captured into one hipGraph replays bit-identically."""
+    from onnx_image_processing_amd.graph import GraphedModule
+    g = load_golden("small_hamming_96x128_k48")
+    cfg = cfg_of(g)
+    a, b = _images(g)
+    model = mods["MatchExtractionWrapper"](mods["ShiTomasiSparseBADSinkhornMatcher"](max_keypoints=int(g["k"]), **cfg),
+                                           max_matches=40, match_threshold=0.1).to(DEV)
+    eager = [t.clone() for t in model(gpu(a), gpu(b))]
+    graphed = GraphedModule(model, gpu(a), gpu(b))
+    for _ in range(3):
+        out = graphed(gpu(a), gpu(b))
+        for x, y in zip(out, eager):
+            assert torch.equal(x, y)
+    swapped = [t.clone() for t in graphed(gpu(b), gpu(a))]                       # new inputs through the same graph
+    for x, y in zip(swapped, model(gpu(b), gpu(a))):
+        assert torch.equal(x, y)
+    with pytest.raises(RuntimeError):
+        graphed(gpu(a[:, :, :50]), gpu(b))
