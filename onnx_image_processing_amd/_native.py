@@ -57,6 +57,8 @@ SIGNATURES = {
     "mi_mnn_from_duals_dots": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_int, c_float, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p],
+    "mi_core_maxima": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "mi_normalise_keypoints": [c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p],
     "mi_essential_matrix": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                             c_void_p, c_void_p],
     "mi_fast_score": [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p],

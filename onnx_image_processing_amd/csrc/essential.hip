@@ -270,6 +270,29 @@ __global__ __launch_bounds__(EM_T) void em_estimate_kernel(const float *__restri
 
 }  // namespace
 
+namespace {
+// (y, x) pixel keypoints -> normalised image coordinates (x, y) = first two rows of K^-1 [x, y, 1]^T
+// (feature_detection/..._essential_matrix.py:334-360)
+__global__ __launch_bounds__(256) void em_normalise_kernel(const float *__restrict__ kpts, long long total,
+                                                           const float *__restrict__ k_inv,
+                                                           float *__restrict__ pts) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const float y = kpts[2 * i + 0], x = kpts[2 * i + 1];
+  pts[2 * i + 0] = (x * k_inv[0] + y * k_inv[1]) + k_inv[2];
+  pts[2 * i + 1] = (x * k_inv[3] + y * k_inv[4]) + k_inv[5];
+}
+}  // namespace
+
+extern "C" int mi_normalise_keypoints(const float *keypoints, long long count, const float *k_inv, float *points,
+                                      mi_stream_t stream) {
+  if (!keypoints || !k_inv || !points) return MI_E_NULL;
+  if (count <= 0 || count > 0x7fffffffLL * 256LL) return MI_E_SHAPE;
+  hipLaunchKernelGGL(em_normalise_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     keypoints, count, k_inv, points);
+  return mi_launch_status();
+}
+
 extern "C" int mi_essential_matrix(const float *p, int batch, int n, int m, const float *pts1, const float *pts2,
                                    const uint8_t *valid1, const uint8_t *valid2, int top_k, int n_iter,
                                    int n_iter_manifold, float *e, mi_stream_t stream) {

@@ -401,6 +401,40 @@ extern "C" int mi_match_filters(float *p, int batch, int n, int m, float ratio_t
   return mi_launch_status();
 }
 
+// ---- SinkhornMatcherWithScores (matching/sinkhorn.py:228-259): row / column maxima of the core of P
+namespace {
+__global__ __launch_bounds__(256) void core_rowmax_kernel(const float *__restrict__ p, int n, int m,
+                                                          float *__restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, i = blockIdx.x * 4 + wave;
+  if (i >= n) return;
+  const float *pr = p + ((size_t)b * (n + 1) + i) * (size_t)(m + 1);
+  float mx = -INFINITY;
+  for (int j = lane; j < m; j += 64) mx = fmaxf(mx, pr[j]);
+  mx = wave_max_dpp(mx);
+  if (lane == 0) out[(size_t)b * n + i] = mx;
+}
+__global__ __launch_bounds__(256) void core_colmax_kernel(const float *__restrict__ p, int n, int m,
+                                                          float *__restrict__ out) {
+  const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  const float *pb = p + (size_t)b * (n + 1) * (size_t)(m + 1) + j;
+  float mx = -INFINITY;
+  for (int i = 0; i < n; ++i) mx = fmaxf(mx, pb[(size_t)i * (m + 1)]);
+  out[(size_t)b * m + j] = mx;
+}
+}  // namespace
+
+extern "C" int mi_core_maxima(const float *p, int batch, int n, int m, float *row_max, float *col_max,
+                              mi_stream_t stream) {
+  if (!p || !row_max || !col_max) return MI_E_NULL;
+  if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
+  hipLaunchKernelGGL(core_rowmax_kernel, dim3(ceil_div(n, 4), batch), dim3(256), 0, (hipStream_t)stream, p, n, m, row_max);
+  hipLaunchKernelGGL(core_colmax_kernel, dim3(ceil_div(m, 256), batch), dim3(256), 0, (hipStream_t)stream, p, n, m,
+                     col_max);
+  return mi_launch_status();
+}
+
 extern "C" int mi_abi_version(void) { return 1; }
 
 extern "C" const char *mi_error_string(int code) {

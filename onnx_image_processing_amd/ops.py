@@ -466,3 +466,23 @@ def dog_responses(image: torch.Tensor, weights_1d: torch.Tensor, want_maps: bool
            ks, out.data_ptr() if out is not None else None, score.data_ptr() if score is not None else None,
            N.stream_ptr())
     return out, score
+
+
+def normalise_keypoints(keypoints: torch.Tensor, k_inv: torch.Tensor) -> torch.Tensor:
+    """(..., 2) pixel keypoints (y, x) -> (..., 2) normalised (x, y) = K^-1 [x, y, 1] (first two rows)."""
+    kp = keypoints.float().contiguous()
+    ki = k_inv.float().contiguous()
+    out = torch.empty_like(kp)
+    N.call("mi_normalise_keypoints", N.dev(kp, F32, "keypoints"), kp.numel() // 2, N.dev(ki, F32, "K_inv"),
+           out.data_ptr(), N.stream_ptr())
+    return out
+
+
+def core_maxima(p: torch.Tensor):
+    """P (B,N+1,M+1) -> (row maxima (B,N), column maxima (B,M)) of the core P[:, :N, :M]."""
+    pp = p.float().contiguous()
+    b, n, m = pp.shape[0], pp.shape[1] - 1, pp.shape[2] - 1
+    r = torch.empty((b, n), dtype=F32, device=pp.device)
+    c = torch.empty((b, m), dtype=F32, device=pp.device)
+    N.call("mi_core_maxima", N.dev(pp, F32, "P"), b, n, m, r.data_ptr(), c.data_ptr(), N.stream_ptr())
+    return r, c

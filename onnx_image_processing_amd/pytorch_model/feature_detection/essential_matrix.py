@@ -5,6 +5,7 @@ import torch
 from torch import nn
 
 from ... import _native as N
+from ... import ops
 from ..descriptor.bad import SparseBAD
 from ..detector.akaze import AKAZE
 from ..geometry.essential_matrix_estimator import EssentialMatrixEstimator
@@ -49,9 +50,7 @@ class _EssentialHead(nn.Module):
         return kp, ksc, d, packed
 
     def _normalised(self, kp: torch.Tensor) -> torch.Tensor:
-        k_inv = self.K_inv.to(kp.device)
-        hom = torch.stack([kp[..., 1], kp[..., 0], torch.ones_like(kp[..., 0])], dim=-1)     # (y,x) -> [x, y, 1]
-        return (hom @ k_inv.T)[..., :2].contiguous()
+        return ops.normalise_keypoints(kp, self.K_inv)                                        # (y,x) -> K^-1 [x, y, 1]
 
     @torch.no_grad()
     def forward(self, image1: torch.Tensor, image2: torch.Tensor):

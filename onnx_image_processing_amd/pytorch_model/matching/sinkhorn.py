@@ -101,8 +101,8 @@ class SinkhornMatcherWithScores(SinkhornMatcher):
     @torch.no_grad()
     def forward(self, desc1: torch.Tensor, desc2: torch.Tensor):
         p = super().forward(desc1, desc2)
-        core = p[:, : desc1.shape[1], : desc2.shape[1]]
-        return p, core.amax(dim=-1), core.amax(dim=-2)
+        scores0, scores1 = ops.core_maxima(p)
+        return p, scores0, scores1
 
 
 class SinkhornMatcherWithFilters(SinkhornMatcher):
