@@ -249,7 +249,7 @@ int mi_akaze_orientation_at_keypoints(const float *scale_scores, const float *sc
 /* ---- matching/sinkhorn.py:228-259  SinkhornMatcherWithScores: maxima of P[:n,:m] per row / column */
 int mi_core_maxima(const float *p, int batch, int n, int m, float *row_max, float *col_max, mi_stream_t stream);
 
-/* ---- feature_detection/*_essential_matrix.py:334-360: `count` keypoints (y, x) in pixels -> normalised
+/* ---- feature_detection/..._essential_matrix.py:334-360: `count` keypoints (y, x) in pixels -> normalised
  * image coordinates (x, y), the first two rows of k_inv (3x3 row-major, device memory) times [x, y, 1]. */
 int mi_normalise_keypoints(const float *keypoints, long long count, const float *k_inv, float *points,
                            mi_stream_t stream);

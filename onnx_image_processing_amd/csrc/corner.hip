@@ -234,8 +234,6 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(const float *__restric
   constexpr int HL = HP + 1;       // halo of the image
   constexpr int TH = 8 * R;        // tile height
   constexpr int LH = TH + 2 * HL;  // staged rows
-  constexpr int NG = 4 + 2 * HP;   // gradient columns per thread
-  constexpr int NP = R + 2 * HP;   // product rows per thread
   __shared__ float4 tile[LH][LW4];
 
   const int t = threadIdx.x;
