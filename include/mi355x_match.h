@@ -135,12 +135,14 @@ int mi_angle_at_keypoints(const float *image, int n, int h, int w, const float *
  * (n,1,h,w) sampled at the keypoint, or from a per-keypoint array (n,k): exactly one non-NULL.
  * bilinear = 0: box centre = nearest pixel (grid_sample "nearest"); 1: the box means of the four
  * neighbouring centres interpolated as grid_sample "bilinear" does (bad.py:535-549), response and
- * sign test in fp32.  The non-oriented bilinear case is angle 0 for every keypoint. */
+ * sign test in fp32.  The non-oriented bilinear case is angle 0 for every keypoint.
+ * status (optional): n*k bytes of workspace; when given, keypoints on uint8-valued windows are done
+ * with an int32 table (half the LDS, same results) and only the rest with the fp64 one. */
 int mi_sparse_bad_oriented(const float *image, int n, int h, int w, const float *keypoints, int k,
                            const float *orientation_map, const float *keypoint_angles,
                            const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
                            float temperature, int normalize, int bilinear, float *desc, uint32_t *bits,
-                           mi_stream_t stream);
+                           uint8_t *status, mi_stream_t stream);
 
 /* ---- matching/sinkhorn.py:79-110,178  cost matrix -> core log-score matrix --------------------
  * z[b, i, j] = -cost(desc1[b,i], desc2[b,j]) / epsilon for i < n, j < m; row pitch `pitch` floats

@@ -12,14 +12,15 @@
 // order the reference's CPU conv produced when the golden vectors were recorded (the oracle, with
 // the same order, reproduces tests/golden/akaze_pipeline.npz bit for bit); tap weights are powers
 // of two, so scaling before or after the sum rounds identically.
-// Simple 32x8 tiles, one thread per pixel: these maps are small next to the matcher stages.
+// 64x16 tiles through LDS, four pixels per thread; the NMS window maximum is separable (rows, then columns).
 #include "common.h"
 
 #include <math.h>
 
 namespace {
 
-constexpr int AK_W = 32, AK_H = 8;
+constexpr int AK_W = 64, AK_H = 16;      // tile; 256 threads, 4 rows of one column per thread
+constexpr int AK_RPT = AK_H / 4;
 
 __device__ __forceinline__ void tile_coords(int tiles_x, int tiles_y, int &img, int &x0, int &y0) {
   int bid = (int)blockIdx.x;
@@ -75,9 +76,12 @@ __global__ __launch_bounds__(256) void diffuse_kernel(const float *__restrict__ 
     FY[r][c] = fy;
   }
   __syncthreads();
-  const int lx = threadIdx.x & (AK_W - 1), ly = threadIdx.x >> 5;
-  const int gx = x0 + lx, gy = y0 + ly;
-  if (gx < w && gy < h) {
+  const int lx = threadIdx.x & (AK_W - 1), lyb = (threadIdx.x >> 6) * AK_RPT;
+  const int gx = x0 + lx;
+#pragma unroll
+  for (int k = 0; k < AK_RPT; ++k) {
+    const int ly = lyb + k, gy = y0 + ly;
+    if (gx >= w || gy >= h) continue;
     // divergence: sobel_x/8 on flux_x + sobel_y/8 on flux_y (:125-126)
     const float dx = (((((FX[ly][lx + 2] - FX[ly][lx]) - 2.0f * FX[ly + 1][lx]) + 2.0f * FX[ly + 1][lx + 2]) -
                        FX[ly + 2][lx]) + FX[ly + 2][lx + 2]) * 0.125f;
@@ -122,13 +126,25 @@ __global__ __launch_bounds__(256) void hessian_kernel(const float *__restrict__ 
     R[i] = resp;
   }
   __syncthreads();
-  const int lx = threadIdx.x & (AK_W - 1), ly = threadIdx.x >> 5;
-  const int gx = x0 + lx, gy = y0 + ly;
-  if (gx < w && gy < h) {
+  // window maximum, separable: rows of R into H2 [rh][AK_W], then down the columns
+  float *H2 = R + rh * rw;
+  for (int i = threadIdx.x; i < rh * AK_W; i += 256) {
+    const int r = i / AK_W, c = i - r * AK_W;
+    const float *p = R + r * rw + c;
+    float mx = p[0];
+    for (int d = 1; d <= 2 * nms_half; ++d) mx = fmaxf(mx, p[d]);
+    H2[i] = mx;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & (AK_W - 1), lyb = (threadIdx.x >> 6) * AK_RPT;
+  const int gx = x0 + lx;
+#pragma unroll
+  for (int k = 0; k < AK_RPT; ++k) {
+    const int ly = lyb + k, gy = y0 + ly;
+    if (gx >= w || gy >= h) continue;
     const float resp = R[(ly + nms_half) * rw + lx + nms_half];
     float mx = -INFINITY;
-    for (int dy = 0; dy <= 2 * nms_half; ++dy)
-      for (int dx = 0; dx <= 2 * nms_half; ++dx) mx = fmaxf(mx, R[(ly + dy) * rw + lx + dx]);
+    for (int d = 0; d <= 2 * nms_half; ++d) mx = fmaxf(mx, H2[(ly + d) * AK_W + lx]);
     const float keep = (resp == mx && resp > threshold) ? 1.0f : 0.0f;                                       // :223,:245
     scores[((size_t)img * h + gy) * w + gx] = fmaxf(resp * keep, 0.0f);                                      // :249-252
   }
@@ -217,7 +233,8 @@ extern "C" int mi_akaze_hessian_scores(const float *l, int n, int h, int w, floa
   const int blocks = grid_for(n, h, w, tx, ty);
   if (blocks < 0) return MI_E_SHAPE;
   const int nh = nms_size / 2;
-  const size_t lds = ((size_t)(AK_H + 2 * nh + 2) * (AK_W + 2 * nh + 2) + (size_t)(AK_H + 2 * nh) * (AK_W + 2 * nh)) * 4;
+  const size_t lds = ((size_t)(AK_H + 2 * nh + 2) * (AK_W + 2 * nh + 2) + (size_t)(AK_H + 2 * nh) * (AK_W + 2 * nh) +
+                      (size_t)(AK_H + 2 * nh) * AK_W) * 4;
   hipLaunchKernelGGL(hessian_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, l, h, w, threshold, nh, scores,
                      tx, ty);
   return mi_launch_status();

@@ -28,6 +28,9 @@ __device__ __forceinline__ int nearest_centre_o(float pos, float scale, int size
   return (int)nearbyintf(x);
 }
 
+// SAT = int: exact for uint8-valued windows (checked per keypoint; others are flagged status = 0 and left
+// to the SAT = double instance), half the LDS, so twice the resident keypoints per CU.
+template <typename SAT>
 __global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restrict__ image, int h, int w,
                                                           const float *__restrict__ kpts, int k,
                                                           const float *__restrict__ theta_map,
@@ -37,11 +40,14 @@ __global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restric
                                                           float temperature, int normalize, float scale_y,
                                                           float scale_x, int bilinear,
                                                           float *__restrict__ desc,
-                                                          uint32_t *__restrict__ bits) {
-  __shared__ double sat[OSP * OSP];
+                                                          uint32_t *__restrict__ bits,
+                                                          uint8_t *__restrict__ status) {
+  constexpr bool INT = sizeof(SAT) == 4;
+  __shared__ SAT sat[OSP * OSP];
   __shared__ float vals[1024];
   const int lane = threadIdx.x;
   const int flat = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  if (!INT && status && status[flat]) return;                          // the integer instance did this keypoint
   const int img = flat / k;
   const float *im = image + (size_t)img * h * w;
   const float ky_raw = kpts[(size_t)flat * 2 + 0];
@@ -61,10 +67,11 @@ __global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restric
   const int groups = num_pairs / 64;
   const int words = num_pairs / 32;
 
-  for (int i = lane; i < OSP; i += 64) { sat[i] = 0.0; sat[i * OSP] = 0.0; }
+  for (int i = lane; i < OSP; i += 64) { sat[i] = (SAT)0; sat[i * OSP] = (SAT)0; }
+  bool integral = true;
   if (lane < OW) {
     const int gx = clampi(ox + lane, 0, w - 1);
-    double acc = 0.0;
+    SAT acc = (SAT)0;
 #pragma unroll 4
     for (int r0 = 0; r0 < OW; r0 += 15) {
       float px[15];
@@ -72,18 +79,27 @@ __global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restric
       for (int r = 0; r < 15; ++r) px[r] = im[(size_t)clampi(oy + r0 + r, 0, h - 1) * w + gx];
 #pragma unroll
       for (int r = 0; r < 15; ++r) {
-        acc += (double)px[r];
+        if (INT) {
+          const int v = (int)px[r];
+          integral = integral && ((float)v == px[r]) && (v >= 0) && (v <= 255);
+        }
+        acc += (SAT)px[r];
         sat[(r0 + r + 1) * OSP + (lane + 1)] = acc;
       }
     }
   }
+  if (INT) {
+    const bool ok = __all(integral);
+    if (lane == 0) status[flat] = ok ? 1 : 0;
+    if (!ok) return;                                                   // wave-uniform
+  }
   __syncthreads();
   if (lane < OW) {
-    double *row = sat + (lane + 1) * OSP + 1;
-    double acc = 0.0;
+    SAT *row = sat + (lane + 1) * OSP + 1;
+    SAT acc = (SAT)0;
 #pragma unroll 4
     for (int c0 = 0; c0 < OW; c0 += 15) {
-      double v[15];
+      SAT v[15];
 #pragma unroll
       for (int c = 0; c < 15; ++c) v[c] = row[c0 + c];
 #pragma unroll
@@ -109,7 +125,7 @@ __global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restric
       const int wy = cy - oy, wx = cx - ox;
       const int a = clampi(wy - r, 0, OW), b = clampi(wy + r + 1, 0, OW);
       const int l = clampi(wx - r, 0, OW), rr = clampi(wx + r + 1, 0, OW);
-      return (sat[b * OSP + rr] - sat[a * OSP + rr]) - (sat[b * OSP + l] - sat[a * OSP + l]);
+      return (double)((sat[b * OSP + rr] - sat[a * OSP + rr]) - (sat[b * OSP + l] - sat[a * OSP + l]));
     };
     const double area = (double)((2 * r + 1) * (2 * r + 1));
     if (bilinear) {
@@ -186,7 +202,7 @@ extern "C" int mi_sparse_bad_oriented(const float *image, int n, int h, int w, c
                                       const float *orientation_map, const float *keypoint_angles,
                                       const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
                                       float temperature, int normalize, int bilinear, float *desc,
-                                      uint32_t *bits, mi_stream_t stream) {
+                                      uint32_t *bits, uint8_t *status, mi_stream_t stream) {
   if (!image || !keypoints || !pair_geom || !pair_thr) return MI_E_NULL;
   if (!orientation_map == !keypoint_angles) return MI_E_NULL;          // exactly one angle source
   if (!desc && !bits) return MI_E_NULL;
@@ -196,8 +212,13 @@ extern "C" int mi_sparse_bad_oriented(const float *image, int n, int h, int w, c
   if (bits && mode != MI_BAD_HARD) return MI_E_PARAM;
   const float scale_y = (float)(2.0 / ((double)(h - 1) + 1e-8));
   const float scale_x = (float)(2.0 / ((double)(w - 1) + 1e-8));
-  hipLaunchKernelGGL(bad_oriented_kernel, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, image, h, w,
-                     keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, num_pairs, mode, temperature,
-                     normalize, scale_y, scale_x, bilinear ? 1 : 0, desc, bits);
+  if (status) {                                                         // integer tables first, the rest in fp64
+    hipLaunchKernelGGL(bad_oriented_kernel<int>, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, image, h, w,
+                       keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, num_pairs, mode,
+                       temperature, normalize, scale_y, scale_x, bilinear ? 1 : 0, desc, bits, status);
+  }
+  hipLaunchKernelGGL(bad_oriented_kernel<double>, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, image, h,
+                     w, keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, num_pairs, mode,
+                     temperature, normalize, scale_y, scale_x, bilinear ? 1 : 0, desc, bits, status);
   return mi_launch_status();
 }

@@ -201,10 +201,11 @@ def sparse_bad_oriented(image: torch.Tensor, keypoints: torch.Tensor, orientatio
     p = pair_geom.numel()
     desc = torch.empty((n, k, p), dtype=F32, device=img.device) if want_desc else None
     bits = torch.empty((n, k, p // 32), dtype=torch.int32, device=img.device) if want_bits else None
+    status = torch.empty((n, k), dtype=torch.uint8, device=img.device)      # int32-table fast path bookkeeping
     N.call("mi_sparse_bad_oriented", N.dev(img, F32, "image"), n, h, w, N.dev(kp, F32, "keypoints"), k, amap, akp,
            N.dev(pair_geom, torch.int32, "pair_geom"), N.dev(pair_thr, F32, "pair_thr"), p, int(mode),
            float(temperature), int(bool(normalize)), int(bool(bilinear)), desc.data_ptr() if want_desc else None,
-           bits.data_ptr() if want_bits else None, N.stream_ptr())
+           bits.data_ptr() if want_bits else None, status.data_ptr(), N.stream_ptr())
     return desc, bits
 
 
