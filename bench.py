@@ -141,7 +141,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-gpu", type=int, default=256)
-    ap.add_argument("--cpu-pairs", type=int, default=24, help="oracle sample size for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=192, help="oracle sample size for cpu_baseline (0 = skip)")
     ap.add_argument("--two-step", action="store_true",
                     help="materialise P and run the extractor on it (default: matches straight from the duals)")
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
