@@ -147,47 +147,71 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
 #pragma unroll
     for (int q = 0; q < 8; ++q) colsum[e][q] = 0.0f;
   float dustcol = 0.0f;          // sum of P_i,dustbin over this wave's rows (wave-uniform)
+  // The RW rows of the wave go through the three phases together, so that their wave-wide
+  // reductions are done four at a time (wave_max4 / wave_sum4).
+  float x[RW][E8][8];            // (z_ij - c_i) + v_j, then e_ij in place
+  float mx[RW], xd[RW], ci[RW];
+  bool live[RW];
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
     const int i = row0 + r;
-    const bool live = i < n;
+    live[r] = i < n;
     const float2 ri = row_info[(size_t)b * n + min(i, n - 1)];                     // wave-uniform
-    const float gi = -2.0f * zp.neg_inv_eps * ri.x, ci = ri.y * zp.neg_inv_eps;
-    const float xd = xd0 - ci;
-    float x[E8][8];              // (z_ij - c_i) + v_j, then e_ij in place
-    float mx = xd;
+    const float gi = -2.0f * zp.neg_inv_eps * ri.x;
+    ci[r] = ri.y * zp.neg_inv_eps;
+    xd[r] = xd0 - ci[r];
+    mx[r] = xd[r];
 #pragma unroll
     for (int e = 0; e < E8; ++e) {
       const uint32_t w4[4] = {raw[r][e].x, raw[r][e].y, raw[r][e].z, raw[r][e].w};
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const float dot = (float)((q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu));
-        x[e][q] = __builtin_fmaf(dot * tq[e][q], gi, wq[e][q]);
+        x[r][e][q] = __builtin_fmaf(dot * tq[e][q], gi, wq[e][q]);
       }
-      mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(x[e][0], x[e][1]), fmaxf(x[e][2], x[e][3])),
-                           fmaxf(fmaxf(x[e][4], x[e][5]), fmaxf(x[e][6], x[e][7]))));
+      mx[r] = fmaxf(mx[r], fmaxf(fmaxf(fmaxf(x[r][e][0], x[r][e][1]), fmaxf(x[r][e][2], x[r][e][3])),
+                                 fmaxf(fmaxf(x[r][e][4], x[r][e][5]), fmaxf(x[r][e][6], x[r][e][7]))));
     }
-    mx = wave_max_dpp(mx);
-    // shift and 2^x scaling in one fma; u is taken from the same shift, so the row is normalised by
-    // exactly what was summed (same scheme as sk_band_p2_kernel)
-    const float nm = -(mx * SKD_L2E);
-    float s = 0.0f;
+  }
+  if constexpr (RW == 4) {
+    wave_max4(mx);
+  } else {
+#pragma unroll
+    for (int r = 0; r < RW; ++r) mx[r] = wave_max_dpp(mx[r]);
+  }
+  // shift and 2^x scaling in one fma; u is taken from the same shift, so the row is normalised by
+  // exactly what was summed (same scheme as sk_band_p2_kernel)
+  float nm[RW], s[RW], ed[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    nm[r] = -(mx[r] * SKD_L2E);
+    s[r] = 0.0f;
 #pragma unroll
     for (int e = 0; e < E8; ++e) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) x[e][q] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[e][q], SKD_L2E, nm));   // 0 outside
-      s += ((x[e][0] + x[e][1]) + (x[e][2] + x[e][3])) + ((x[e][4] + x[e][5]) + (x[e][6] + x[e][7]));
+      for (int q = 0; q < 8; ++q)
+        x[r][e][q] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[r][e][q], SKD_L2E, nm[r]));     // 0 outside the matrix
+      s[r] += ((x[r][e][0] + x[r][e][1]) + (x[r][e][2] + x[r][e][3])) + ((x[r][e][4] + x[r][e][5]) + (x[r][e][6] + x[r][e][7]));
     }
-    const float ed = __builtin_amdgcn_exp2f(__builtin_fmaf(xd, SKD_L2E, nm));      // dustbin column entry
-    s = wave_sum_dpp(s) + ed;
-    if (lane == 0 && live)                                                          // sinkhorn.py:139
-      u[(size_t)b * (n + 1) + i] = (nm - __builtin_amdgcn_logf(s)) * SKD_LN2 - ci;
-    const float wgt = live ? __builtin_amdgcn_rcpf(s) : 0.0f;
+    ed[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(xd[r], SKD_L2E, nm[r]));                     // dustbin column entry
+  }
+  if constexpr (RW == 4) {
+    wave_sum4(s);
+  } else {
+#pragma unroll
+    for (int r = 0; r < RW; ++r) s[r] = wave_sum_dpp(s[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const float st = s[r] + ed[r];
+    if (lane == 0 && live[r])                                                       // sinkhorn.py:139
+      u[(size_t)b * (n + 1) + row0 + r] = (nm[r] - __builtin_amdgcn_logf(st)) * SKD_LN2 - ci[r];
+    const float wgt = live[r] ? __builtin_amdgcn_rcpf(st) : 0.0f;
 #pragma unroll
     for (int e = 0; e < E8; ++e)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) colsum[e][q] = __builtin_fmaf(x[e][q], wgt, colsum[e][q]);   // += P_ij
-    dustcol = __builtin_fmaf(ed, wgt, dustcol);
+      for (int q = 0; q < 8; ++q) colsum[e][q] = __builtin_fmaf(x[r][e][q], wgt, colsum[e][q]);   // += P_ij
+    dustcol = __builtin_fmaf(ed[r], wgt, dustcol);
   }
 #pragma unroll
   for (int e = 0; e < E8; ++e)
