@@ -75,7 +75,7 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 __device__ __forceinline__ float mi_readlane_f(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
-__device__ __forceinline__ void wave_max4(float (&v)[4]) {
+__device__ __forceinline__ void wave_max4(float *v) {     // v[0..3], registers
   float a0, a1, b0, b1, c0, c1;
   MI_SWAP32(v[0], v[1], a0, a1);                 // [v0.lo | v1.lo], [v0.hi | v1.hi]
   MI_SWAP32(v[2], v[3], b0, b1);
@@ -91,7 +91,7 @@ __device__ __forceinline__ void wave_max4(float (&v)[4]) {
   v[1] = mi_readlane_f(m, 32);
   v[3] = mi_readlane_f(m, 48);
 }
-__device__ __forceinline__ void wave_sum4(float (&v)[4]) {
+__device__ __forceinline__ void wave_sum4(float *v) {
   float a0, a1, b0, b1, c0, c1;
   MI_SWAP32(v[0], v[1], a0, a1);
   MI_SWAP32(v[2], v[3], b0, b1);

@@ -173,8 +173,9 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
                                  fmaxf(fmaxf(x[r][e][4], x[r][e][5]), fmaxf(x[r][e][6], x[r][e][7]))));
     }
   }
-  if constexpr (RW == 4) {
-    wave_max4(mx);
+  if constexpr (RW % 4 == 0) {
+#pragma unroll
+    for (int r = 0; r < RW; r += 4) wave_max4(mx + r);
   } else {
 #pragma unroll
     for (int r = 0; r < RW; ++r) mx[r] = wave_max_dpp(mx[r]);
@@ -195,8 +196,9 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
     }
     ed[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(xd[r], SKD_L2E, nm[r]));                     // dustbin column entry
   }
-  if constexpr (RW == 4) {
-    wave_sum4(s);
+  if constexpr (RW % 4 == 0) {
+#pragma unroll
+    for (int r = 0; r < RW; r += 4) wave_sum4(s + r);
   } else {
 #pragma unroll
     for (int r = 0; r < RW; ++r) s[r] = wave_sum_dpp(s[r]);
@@ -295,7 +297,7 @@ void launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int b
   }
 }
 
-int dots_rows_per_band(int m) { return m <= 512 ? 32 : (m <= 1024 ? 16 : 0); }
+int dots_rows_per_band(int m) { return m <= 512 ? 32 : (m <= 1024 ? 16 : 0); }   // 8 rows per wave measured slower
 
 // workspace: band partials (one float per column per band), then the padded per-column arrays wp, tp
 size_t dots_partials_bytes(int batch, int n, int m, int band) {
