@@ -16,8 +16,18 @@ dst = os.path.join(ROOT, "profiles")
 
 
 def short(name):
+    """kernel name without namespaces and argument list (template arguments kept)"""
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    return name.split("(")[0]
+    depth, out = 0, []
+    for ch in name:
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            break
+        out.append(ch)
+    return "".join(out).replace(", ", ",")
 
 
 line = open(os.path.join(SRC, "bench.json")).read().strip().splitlines()[-1]
@@ -29,7 +39,7 @@ with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-pairs 0   "
             "(1 x MI355X, 256 pairs/step)\n# name, calls, total_ms, avg_us, pct\n")
     for name, calls, total, avg, pct in db.execute("select * from top_kernels"):
-        f.write(f"{name[:140]}, {calls}, {total / 1e3:.3f}, {avg:.2f}, {pct:.2f}\n")
+        f.write(f"{short(name)}, {calls}, {total / 1e3:.3f}, {avg:.2f}, {pct:.2f}\n")
 
 traffic = collections.defaultdict(dict)
 for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
