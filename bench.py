@@ -161,6 +161,11 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if not os.path.exists(_native.LIB_PATH) and local == 0:      # a checkout without the (git-ignored) build product
+        from onnx_image_processing_amd.build import build
+        build(verbose=False)
+    if world > 1:
+        dist.barrier()
     _native.load()
 
     B = args.pairs_per_gpu
