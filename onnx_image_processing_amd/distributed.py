@@ -14,6 +14,7 @@ import torch
 import torch.distributed as dist
 
 RECORD_FIELDS = 6  # y1, x1, y2, x2, score, valid
+_use_all_gather = False
 
 
 def env_world() -> tuple[int, int, int]:
@@ -62,9 +63,17 @@ def gather_records(rec: torch.Tensor, dst: int = 0) -> torch.Tensor | None:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return rec
     world, rank = dist.get_world_size(), dist.get_rank()
-    out = [torch.empty_like(rec) for _ in range(world)] if rank == dst else None
-    dist.gather(rec, out, dst=dst)
-    return torch.cat(out, dim=0) if rank == dst else None
+    global _use_all_gather
+    if not _use_all_gather:
+        try:
+            out = [torch.empty_like(rec) for _ in range(world)] if rank == dst else None
+            dist.gather(rec, out, dst=dst)
+            return torch.cat(out, dim=0) if rank == dst else None
+        except RuntimeError:                      # a backend without gather: every rank takes all slabs instead
+            _use_all_gather = True
+    full = torch.empty((world,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(full, rec)
+    return full.reshape((-1,) + tuple(rec.shape[1:])) if rank == dst else None
 
 
 def barrier_max_ms(elapsed_ms: float, device: torch.device | str) -> float:
