@@ -92,9 +92,13 @@ def side_workload(args, rank, world, dev) -> None:
         what = "Shi-Tomasi sparse pipeline, 1920x1080, K=1024 (BASELINE configs[2])"
     else:
         h, w, k = H, W, K
-        cfg = {kk: v for kk, v in CFG.items() if kk != "block_size"}
+        # export_akaze_sparse_bad_sinkhorn.py defaults: 256 pairs, no binarisation, NMS radius 3
+        cfg = dict(num_pairs=256, binarize=False, sinkhorn_iterations=20, epsilon=0.05, unused_score=1.0,
+                   distance_type="l2", nms_radius=3, score_threshold=0.0, normalize_descriptors=True,
+                   sampling_mode="nearest")
         base = AKAZESparseBADSinkhornMatcher(max_keypoints=k, **cfg)
-        what = "AKAZE(3 scales x 3 steps) + oriented sparse BAD + Sinkhorn, 640x480, K=512 (BASELINE configs[3])"
+        what = ("AKAZE(3 scales x 3 steps) + oriented sparse BAD(256, raw) + Sinkhorn(20, eps 0.05), 640x480, K=512 "
+                "(BASELINE configs[3], AKAZE export-CLI values)")
     begin, _ = D.shard_range(B * world, rank, world)
     a, b = synth_batch(1000 + begin, B, h, w)
     img1, img2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
