@@ -247,6 +247,101 @@ __global__ __launch_bounds__(256) void cost_f32_kernel(const float *__restrict__
   }
 }
 
+// L2, d % 4 == 0: 128x128 tile, each of the 4 waves owns 64x64 of it as 2x2 MFMA tiles (one LDS fragment
+// read per MFMA instead of two), 16-byte staging loads with the next k-slab's loads in flight during the
+// MFMAs of the current one.  Same arithmetic as cost_f32_kernel (fp32 fma chain over k in the MFMA).
+constexpr int CG_T = 128, CG_K = 32, CG_P = CG_K + 1;
+
+__global__ __launch_bounds__(256) void cost_f32_big_kernel(const float *__restrict__ d1, const float *__restrict__ d2,
+                                                           int n, int m, int d, float eps, float *__restrict__ z,
+                                                           int pitch) {
+  __shared__ float sa[CG_T * CG_P];
+  __shared__ float sb[CG_T * CG_P];
+  __shared__ float nrm_a[CG_T], nrm_b[CG_T];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int j0 = blockIdx.x * CG_T, i0 = blockIdx.y * CG_T, b = blockIdx.z;
+  const float *a_g = d1 + (size_t)b * n * d;
+  const float *b_g = d2 + (size_t)b * m * d;
+  const int srow = t >> 3, sk = (t & 7) * 4;            // staging: one float4 of rows srow, +32, +64, +96
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  v16f acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+  float ssa[4] = {0.f, 0.f, 0.f, 0.f}, ssb[4] = {0.f, 0.f, 0.f, 0.f};
+
+  auto fetch = [&](int k0, float4 (&va)[4], float4 (&vb)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = srow + 32 * q, kk = k0 + sk;
+      va[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      vb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i0 + r < n && kk < d) va[q] = *reinterpret_cast<const float4 *>(a_g + (size_t)(i0 + r) * d + kk);
+      if (j0 + r < m && kk < d) vb[q] = *reinterpret_cast<const float4 *>(b_g + (size_t)(j0 + r) * d + kk);
+    }
+  };
+  float4 va[4], vb[4], na[4], nb[4];
+  fetch(0, va, vb);
+  for (int k0 = 0; k0 < d; k0 += CG_K) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float *pa = sa + (srow + 32 * q) * CG_P + sk, *pb = sb + (srow + 32 * q) * CG_P + sk;
+      pa[0] = va[q].x; pa[1] = va[q].y; pa[2] = va[q].z; pa[3] = va[q].w;
+      pb[0] = vb[q].x; pb[1] = vb[q].y; pb[2] = vb[q].z; pb[3] = vb[q].w;
+      ssa[q] += (va[q].x * va[q].x + va[q].y * va[q].y) + (va[q].z * va[q].z + va[q].w * va[q].w);
+      ssb[q] += (vb[q].x * vb[q].x + vb[q].y * vb[q].y) + (vb[q].z * vb[q].z + vb[q].w * vb[q].w);
+    }
+    __syncthreads();
+    if (k0 + CG_K < d) fetch(k0 + CG_K, na, nb);        // in flight during the MFMAs below
+#pragma unroll
+    for (int kk = 0; kk < CG_K; kk += 2) {
+      float fa[2], fb[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        fa[q] = sa[(wm + q * 32 + lr) * CG_P + kk + lh];
+        fb[q] = sb[(wn + q * 32 + lr) * CG_P + kk + lh];
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { va[q] = na[q]; vb[q] = nb[q]; }
+  }
+  // squared norms: the 8 staging threads of a row hold partial sums
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float x = ssa[q], y = ssb[q];
+    x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64);
+    y += __shfl_xor(y, 1, 64); y += __shfl_xor(y, 2, 64); y += __shfl_xor(y, 4, 64);
+    if ((t & 7) == 0) { nrm_a[srow + 32 * q] = x; nrm_b[srow + 32 * q] = y; }
+  }
+  __syncthreads();
+  float *zb = z + (size_t)b * (size_t)n * pitch;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int rl = wm + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int cl = wn + ni * 32 + lr;
+        const int gi = i0 + rl, gj = j0 + cl;
+        if (gi < n && gj < m) {
+          const float cost = fmaxf((nrm_a[rl] + nrm_b[cl]) - 2.0f * acc[mi][ni][e], 0.0f);     // sinkhorn.py:101-103
+          zb[(size_t)gi * pitch + gj] = -cost / eps;                                           // :178
+        }
+      }
+}
+
 int check_z(const void *a, const void *b, const void *z, int batch, int n, int m, int pitch, double eps) {
   if (!a || !b || !z) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
@@ -298,6 +393,11 @@ extern "C" int mi_cost_logscores_f32(const float *desc1, const float *desc2, int
   if (d <= 0) return MI_E_SHAPE;
   dim3 grid(ceil_div(m, CF_T), ceil_div(n, CF_T), batch);
   const float eps = (float)epsilon;
+  if (distance == MI_DIST_L2 && d % 4 == 0 && (((uintptr_t)desc1 | (uintptr_t)desc2) % 16) == 0 && n >= 64 && m >= 64) {
+    dim3 big(ceil_div(m, CG_T), ceil_div(n, CG_T), batch);
+    hipLaunchKernelGGL(cost_f32_big_kernel, big, dim3(256), 0, (hipStream_t)stream, desc1, desc2, n, m, d, eps, z, pitch);
+    return mi_launch_status();
+  }
   if (distance == MI_DIST_L2)
     hipLaunchKernelGGL(cost_f32_kernel<MI_DIST_L2>, grid, dim3(256), 0, (hipStream_t)stream, desc1, desc2, n,
                        m, d, eps, z, pitch);
