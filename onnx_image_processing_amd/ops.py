@@ -292,10 +292,10 @@ def sinkhorn_bits(bits1: torch.Tensor, bits2: torch.Tensor, normalized: bool, ep
 def match_filters(p: torch.Tensor, ratio_threshold: float, dustbin_margin: float):
     """In-place outlier filters on P (B,N+1,M+1) -> (P, valid (B,N) bool)."""
     b, n1, m1 = p.shape
-    valid = torch.empty((b, n1 - 1), dtype=torch.uint8, device=p.device)
+    valid = torch.empty((b, n1 - 1), dtype=torch.bool, device=p.device)       # the kernel writes 0/1 bytes
     N.call("mi_match_filters", N.dev(p, F32, "P"), b, n1 - 1, m1 - 1, float(ratio_threshold), float(dustbin_margin),
            valid.data_ptr(), N.stream_ptr())
-    return p, valid.bool()
+    return p, valid
 
 
 def mnn_extract(p: torch.Tensor, kpts1: torch.Tensor, kpts2: torch.Tensor, max_matches: int, threshold: float,
@@ -314,18 +314,18 @@ def mnn_extract(p: torch.Tensor, kpts1: torch.Tensor, kpts2: torch.Tensor, max_m
     mk1 = torch.empty((b, max_matches, 2), dtype=F32, device=dev)
     mk2 = torch.empty((b, max_matches, 2), dtype=F32, device=dev)
     sc = torch.empty((b, max_matches), dtype=F32, device=dev)
-    valid = torch.empty((b, max_matches), dtype=torch.uint8, device=dev)
+    valid = torch.empty((b, max_matches), dtype=torch.bool, device=dev)          # the kernel writes 0/1 bytes
     ij = torch.empty((b, max_matches, 2), dtype=torch.int32, device=dev)
     N.call("mi_mnn_extract", N.dev(pp, F32, "P"), b, n, m, N.dev(k1, F32, "keypoints1"), N.dev(k2, F32, "keypoints2"),
            int(max_matches), float(threshold), row_best.data_ptr(), col_best.data_ptr(), mk1.data_ptr(),
            mk2.data_ptr(), sc.data_ptr(), valid.data_ptr(), ij.data_ptr(), N.stream_ptr())
-    out = (mk1, mk2, sc, valid.bool())
+    out = (mk1, mk2, sc, valid)
     return out + (ij,) if return_indices else out
 
 
 def _mnn_outputs(b, max_matches, dev):
     return (torch.empty((b, max_matches, 2), dtype=F32, device=dev), torch.empty((b, max_matches, 2), dtype=F32, device=dev),
-            torch.empty((b, max_matches), dtype=F32, device=dev), torch.empty((b, max_matches), dtype=torch.uint8, device=dev),
+            torch.empty((b, max_matches), dtype=F32, device=dev), torch.empty((b, max_matches), dtype=torch.bool, device=dev),
             torch.empty((b, max_matches, 2), dtype=torch.int32, device=dev))
 
 
@@ -347,7 +347,7 @@ def mnn_from_duals(z: torch.Tensor, m: int, pitch: int, u: torch.Tensor, v: torc
            N.dev(k1, F32, "keypoints1"), N.dev(k2, F32, "keypoints2"), int(max_matches), float(threshold),
            work.data_ptr(), wbytes, mk1.data_ptr(), mk2.data_ptr(), sc.data_ptr(), valid.data_ptr(), ij.data_ptr(),
            N.stream_ptr())
-    out = (mk1, mk2, sc, valid.bool())
+    out = (mk1, mk2, sc, valid)
     return out + (ij,) if return_indices else out
 
 
@@ -365,7 +365,7 @@ def mnn_from_duals_dots(state, m: int, epsilon: float, u: torch.Tensor, v: torch
            float(epsilon), N.dev(u, F32, "u"), N.dev(v, F32, "v"), N.dev(k1, F32, "keypoints1"),
            N.dev(k2, F32, "keypoints2"), int(max_matches), float(threshold), work.data_ptr(), wbytes, mk1.data_ptr(),
            mk2.data_ptr(), sc.data_ptr(), valid.data_ptr(), ij.data_ptr(), N.stream_ptr())
-    out = (mk1, mk2, sc, valid.bool())
+    out = (mk1, mk2, sc, valid)
     return out + (ij,) if return_indices else out
 
 

@@ -154,3 +154,16 @@ def test_synthetic_inputs_are_deterministic():
     assert x.shape == (2, 1, 32, 48) and x.dtype == np.float32 and np.abs(y[0, 0] - np.roll(x[0, 0], (3, 5), (0, 1))).max() <= 2
     import hashlib
     assert hashlib.sha256(synth_image(1000).tobytes()).hexdigest()[:16] == hashlib.sha256(a.tobytes()).hexdigest()[:16]
+
+
+def test_graft_entry_smoke_arguments_are_oracle_compatible():
+    """smoke() hands its hyper-parameters to the oracle: keep that call valid without a GPU."""
+    import inspect
+    import re
+
+    from oracle import numpy_oracle as O
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    cfg_src = re.search(r"cfg = dict\((.*?)\)\n", src, re.S).group(1)
+    keys = set(re.findall(r"(\w+)=", cfg_src)) - {"num_pairs"}
+    assert keys <= set(inspect.signature(O.match_pair).parameters), keys
+    assert 'if k != "num_pairs"' in src
