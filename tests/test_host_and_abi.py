@@ -167,3 +167,36 @@ def test_graft_entry_smoke_arguments_are_oracle_compatible():
     keys = set(re.findall(r"(\w+)=", cfg_src)) - {"num_pairs"}
     assert keys <= set(inspect.signature(O.match_pair).parameters), keys
     assert 'if k != "num_pairs"' in src
+
+
+def test_argument_validation_of_the_widened_entries(lib_path):
+    """Host-side MI_E_* checks of the later entry points (no launch happens: safe without a GPU)."""
+    lib = ctypes.CDLL(lib_path)
+    buf = ctypes.create_string_buffer(256)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    vp, ci, cf, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double
+    lib.mi_essential_matrix.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, ci, vp, vp]
+    assert lib.mi_essential_matrix(None, 1, 8, 8, p, p, None, None, 3, 30, 10, p, None) == -1       # NULL P
+    assert lib.mi_essential_matrix(p, 1, 8, 8, p, p, p, None, 3, 30, 10, p, None) == -1             # one validity mask only
+    assert lib.mi_essential_matrix(p, 1, 2000, 8, p, p, None, None, 3, 30, 10, p, None) == -3       # n > 1024
+    assert lib.mi_essential_matrix(p, 1, 8, 8, p, p, None, None, 9, 30, 10, p, None) == -3          # top_k > 8
+    assert lib.mi_essential_matrix(p, 1, 2, 8, p, p, None, None, 3, 30, 10, p, None) == -3          # top_k > n
+    lib.mi_mnn_duals_workspace_bytes.restype = ctypes.c_size_t
+    lib.mi_mnn_duals_workspace_bytes.argtypes = [ci, ci, ci]
+    assert lib.mi_mnn_duals_workspace_bytes(2, 512, 512) == (2 * 512 + 2 * 512 + 2 * 16 * 512) * 8
+    assert lib.mi_mnn_duals_workspace_bytes(2, 512, 2000) == 0                                       # m > 1024: unsupported
+    lib.mi_mnn_from_duals.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp, ci, cf, vp, ctypes.c_size_t, vp, vp, vp, vp, vp, vp]
+    assert lib.mi_mnn_from_duals(None, 1, 8, 8, 8, p, p, p, p, 4, 0.1, p, 4096, p, p, p, p, None, None) == -1
+    assert lib.mi_mnn_from_duals(p, 1, 8, 8, 6, p, p, p, p, 4, 0.1, p, 4096, p, p, p, p, None, None) == -5    # pitch < m
+    assert lib.mi_mnn_from_duals(p, 1, 8, 8, 8, p, p, p, p, 4, 0.1, p, 8, p, p, p, p, None, None) == -4       # workspace too small
+    lib.mi_akaze_diffuse.argtypes = [vp, ci, ci, ci, cf, cf, vp, vp]
+    assert lib.mi_akaze_diffuse(p, 1, 8, 8, 0.05, 0.25, p, None) == -1                               # in place is refused
+    lib.mi_akaze_hessian_scores.argtypes = [vp, ci, ci, ci, cf, ci, vp, vp]
+    assert lib.mi_akaze_hessian_scores(p, 1, 8, 8, 0.001, 4, p, None) == -3                          # even NMS window
+    lib.mi_dog_responses.argtypes = [vp, ci, ci, ci, vp, ci, ci, vp, vp, vp]
+    assert lib.mi_dog_responses(p, 1, 8, 8, p, 1, 9, p, None, None) == -3                            # fewer than 2 scales
+    assert lib.mi_dog_responses(p, 1, 8, 8, p, 3, 8, p, None, None) == -3                            # even kernel
+    assert lib.mi_dog_responses(p, 1, 8, 8, p, 3, 9, None, None, None) == -1                         # no output at all
+    lib.mi_sparse_bad_oriented.argtypes = [vp, ci, ci, ci, vp, ci, vp, vp, vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, vp]
+    assert lib.mi_sparse_bad_oriented(p, 1, 64, 64, p, 4, p, p, p, p, 256, 2, 10.0, 1, 0, p, None, None, None) == -1   # two angle sources
+    assert lib.mi_sparse_bad_oriented(p, 1, 64, 64, p, 4, p, None, p, p, 100, 2, 10.0, 1, 0, p, None, None, None) == -3  # pairs % 64
