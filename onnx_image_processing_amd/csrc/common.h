@@ -108,6 +108,13 @@ __device__ __forceinline__ void wave_sum4(float *v) {
   v[3] = mi_readlane_f(m, 48);
 }
 
+// P = exp(log P) of the final assignment matrix (reference matching/sinkhorn.py:145,206), ONE definition
+// shared by K6's final pass and K7's matches-from-duals so that both produce the same bits:
+// v_exp_f32(t * log2 e).  Relative error <= 1 ulp + |t| * 2^-24 (the rounding of the scaled argument),
+// i.e. < 1e-6 for every |t| that yields a representable P -- two orders inside the 1e-4 parity bound --
+// at 3 instructions instead of libm's ~20.
+__device__ __forceinline__ float mi_prob_exp(float t) { return __builtin_amdgcn_exp2f(t * 1.4426950408889634f); }
+
 // log-score of the packed-descriptor (uint16 dot product) form, shared by K6 and K7 so that both
 // rebuild the same bits: z = nie*(na + nb) + dot*sb*(-2*nie*sa), nie = -1/epsilon, (scale, squared
 // norm) pairs per descriptor (reference matching/sinkhorn.py:101-103,178; the cost's clamp at 0 only

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(MX_THREADS) void mnn_select_kernel(
 }
 
 // ---- mutual-NN straight from the Sinkhorn duals: P is never written ------------------------------
-// P_ij = expf((z_ij + u_i) + v_j) is evaluated in registers with the very expression K6's final pass
+// P_ij = mi_prob_exp((z_ij + u_i) + v_j) is evaluated in registers with the very expression K6's final pass
 // uses, so row/column winners (and their scores) are bit-identical to running mi_sinkhorn with a P
 // buffer followed by mi_mnn_extract.  One pass over the log-scores instead of a write and two reads
 // of P.  A workgroup owns a band of NW*RW rows (a wave holds RW whole rows, 8 consecutive columns
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * NW) void mnn_band_kernel(SRC src, int n, int m
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int j = e * 512 + lane * 8 + q;
-        float p = expf((x[q] + ui) + vv[e][q]);                         // sinkhorn.py:145,206
+        float p = mi_prob_exp((x[q] + ui) + vv[e][q]);                         // sinkhorn.py:145,206
         p = (live && j < m) ? p : -1.0f;
         if (p > rbest) { rbest = p; rj = j; }
         if (p > cbest[e][q]) { cbest[e][q] = p; cidx[e][q] = i; }

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void sk_exp_kernel(const float *__restrict__ z
   float *pr = p + ((size_t)b * (n + 1) + i) * (size_t)(m + 1);
   for (int j = lane; j <= m; j += 64) {
     const float zz = (i < n && j < m) ? zr[j] : dust;
-    pr[j] = expf((zz + ui) + vb[j]);                         // sinkhorn.py:145,206
+    pr[j] = mi_prob_exp((zz + ui) + vb[j]);                         // sinkhorn.py:145,206
   }
 }
 

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void sk_exp_dots_kernel(const uint16_t *__rest
   for (int j = lane; j <= m; j += 64) {
     float zz = zp.dust;
     if (i < n && j < m) zz = z_of((float)dr[j], ri, col_info[(size_t)b * m + j], zp.neg_inv_eps);
-    pr[j] = expf((zz + ui) + vb[j]);                         // sinkhorn.py:145,206
+    pr[j] = mi_prob_exp((zz + ui) + vb[j]);                         // sinkhorn.py:145,206
   }
 }
 
