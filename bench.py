@@ -240,6 +240,15 @@ def main() -> None:
                          "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": k1_bytes,
                          "ms_per_launch": k1_ms},
             "kernels": kernels,
+            # informational: the other bandwidth-type stages by their algorithmic bytes
+            "roofline_other": {
+                "mi_nms_candidates": {"bytes_per_call": 4.0 * B * H * W, "unit": "GB/s",
+                                      "achieved": 4.0 * B * H * W / (float(np.mean(per_call["mi_nms_candidates"])) * 1e-3) / 1e9},
+                "mi_sinkhorn_dots (per iteration, 2 B/element)": {
+                    "bytes_per_call": 2.0 * B * K * K * CFG["sinkhorn_iterations"], "unit": "GB/s",
+                    "achieved": 2.0 * B * K * K * CFG["sinkhorn_iterations"]
+                    / (float(np.mean(per_call["mi_sinkhorn_dots"])) * 1e-3) / 1e9} if "mi_sinkhorn_dots" in per_call else None,
+            },
         }
         if world == 1 and args.cpu_pairs > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
