@@ -842,3 +842,23 @@ def test_hipgraph_replay_equals_eager(mods):
         assert torch.equal(x, y)
     with pytest.raises(RuntimeError):
         graphed(gpu(a[:, :, :50]), gpu(b))
+
+
+@pytest.mark.parametrize("h,w", [(97, 131), (64, 70), (33, 45)])
+def test_odd_image_sizes_vs_oracle(mods, h, w):
+    """Widths that are not a multiple of 4 take the generic corner / NMS kernels; keypoints near every border."""
+    a, b = synth_batch(4100 + h, 2, h, w)
+    sc = O.shi_tomasi_score(a, 3)[:, 0]
+    for r in (2, 5):
+        assert np.array_equal(mods["apply_nms_maxpool"](gpu(sc), r).cpu().numpy(), O.nms_mask(sc, r))
+    cfg = dict(block_size=3, num_pairs=256, binarize=True, soft_binarize=False, sinkhorn_iterations=8, epsilon=0.1,
+               nms_radius=2, border_margin=0)
+    k = 40
+    model = mods["ShiTomasiSparseBADSinkhornMatcher"](max_keypoints=k, **cfg).to(DEV)
+    k1, k2, p = [t.cpu().numpy() for t in model(gpu(a), gpu(b))]
+    box, thr = bad_tables(256)
+    kw = {kk: v for kk, v in cfg.items() if kk != "num_pairs"}
+    o1, o2, op = O.match_pair(a, b, box, thr, k, **kw)
+    assert np.array_equal(k1, o1) and np.array_equal(k2, o2)
+    ok, worst = p_close(p, op)
+    assert ok, worst
