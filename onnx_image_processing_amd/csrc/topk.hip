@@ -5,8 +5,9 @@
 // score descending, then linear index ascending -- independent of how K2 ordered them.
 //
 // Input: the segmented candidate buffer of K2 (one segment per 128x32 tile, count per
-// segment).  One 1024-thread workgroup per image; each of its 16 waves walks whole segments.
-// Up to 4096 candidates are gathered into LDS and bitonic-sorted directly.  Longer lists
+// segment).  One 1024-thread workgroup per image.  Up to 4096 candidates are gathered into LDS
+// (slot ranges handed out by one LDS atomic per segment up front, four segments' loads in flight
+// per wave) and bitonic-sorted, with the keys in registers when the padded count is exactly 4096.  Longer lists
 // (plateau images can make every pixel a candidate) first run an exact 8-pass MSB radix select
 // for the k-th largest key straight from global memory, then sort only the k survivors.
 #include "common.h"
@@ -16,6 +17,7 @@ namespace {
 constexpr int TK_THREADS = 1024;
 constexpr int TK_WAVES = TK_THREADS / 64;
 constexpr int TK_MAX = 4096;
+constexpr int TK_SEGS = 1024;        // segments with a slot-table entry (1920x1080 has 510)
 
 __device__ __forceinline__ void bitonic_sort_desc(uint64_t *keys, int npad, int t) {
   for (int size = 2; size <= npad; size <<= 1) {
@@ -35,12 +37,90 @@ __device__ __forceinline__ void bitonic_sort_desc(uint64_t *keys, int npad, int 
   }
 }
 
+// The same network for exactly TK_MAX = 4 * TK_THREADS keys with the keys in registers: thread t owns
+// elements 4t..4t+3, so strides 1-2 are register swaps, strides 4-128 are wave shuffles (partner lane =
+// lane ^ stride/4) and only strides >= 256 -- 10 of the 78 stages -- go through LDS, ping-ponging two
+// buffers so that each needs a single barrier.  Identical result to bitonic_sort_desc (same network).
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_stage_4096(uint64_t (&r)[4], uint64_t *keys, uint64_t *keys2, int t, int &flip) {
+  if constexpr (STRIDE < 4) {                        // partner in the same thread
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if ((j ^ STRIDE) > j) {
+        const bool desc = (((t * 4 + j) & SIZE) == 0);
+        const uint64_t a = r[j], b = r[j ^ STRIDE];
+        const bool sw = (a < b) == desc;
+        r[j] = sw ? b : a;
+        r[j ^ STRIDE] = sw ? a : b;
+      }
+    }
+  } else {
+    uint64_t other[4];
+    if constexpr (STRIDE < 256) {                    // partner lane in the same wave
+#pragma unroll
+      for (int j = 0; j < 4; ++j) other[j] = __shfl_xor(r[j], STRIDE >> 2, 64);
+    } else {                                         // partner in another wave: through LDS, buffers alternate
+      uint64_t *buf = flip ? keys2 : keys;
+      flip ^= 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) buf[t * 4 + j] = r[j];
+      __syncthreads();
+      const int pt = t ^ (STRIDE >> 2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) other[j] = buf[pt * 4 + j];
+    }
+    const bool lower = (t & (STRIDE >> 2)) == 0;     // this element is the lower index of its pair
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool desc = (((t * 4 + j) & SIZE) == 0);
+      const bool gt = r[j] > other[j];
+      const uint64_t mx = gt ? r[j] : other[j], mn = gt ? other[j] : r[j];
+      r[j] = (lower == desc) ? mx : mn;
+    }
+  }
+}
+
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_merge_4096(uint64_t (&r)[4], uint64_t *keys, uint64_t *keys2, int t, int &flip) {
+  if constexpr (STRIDE >= 1) {
+    bitonic_stage_4096<SIZE, STRIDE>(r, keys, keys2, t, flip);
+    bitonic_merge_4096<SIZE, STRIDE / 2>(r, keys, keys2, t, flip);
+  }
+}
+
+template <int SIZE>
+__device__ __forceinline__ void bitonic_levels_4096(uint64_t (&r)[4], uint64_t *keys, uint64_t *keys2, int t, int &flip) {
+  if constexpr (SIZE <= TK_MAX) {
+    bitonic_merge_4096<SIZE, SIZE / 2>(r, keys, keys2, t, flip);
+    bitonic_levels_4096<SIZE * 2>(r, keys, keys2, t, flip);
+  }
+}
+
+// The same network for exactly TK_MAX = 4 * TK_THREADS keys with the keys in registers (every stage a
+// compile-time instance, so the four keys stay in VGPRs): thread t owns elements 4t..4t+3, strides 1-2 are
+// register swaps, strides 4-128 wave shuffles (partner lane = lane ^ stride/4) and only strides >= 256 --
+// 10 of the 78 stages -- go through LDS, ping-ponging two buffers so that each needs a single barrier.
+// Identical result to bitonic_sort_desc (same network).
+__device__ __forceinline__ void bitonic_sort_desc_4096(uint64_t *keys, uint64_t *keys2, int t) {
+  uint64_t r[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = keys[t * 4 + j];
+  int flip = 0;
+  bitonic_levels_4096<2>(r, keys, keys2, t, flip);
+  __syncthreads();                                          // the last LDS readers are done
+#pragma unroll
+  for (int j = 0; j < 4; ++j) keys[t * 4 + j] = r[j];
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__restrict__ cand,
                                                           const uint32_t *__restrict__ count, int segments,
                                                           uint32_t seg_cap, int w, int k,
                                                           float *__restrict__ kpts,
                                                           float *__restrict__ kscores) {
   __shared__ uint64_t keys[TK_MAX];
+  __shared__ uint64_t keys2[TK_MAX];      // second buffer of the register sort's cross-wave stages
+  __shared__ uint32_t seg_cnt[TK_SEGS], seg_base[TK_SEGS];
   __shared__ uint32_t hist[256];
   __shared__ uint32_t wsum[TK_WAVES];
   __shared__ uint64_t s_prefix;
@@ -51,21 +131,59 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
   const uint64_t *list = cand + (size_t)img * segments * seg_cap;
   const uint32_t *cnt = count + (size_t)img * segments;
 
-  // total number of candidates of this image
+  // total number of candidates of this image; with few enough segments each one also gets its slot range in
+  // the LDS key array right here (one LDS atomic per segment), so that the gather below has no dependent
+  // global load or atomic in front of its candidate loads
+  const bool slots = segments <= TK_SEGS;
   uint32_t part = 0;
-  for (int s = t; s < segments; s += TK_THREADS) part += min(cnt[s], seg_cap);
+  if (t == 0) s_fill = 0u;
+  __syncthreads();
+  for (int s = t; s < segments; s += TK_THREADS) {
+    const uint32_t c = min(cnt[s], seg_cap);
+    part += c;
+    if (slots) {
+      seg_cnt[s] = c;
+      seg_base[s] = c ? atomicAdd(&s_fill, c) : 0u;
+    }
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
   if (lane == 0) wsum[wave] = part;
-  if (t == 0) s_fill = 0u;
   __syncthreads();
   uint32_t n = 0;
 #pragma unroll
   for (int q = 0; q < TK_WAVES; ++q) n += wsum[q];
   int nsel;
 
-  if (n <= (uint32_t)TK_MAX) {
-    // gather every segment into LDS (order irrelevant: sorted next); one LDS atomic per segment
+  if (n <= (uint32_t)TK_MAX && slots) {
+    // gather: a wave takes four segments at a time, all their loads in flight before the first LDS store
+    for (int s0 = wave * 4; s0 < segments; s0 += TK_WAVES * 4) {
+      uint64_t v[4];
+      uint32_t c[4], base[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int sg = s0 + q;
+        c[q] = sg < segments ? seg_cnt[sg] : 0u;
+        base[q] = sg < segments ? seg_base[sg] : 0u;
+        v[q] = 0ull;
+        if ((uint32_t)lane < c[q]) v[q] = list[(size_t)sg * seg_cap + lane];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if ((uint32_t)lane < c[q]) keys[base[q] + lane] = v[q];
+        for (uint32_t i = 64 + lane; i < c[q]; i += 64) keys[base[q] + i] = list[(size_t)(s0 + q) * seg_cap + i];
+      }
+    }
+    int npad = 2;
+    while (npad < (int)n) npad <<= 1;
+    __syncthreads();
+    for (int i = (int)n + t; i < npad; i += TK_THREADS) keys[i] = 0ull;
+    __syncthreads();
+    if (npad == TK_MAX) bitonic_sort_desc_4096(keys, keys2, t);
+    else bitonic_sort_desc(keys, npad, t);
+    nsel = (int)n < k ? (int)n : k;
+  } else if (n <= (uint32_t)TK_MAX) {
+    // more segments than slot-table entries (very large images): a wave walks whole segments
     for (int s = wave; s < segments; s += TK_WAVES) {
       const uint32_t c = min(cnt[s], seg_cap);
       if (c == 0u) continue;
@@ -80,11 +198,12 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
     __syncthreads();
     for (int i = (int)n + t; i < npad; i += TK_THREADS) keys[i] = 0ull;
     __syncthreads();
-    bitonic_sort_desc(keys, npad, t);
+    if (npad == TK_MAX) bitonic_sort_desc_4096(keys, keys2, t);
+    else bitonic_sort_desc(keys, npad, t);
     nsel = (int)n < k ? (int)n : k;
   } else {
     // exact k-th largest key by MSB radix select (8 digits of 8 bits); n > TK_MAX >= k here
-    if (t == 0) { s_prefix = 0ull; s_krem = (uint32_t)k; }
+    if (t == 0) { s_prefix = 0ull; s_krem = (uint32_t)k; s_fill = 0u; }   // s_fill: the slot table may have used it
     uint64_t mask = 0ull;
     for (int shift = 56; shift >= 0; shift -= 8) {
       if (t < 256) hist[t] = 0u;
