@@ -124,7 +124,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
   __shared__ uint32_t hist[256];
   __shared__ uint32_t wsum[TK_WAVES];
   __shared__ uint64_t s_prefix;
-  __shared__ uint32_t s_krem, s_fill;
+  __shared__ uint32_t s_krem, s_fill, s_done;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int img = blockIdx.x;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
     nsel = (int)n < k ? (int)n : k;
   } else {
     // exact k-th largest key by MSB radix select (8 digits of 8 bits); n > TK_MAX >= k here
-    if (t == 0) { s_prefix = 0ull; s_krem = (uint32_t)k; s_fill = 0u; }   // s_fill: the slot table may have used it
+    if (t == 0) { s_prefix = 0ull; s_krem = (uint32_t)k; s_fill = 0u; s_done = 0u; }   // s_fill: the slot table may have used it
     uint64_t mask = 0ull;
     for (int shift = 56; shift >= 0; shift -= 8) {
       if (t < 256) hist[t] = 0u;
@@ -252,6 +252,9 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
             if (krem <= above + c[q]) {
               s_prefix = prefix | ((uint64_t)(255 - 4 * t - q) << shift);
               s_krem = krem - above;
+              // the whole bin is wanted: every key with this prefix (low bits anything) is among the k largest,
+              // so the prefix itself is the threshold and the remaining digits need no pass
+              if (krem - above == c[q]) s_done = 1u;
               break;
             }
             above += c[q];
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
       }
       mask |= (0xFFull << shift);
       __syncthreads();
+      if (s_done) break;                // workgroup-uniform
     }
     const uint64_t kth = s_prefix;   // keys are distinct: exactly k keys are >= kth
     for (int s = wave; s < segments; s += TK_WAVES) {
