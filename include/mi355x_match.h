@@ -46,6 +46,7 @@ const char *mi_error_string(int code);
 /* Development/test hook: choose between equivalent kernel implementations (results are
  * identical).  key 1: corner response, 0 = streaming LDS-DMA kernel (default), 1 = register-
  * staged tile kernel.  key 2: rows per thread of the streaming corner kernel (4, 5 or 8).
+ * key 6: number of batch parts mi_sinkhorn_dots runs on separate streams (1..4, default 2).
  * key 4: Sinkhorn band kernel, 0 = probability form, lean instruction stream (default), 2 = first
  * probability-form kernel, 1 = log-domain (max,sum) partials (results agree to fp32 rounding). */
 int mi_debug_set(int key, int value);

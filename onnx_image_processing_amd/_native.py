@@ -92,6 +92,11 @@ def load() -> ctypes.CDLL:
             fn = getattr(lib, name)            # AttributeError if the ABI and the binding diverge
             fn.argtypes = argtypes
             fn.restype = _RESTYPE.get(name, c_int)
+        # development hook: MI_DEBUG_SET="key=value,key=value" selects between equivalent kernel implementations
+        for item in filter(None, os.environ.get("MI_DEBUG_SET", "").split(",")):
+            key, value = item.split("=")
+            if lib.mi_debug_set(int(key), int(value)) != 0:
+                raise RuntimeError(f"MI_DEBUG_SET: mi_debug_set({key}, {value}) was refused")
         _lib = lib
     return _lib
 

@@ -14,6 +14,9 @@
 
 #include <math.h>
 
+// test hook (mi_debug_set key 6): number of batch parts run on separate streams (1 = one stream)
+int mi_g_sinkhorn_split = 2;           // whole bench step: 1.88 / 1.82 / 1.92 ms with 1 / 2 / 3 parts of 256 pairs
+
 namespace {
 
 __device__ __forceinline__ float sk_exp(float d) { return __builtin_amdgcn_exp2f(d * 1.4426950408889634f); }
@@ -280,6 +283,25 @@ __global__ __launch_bounds__(256) void sk_exp_dots_kernel(const uint16_t *__rest
   }
 }
 
+// helper streams for the split schedule below (created once; fork/join by events, so the caller's
+// stream semantics are unchanged: everything is ordered after earlier work on `s` and before later work)
+constexpr int SK_MAX_PARTS = 4;
+struct ForkJoin {
+  hipStream_t side[SK_MAX_PARTS - 1] = {};
+  hipEvent_t fork = nullptr, join[SK_MAX_PARTS - 1] = {};
+  bool ok = false;
+  ForkJoin() {
+    ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < SK_MAX_PARTS - 1; ++i)
+      ok = ok && hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&join[i], hipEventDisableTiming) == hipSuccess;
+  }
+};
+ForkJoin &fork_join() {
+  static ForkJoin fj;
+  return fj;
+}
+
 template <int E8, int RW, int NW>
 void launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int batch, int n, int m, int pitch,
                  ZParams zp, int iterations, float *u, float *v, float *part, float *wp, float *tp, float log_m,
@@ -288,12 +310,38 @@ void launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int b
   constexpr int CP = 512 * E8;    // padded column count of wp / tp
   hipLaunchKernelGGL(sk_dots_init_kernel, dim3(ceil_div(CP, 256), batch), dim3(256), 0, s, ci, m, CP, zp.neg_inv_eps,
                      wp, tp);
+  // An iteration is a big row kernel and a tiny column kernel that depend on each other, so between them
+  // the GPU drains and refills (about 5 us per iteration).  With enough pairs the batch is cut into parts
+  // on separate streams: while one part is in its column kernel / launch gap another part's row kernel
+  // keeps the CUs busy.  The parts are independent problems, so results do not change.
+  ForkJoin &fj = fork_join();
+  int parts = mi_g_sinkhorn_split;
+  if (parts > SK_MAX_PARTS) parts = SK_MAX_PARTS;
+  if (parts < 1 || !fj.ok || batch < 32 * parts) parts = 1;
+  if (parts > 1) {
+    (void)hipEventRecord(fj.fork, s);
+    for (int q = 1; q < parts; ++q) (void)hipStreamWaitEvent(fj.side[q - 1], fj.fork, 0);
+  }
+  // enqueue iteration by iteration so that no stream runs far ahead of the others
   for (int it = 0; it < iterations; ++it) {
     const int vz = it == 0 ? 1 : 0;
-    hipLaunchKernelGGL((sk_band_dots_kernel<E8, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, dots, n, m, pitch,
-                       ri, zp, v, u, part, log_m, vz, wp, tp, CP);
-    hipLaunchKernelGGL(sk_vcombine_dots_kernel, dim3(ceil_div(m + 1, 256), batch), dim3(256), 0, s, part, m, nb + 1,
-                       v, log_n, vz, ci, zp.neg_inv_eps, wp, CP);
+    for (int q = 0; q < parts; ++q) {
+      const int b0 = (int)((long long)batch * q / parts), nbatch = (int)((long long)batch * (q + 1) / parts) - b0;
+      hipStream_t st = q ? fj.side[q - 1] : s;
+      const uint16_t *d0 = dots + (size_t)b0 * n * pitch;
+      const float2 *ri0 = ri + (size_t)b0 * n, *ci0 = ci + (size_t)b0 * m;
+      float *u0 = u + (size_t)b0 * (n + 1), *v0 = v + (size_t)b0 * (m + 1);
+      float *part0 = part + (size_t)b0 * (nb + 1) * (size_t)(m + 1);
+      float *wp0 = wp + (size_t)b0 * CP, *tp0 = tp + (size_t)b0 * CP;
+      hipLaunchKernelGGL((sk_band_dots_kernel<E8, RW, NW>), dim3(nb + 1, nbatch), dim3(64 * NW), 0, st, d0, n, m, pitch,
+                         ri0, zp, v0, u0, part0, log_m, vz, wp0, tp0, CP);
+      hipLaunchKernelGGL(sk_vcombine_dots_kernel, dim3(ceil_div(m + 1, 256), nbatch), dim3(256), 0, st, part0, m, nb + 1,
+                         v0, log_n, vz, ci0, zp.neg_inv_eps, wp0, CP);
+    }
+  }
+  for (int q = 1; q < parts; ++q) {
+    (void)hipEventRecord(fj.join[q - 1], fj.side[q - 1]);
+    (void)hipStreamWaitEvent(s, fj.join[q - 1], 0);
   }
 }
 
