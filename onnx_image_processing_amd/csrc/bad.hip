@@ -58,6 +58,10 @@ __device__ __forceinline__ int nearest_centre(float pos, float scale, int size) 
 // ---- fast kernel: 4 waves = 4 keypoints per workgroup, no workgroup-level synchronisation -----
 // waves_per_eu(8, 8): 41 VGPRs instead of 102 -- the kernel waits on its window gather (58 % of wave cycles
 // parked on s_waitcnt), so twice the resident waves, i.e. loads in flight, buys 12 %
+// GROUPS = num_pairs / 64 at compile time (0: read it at run time).  With a constant trip count the pair
+// loop is straight-line code and the compiler hoists the pair-table loads of later groups above the box
+// gathers of earlier ones; with a run-time count every group paid an L1/L2 round trip where it was used.
+template <int GROUPS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void bad_fast_kernel(const float *__restrict__ image, int h, int w,
                                                        const float *__restrict__ kpts, int k, int total,
                                                        int num_pairs, int normalize,
@@ -66,17 +70,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                        float *__restrict__ desc, uint32_t *__restrict__ bits,
                                                        uint8_t *__restrict__ status) {
   __shared__ int sat_all[4][FW * FW];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // everything per keypoint is wave-uniform; readfirstlane tells the compiler (scalar branches and addresses)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // XCD-contiguous order: the keypoints of one image run on one XCD, so their overlapping windows
   // are fetched through one L2 instead of once per XCD
   const int flat = (int)xcd_contiguous_id(blockIdx.x, gridDim.x) * 4 + wave;
-  if (flat >= total) return;                                   // wave-uniform
+  if (flat >= total) return;
   const int img = flat / k;
   const float *im = image + (size_t)img * h * w;
   const float ky = kpts[(size_t)flat * 2 + 0];
   const float kx = kpts[(size_t)flat * 2 + 1];
-  const int groups = num_pairs / 64;
-  const int words = num_pairs / 32;
+  const int groups = GROUPS ? GROUPS : num_pairs / 64;
+  const int words = 2 * groups;
+  constexpr int GMAX = GROUPS ? GROUPS : 16;
 
   if (!(ky >= 0.0f)) {                                         // invalid keypoint: zero descriptor (bad.py:461,570)
     if (bits) for (int q = lane; q < words; q += 64) bits[(size_t)flat * words + q] = 0u;
@@ -100,9 +106,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const int gx = clampi(ox + c, 0, w - 1);
   float px[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) px[r] = im[(size_t)clampi(oy + 16 * half + r, 0, h - 1) * w + gx];
+  for (int r = 0; r < 16; ++r) px[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(im) + (uint32_t)(clampi(oy + 16 * half + r, 0, h - 1) * w + gx) * 4u);   // scalar base + 32-bit byte offset
   const uint4 *plan_offs = reinterpret_cast<const uint4 *>(plan + 1);
   const int *plan_tint = reinterpret_cast<const int *>(plan_offs + num_pairs);
+  // the first pair-table words ride behind the window gather instead of waiting for the table build
+  constexpr int NPRE = GROUPS ? 3 : 0;
+  uint4 o_pre[NPRE ? NPRE : 1];
+  int t_pre[NPRE ? NPRE : 1];
+#pragma unroll
+  for (int g = 0; g < NPRE; ++g) {
+    o_pre[g] = plan_offs[g * 64 + lane];
+    t_pre[g] = plan_tint[g * 64 + lane];
+  }
   bool integral = true;
   int col[16];
   int acc = 0;
@@ -136,45 +151,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   }
   __builtin_amdgcn_wave_barrier();
   const char *sbase = reinterpret_cast<const char *>(isat);
-  unsigned long long wordv[16];
+  unsigned long long wordv[GMAX];
   int pop = 0;
+  auto emit = [&](int g, int d, int tint) {
+    const unsigned long long word = __ballot(d <= tint);                 // bad.py:567
+    wordv[g] = word;
+    pop += (int)__popcll(word);
+  };
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    wordv[g] = 0ull;
-    if (g < groups) {
-      const int tint = plan_tint[g * 64 + lane];
-      int s1, s2;
-      if (interior) {                                                      // wave-uniform
-        const uint4 o = plan_offs[g * 64 + lane];
-        auto at = [&](uint32_t byte_off) { return *reinterpret_cast<const int *>(sbase + byte_off); };
-        s1 = (at(o.x & 0xFFFFu) - at(o.x >> 16)) - (at(o.y & 0xFFFFu) - at(o.y >> 16));
-        s2 = (at(o.z & 0xFFFFu) - at(o.z >> 16)) - (at(o.w & 0xFFFFu) - at(o.w >> 16));
-      } else {
-        // box centre = clamp(keypoint + offset) into the image (bad.py:518-556 for integer positions),
-        // in window coordinates; rows a..b-1 / columns l..r-1 of the table with its leading zero row
+  for (int g = 0; g < GMAX; ++g) wordv[g] = 0ull;
+  if (interior) {                                                          // wave-uniform
+    auto at = [&](uint32_t byte_off) { return *reinterpret_cast<const int *>(sbase + byte_off); };
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+      if (g < groups) {
+        const uint4 o = g < NPRE ? o_pre[g] : plan_offs[g * 64 + lane];
+        const int tint = g < NPRE ? t_pre[g] : plan_tint[g * 64 + lane];
+        const int s1 = (at(o.x & 0xFFFFu) - at(o.x >> 16)) - (at(o.y & 0xFFFFu) - at(o.y >> 16));
+        const int s2 = (at(o.z & 0xFFFFu) - at(o.z >> 16)) - (at(o.w & 0xFFFFu) - at(o.w >> 16));
+        emit(g, s1 - s2, tint);
+      }
+    }
+  } else {
+    // box centre = clamp(keypoint + offset) into the image (bad.py:518-556 for integer positions),
+    // in window coordinates; rows a..b-1 / columns l..r-1 of the table with its leading zero row
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+      if (g < groups) {
         const uint32_t q = geom[g * 64 + lane];
+        const int tint = plan_tint[g * 64 + lane];
         const int rad = (int)((q >> 20) & 15u);
         auto box = [&](int offx, int offy) {
           const int cx = clampi((int)kx + offx, 0, w - 1) - ox, cy = clampi((int)ky + offy, 0, h - 1) - oy;
           const int a = cy - rad, b = cy + rad + 1, l = cx - rad, r = cx + rad + 1;
           return (isat[b * FW + r] - isat[a * FW + r]) - (isat[b * FW + l] - isat[a * FW + l]);
         };
-        s1 = box((int)(q & 31u) - 16, (int)((q >> 10) & 31u) - 16);
-        s2 = box((int)((q >> 5) & 31u) - 16, (int)((q >> 15) & 31u) - 16);
-      }
-      const unsigned long long word = __ballot((s1 - s2) <= tint);   // bad.py:567
-      wordv[g] = word;
-      pop += (int)__popcll(word);
-      if (bits && lane == 0) {
-        bits[(size_t)flat * words + 2 * g] = (uint32_t)word;
-        bits[(size_t)flat * words + 2 * g + 1] = (uint32_t)(word >> 32);
+        const int s1 = box((int)(q & 31u) - 16, (int)((q >> 10) & 31u) - 16);
+        const int s2 = box((int)((q >> 5) & 31u) - 16, (int)((q >> 15) & 31u) - 16);
+        emit(g, s1 - s2, tint);
       }
     }
+  }
+  if (bits) {                                      // lane g stores word g: one store for the whole packed row
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) mine = (lane == g) ? wordv[g] : mine;
+    if (lane < groups) reinterpret_cast<unsigned long long *>(bits + (size_t)flat * words)[lane] = mine;
   }
   if (desc) {
     const float inv = normalize ? fmaxf(sqrtf((float)pop), 1e-12f) : 1.0f;       // bad.py:573
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
+    for (int g = 0; g < GMAX; ++g) {
       if (g < groups) {
         const float v = ((wordv[g] >> lane) & 1ull) ? 1.0f : 0.0f;
         desc[(size_t)flat * num_pairs + g * 64 + lane] = normalize ? v / inv : v;
@@ -394,10 +421,12 @@ extern "C" int mi_sparse_bad(const float *image, int n, int h, int w, const floa
   // bad.py:469-470: python double 2/(size-1+1e-8), multiplied into an fp32 tensor
   const float scale_y = (float)(2.0 / ((double)(h - 1) + 1e-8));
   const float scale_x = (float)(2.0 / ((double)(w - 1) + 1e-8));
-  const bool fast = plan != nullptr && status != nullptr && mode == MI_BAD_HARD && h >= 32 && w >= 32;
+  const bool fast = plan != nullptr && status != nullptr && mode == MI_BAD_HARD && h >= 32 && w >= 32 &&
+                    (long long)h * w < (1LL << 30);          // the fast kernel addresses a plane with 32-bit byte offsets
   if (fast) {
     const BadPlan *bp = reinterpret_cast<const BadPlan *>(plan);
-    hipLaunchKernelGGL(bad_fast_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, s, image, h, w, keypoints,
+    auto fast_kernel = num_pairs == 512 ? bad_fast_kernel<8> : num_pairs == 256 ? bad_fast_kernel<4> : bad_fast_kernel<0>;
+    hipLaunchKernelGGL(fast_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, s, image, h, w, keypoints,
                        k, total, num_pairs, normalize, bp, pair_geom, desc, bits, status);
     hipLaunchKernelGGL(bad_plan_gate_kernel, dim3(64), dim3(256), 0, s, bp, status, total);
     constexpr int CHUNK = 16;
