@@ -13,7 +13,8 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_size_t, c_uint32, c_voi
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libmi355x_match.so")
+# MI355X_MATCH_LIB: development hook (A/B timing of two builds on one box); the default is the in-tree build
+LIB_PATH = os.environ.get("MI355X_MATCH_LIB") or os.path.join(_PKG, "lib", "libmi355x_match.so")
 
 # name -> argtypes (return type is int unless listed in _RESTYPE); mirrors include/mi355x_match.h
 SIGNATURES = {
