@@ -23,6 +23,28 @@ __device__ __forceinline__ uint64_t make_key(float m, uint32_t lin) {
   return ((uint64_t)__float_as_uint(m) << 32) | (uint64_t)(0xFFFFFFFFu - lin);
 }
 
+// v_max_f32 / v_max3_f32 exactly as written.  fmaxf() makes the compiler first quiet a possible signalling
+// NaN in every value that comes from memory (one `v_max x, x` each: +45 % instructions in the two maximum
+// passes, which are bound by VALU issue); the instructions already return the other operand for a NaN.
+__device__ __forceinline__ float vmax2(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// max(acc, e[0..N)) with two new operands per instruction
+template <int N>
+__device__ __forceinline__ float vmax_fold(float acc, const float *e) {
+#pragma unroll
+  for (int i = 0; i + 1 < N; i += 2) acc = vmax3(acc, e[i], e[i + 1]);
+  if constexpr (N & 1) acc = vmax2(acc, e[N - 1]);
+  return acc;
+}
+
 // Workgroup-wide compaction of up to NQ survivors per thread into one segment.
 // kidx[q] == 0xFFFFFFFF marks "not a survivor".  Must be called by all NWV * 64 threads.
 template <int NQ, int NWV>
@@ -30,13 +52,19 @@ __device__ __forceinline__ void compact_tile(uint32_t nkeep, const float (&kval)
                                              uint64_t *__restrict__ seg, uint32_t *__restrict__ seg_count) {
   __shared__ uint32_t wave_total[NWV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t incl = nkeep;
+  (void)nkeep;
+  // slot of survivor q of this lane inside the wave = survivors of rounds < q + survivors of round q in
+  // lower lanes: one ballot and one mbcnt per round, counts carried in SGPRs (a 6-step __shfl_up scan
+  // would be six dependent trips through the LDS crossbar at the very end of the kernel)
+  uint32_t wave_cnt = 0;
+  uint32_t slot_in_wave[NQ];
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t up = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += up;
+  for (int q = 0; q < NQ; ++q) {
+    const unsigned long long m = __ballot(kidx[q] != 0xFFFFFFFFu);
+    slot_in_wave[q] = wave_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    wave_cnt += (uint32_t)__popcll(m);
   }
-  if (lane == 63) wave_total[wave] = incl;
+  if (lane == 0) wave_total[wave] = wave_cnt;
   __syncthreads();
   uint32_t base = 0, total = 0;
 #pragma unroll
@@ -46,10 +74,9 @@ __device__ __forceinline__ void compact_tile(uint32_t nkeep, const float (&kval)
     total += c;
   }
   if (threadIdx.x == 0) *seg_count = total;
-  uint32_t slot = base + incl - nkeep;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    if (kidx[q] != 0xFFFFFFFFu) seg[slot++] = make_key(kval[q], kidx[q]);
+    if (kidx[q] != 0xFFFFFFFFu) seg[base + slot_in_wave[q]] = make_key(kval[q], kidx[q]);
   }
 }
 
@@ -226,27 +253,27 @@ __global__ __launch_bounds__(NTH) void nms_fast_kernel(const float *__restrict__
     float v[NV];
 #pragma unroll
     for (int c = 0; c < NV / 4; ++c) {
-      const float4 q = pa[rr][cg + c];
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      f4v q = *reinterpret_cast<const f4v *>(&pa[rr][cg + c]);
+      // keep the 16-byte read whole: left alone the compiler fetches only the 4+2r floats it needs with
+      // ds_read2_b32, whose 16-byte lane stride is a 4-way bank conflict; ds_read_b128 has none
+      asm volatile("" : "+v"(q));
       v[4 * c] = q.x; v[4 * c + 1] = q.y; v[4 * c + 2] = q.z; v[4 * c + 3] = q.w;
     }
     // windows [B0+o-R, B0+o+R], o = 0..3; for R >= 2 they share the core [B0+3-R, B0+R]
     float o[4];
     if constexpr (R >= 2) {
-      float core = v[B0 + 3 - R];
-#pragma unroll
-      for (int c = B0 + 4 - R; c <= B0 + R; ++c) core = fmaxf(core, v[c]);
+      const float core = vmax_fold<2 * R - 3>(v[B0 + 3 - R], &v[B0 + 4 - R]);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float m = core;
+        float ext[3];                          // 3 - k values left of the core, k right of it
 #pragma unroll
-        for (int c = B0 + k - R; c < B0 + 3 - R; ++c) m = fmaxf(m, v[c]);
-#pragma unroll
-        for (int c = B0 + R + 1; c <= B0 + k + R; ++c) m = fmaxf(m, v[c]);
-        o[k] = m;
+        for (int e = 0; e < 3; ++e) ext[e] = (e < 3 - k) ? v[B0 + k - R + e] : v[B0 + R + 1 + (e - (3 - k))];
+        o[k] = vmax_fold<3>(core, ext);
       }
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = fmaxf(fmaxf(v[B0 + k - 1], v[B0 + k]), v[B0 + k + 1]);
+      for (int k = 0; k < 4; ++k) o[k] = vmax3(v[B0 + k - 1], v[B0 + k], v[B0 + k + 1]);
     }
     pb[rr][cg] = make_float4(o[0], o[1], o[2], o[3]);
   }
@@ -254,28 +281,33 @@ __global__ __launch_bounds__(NTH) void nms_fast_kernel(const float *__restrict__
 
   // column pass: thread = 4 columns x RPT rows; window k covers rows [k, k + 2R], all sharing [RPT-1, 2R]
   const int tx = t & 31, ty = t >> 5;
-  float4 rows[RPT + 2 * R];
+  float rc[4][RPT + 2 * R];                    // [column][row]
 #pragma unroll
-  for (int q = 0; q < RPT + 2 * R; ++q) rows[q] = pb[ty * RPT + q][tx];
-  float4 core = rows[RPT - 1];
+  for (int q = 0; q < RPT + 2 * R; ++q) {
+    const float4 rq = pb[ty * RPT + q][tx];
+    rc[0][q] = rq.x; rc[1][q] = rq.y; rc[2][q] = rq.z; rc[3][q] = rq.w;
+  }
+  float core[4];
 #pragma unroll
-  for (int q = RPT; q <= 2 * R; ++q) core = max4(core, rows[q]);
+  for (int c = 0; c < 4; ++c) core[c] = vmax_fold<2 * R - RPT + 1>(rc[c][RPT - 1], &rc[c][RPT]);
   const int gx = x0 + 4 * tx;
   uint32_t nkeep = 0;
   float kval[RPT * 4];
   uint32_t kidx[RPT * 4];
 #pragma unroll
   for (int k = 0; k < RPT; ++k) {
-    float4 m = core;
+    float mv[4];
 #pragma unroll
-    for (int q = k; q < RPT - 1; ++q) m = max4(m, rows[q]);
+    for (int c = 0; c < 4; ++c) {
+      float ext[RPT > 1 ? RPT - 1 : 1];        // RPT-1-k rows above the core, k below it
 #pragma unroll
-    for (int q = 2 * R + 1; q <= k + 2 * R; ++q) m = max4(m, rows[q]);
+      for (int e = 0; e < RPT - 1; ++e) ext[e] = (e < RPT - 1 - k) ? rc[c][k + e] : rc[c][2 * R + 1 + (e - (RPT - 1 - k))];
+      mv[c] = vmax_fold<RPT - 1>(core[c], ext);
+    }
     const int ly = ty * RPT + k, gy = y0 + ly;
     const float4 s = pa[ly + R][tx + PC];
     const bool in_img = (gx < w) && (gy < h);
     const float sv[4] = {s.x, s.y, s.z, s.w};
-    const float mv[4] = {m.x, m.y, m.z, m.w};
     float outv[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
