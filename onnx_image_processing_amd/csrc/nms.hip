@@ -80,6 +80,42 @@ __device__ __forceinline__ void compact_tile(uint32_t nkeep, const float (&kval)
   }
 }
 
+// Same, from lane predicates: the predicates live in SGPR pairs (their ANDs run on the scalar unit and a
+// ballot is free), and everything a survivor needs -- slot, linear index, key -- is computed inside the
+// branch only survivors take.  lin_of(q) gives survivor q's linear pixel index.
+template <int NQ, int NWV, class LinOf>
+__device__ __forceinline__ void compact_tile_pred(const bool (&keep)[NQ], const float (&kval)[NQ], LinOf lin_of,
+                                                  uint64_t *__restrict__ seg, uint32_t *__restrict__ seg_count) {
+  __shared__ uint32_t wave_total[NWV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long m[NQ];
+  uint32_t before[NQ];                         // survivors of earlier rounds in this wave (wave-uniform)
+  uint32_t wave_cnt = 0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    m[q] = __ballot(keep[q]);
+    before[q] = wave_cnt;
+    wave_cnt += (uint32_t)__popcll(m[q]);
+  }
+  if (lane == 0) wave_total[wave] = wave_cnt;
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) {
+    const uint32_t c = wave_total[w];
+    base += (w < wave) ? c : 0u;
+    total += c;
+  }
+  if (threadIdx.x == 0) *seg_count = total;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if (keep[q]) {
+      const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[q], 0u));
+      seg[base + before[q] + below] = make_key(kval[q], lin_of(q));
+    }
+  }
+}
+
 __device__ __forceinline__ bool in_border(int gy, int gx, int h, int w, int margin) {
   return (margin <= 0) || (gy >= margin && gy < h - margin && gx >= margin && gx < w - margin);
 }
@@ -291,9 +327,13 @@ __global__ __launch_bounds__(NTH) void nms_fast_kernel(const float *__restrict__
 #pragma unroll
   for (int c = 0; c < 4; ++c) core[c] = vmax_fold<2 * R - RPT + 1>(rc[c][RPT - 1], &rc[c][RPT]);
   const int gx = x0 + 4 * tx;
-  uint32_t nkeep = 0;
   float kval[RPT * 4];
-  uint32_t kidx[RPT * 4];
+  bool keep[RPT * 4];
+  // image / border tests per column and per row of the thread, not per pixel (w % 4 == 0: a float4 chunk is
+  // wholly inside or outside the image)
+  bool col_ok[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) col_ok[c] = (gx < w) && (margin <= 0 || (gx + c >= margin && gx + c < w - margin));
 #pragma unroll
   for (int k = 0; k < RPT; ++k) {
     float mv[4];
@@ -307,6 +347,7 @@ __global__ __launch_bounds__(NTH) void nms_fast_kernel(const float *__restrict__
     const int ly = ty * RPT + k, gy = y0 + ly;
     const float4 s = pa[ly + R][tx + PC];
     const bool in_img = (gx < w) && (gy < h);
+    const bool row_ok = (gy < h) && (margin <= 0 || (gy >= margin && gy < h - margin));
     const float sv[4] = {s.x, s.y, s.z, s.w};
     float outv[4];
 #pragma unroll
@@ -314,16 +355,18 @@ __global__ __launch_bounds__(NTH) void nms_fast_kernel(const float *__restrict__
       const bool is_max = sv[c] >= (mv[c] - 1e-7f);                      // keypoint_utils.py:43
       outv[c] = is_max ? 1.0f : 0.0f;
       if (MODE == 1) {
-        const bool keep = in_img && is_max && in_border(gy, gx + c, h, w, margin) && (sv[c] > thr_eff);
+        keep[k * 4 + c] = is_max && (sv[c] > thr_eff) && col_ok[c] && row_ok;
         kval[k * 4 + c] = sv[c];
-        kidx[k * 4 + c] = keep ? (uint32_t)(gy * w + gx + c) : 0xFFFFFFFFu;
-        nkeep += keep ? 1u : 0u;
       }
     }
     if (MODE == 0 && in_img)
       *reinterpret_cast<float4 *>(mask + ((size_t)img * h + gy) * w + gx) = make_float4(outv[0], outv[1], outv[2], outv[3]);
   }
-  if (MODE == 1) compact_tile<RPT * 4, NTH / 64>(nkeep, kval, kidx, cand + (size_t)seg_id * SEG_CAP, count + seg_id);
+  if (MODE == 1) {
+    const uint32_t lin0 = (uint32_t)((y0 + ty * RPT) * w + gx);
+    compact_tile_pred<RPT * 4, NTH / 64>(keep, kval, [&](int q) { return lin0 + (uint32_t)((q >> 2) * w + (q & 3)); },
+                                         cand + (size_t)seg_id * SEG_CAP, count + seg_id);
+  }
 }
 
 template <int MODE>
