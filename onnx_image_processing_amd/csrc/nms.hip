@@ -247,8 +247,13 @@ __global__ __launch_bounds__(NTH) void nms_fast_kernel(const float *__restrict__
   constexpr int B0 = 4 * PC;                   // index of output column 0 inside those floats
   constexpr int RPT = NT_H / (NTH / 32);       // rows per thread in the column pass (4 or 2)
   static_assert(2 * R >= RPT - 1, "the RPT windows of a thread must share rows");
-  __shared__ float4 pa[LH][AW4];               // scores (+halo), -inf outside the image
-  __shared__ float4 pb[LH][NT_W / 4];          // horizontal window maxima
+  // One LDS plane: scores (+halo, -inf outside the image); the row pass overwrites its interior columns with
+  // the horizontal window maxima IN PLACE.  That is safe because a wave's 64 row-pass items are two whole rows
+  // (32 column groups each): every read of a row is issued by the wave that later writes it, and a wave's LDS
+  // operations execute in order.  The centre pixels the column pass compares against are fetched from global
+  // memory (L2 hits) up front instead.  24 KB per workgroup instead of 46: 4 workgroups (32 waves) per CU.
+  __shared__ float4 pa[LH][AW4];
+  static_assert(NT_W / 4 == 32, "a wave's row-pass items must be whole rows");
 
   const int t = threadIdx.x;
   const int seg_id = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);   // neighbouring tiles share an XCD's L2
@@ -260,6 +265,9 @@ __global__ __launch_bounds__(NTH) void nms_fast_kernel(const float *__restrict__
   const int x0 = tx_tile * NT_W, y0 = ty_tile * NT_H;
   const float *sc = score + (size_t)img * h * w;
   const float ninf = -INFINITY;
+  const int tx = t & 31, ty = t >> 5;          // column-pass coordinates: 4 columns x RPT rows
+  const int gx = x0 + 4 * tx;
+  float4 centre[RPT];
 
   {
     float4 v[NCH];
@@ -270,7 +278,14 @@ __global__ __launch_bounds__(NTH) void nms_fast_kernel(const float *__restrict__
       const int gy = y0 - R + rr, gx = x0 - 4 * PC + 4 * cc;
       v[q] = make_float4(ninf, ninf, ninf, ninf);
       if (i < LH * AW4 && gy >= 0 && gy < h && gx >= 0 && gx < w)
-        v[q] = *reinterpret_cast<const float4 *>(sc + (size_t)gy * w + gx);
+        v[q] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc) + (uint32_t)(gy * w + gx) * 4u);   // scalar base + 32-bit offset
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int gy = y0 + ty * RPT + k;
+      centre[k] = make_float4(ninf, ninf, ninf, ninf);
+      if (gx < w && gy < h)
+        centre[k] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(sc) + (uint32_t)(gy * w + gx) * 4u);
     }
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
@@ -311,22 +326,20 @@ __global__ __launch_bounds__(NTH) void nms_fast_kernel(const float *__restrict__
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = vmax3(v[B0 + k - 1], v[B0 + k], v[B0 + k + 1]);
     }
-    pb[rr][cg] = make_float4(o[0], o[1], o[2], o[3]);
+    pa[rr][cg + PC] = make_float4(o[0], o[1], o[2], o[3]);      // in place (see above)
   }
   __syncthreads();
 
   // column pass: thread = 4 columns x RPT rows; window k covers rows [k, k + 2R], all sharing [RPT-1, 2R]
-  const int tx = t & 31, ty = t >> 5;
   float rc[4][RPT + 2 * R];                    // [column][row]
 #pragma unroll
   for (int q = 0; q < RPT + 2 * R; ++q) {
-    const float4 rq = pb[ty * RPT + q][tx];
+    const float4 rq = pa[ty * RPT + q][tx + PC];
     rc[0][q] = rq.x; rc[1][q] = rq.y; rc[2][q] = rq.z; rc[3][q] = rq.w;
   }
   float core[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) core[c] = vmax_fold<2 * R - RPT + 1>(rc[c][RPT - 1], &rc[c][RPT]);
-  const int gx = x0 + 4 * tx;
   float kval[RPT * 4];
   bool keep[RPT * 4];
   // image / border tests per column and per row of the thread, not per pixel (w % 4 == 0: a float4 chunk is
@@ -345,7 +358,7 @@ __global__ __launch_bounds__(NTH) void nms_fast_kernel(const float *__restrict__
       mv[c] = vmax_fold<RPT - 1>(core[c], ext);
     }
     const int ly = ty * RPT + k, gy = y0 + ly;
-    const float4 s = pa[ly + R][tx + PC];
+    const float4 s = centre[k];
     const bool in_img = (gx < w) && (gy < h);
     const bool row_ok = (gy < h) && (margin <= 0 || (gy >= margin && gy < h - margin));
     const float sv[4] = {s.x, s.y, s.z, s.w};
@@ -373,6 +386,7 @@ template <int MODE>
 bool launch_fast(const float *score, int n, int h, int w, int radius, float *mask, float thr_eff, int margin,
                  uint64_t *cand, uint32_t *count, hipStream_t s) {
   if (w % 4 != 0 || radius < 1 || radius > 8 || ((uintptr_t)score % 16) != 0) return false;
+  if ((long long)h * w >= (1LL << 30)) return false;        // the fast kernel addresses a plane with 32-bit byte offsets
   if (MODE == 0 && ((uintptr_t)mask % 16) != 0) return false;
   const int tiles_x = ceil_div(w, NT_W), tiles_y = ceil_div(h, NT_H);
   const dim3 grid((unsigned)(n * tiles_x * tiles_y));
