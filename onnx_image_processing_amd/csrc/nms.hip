@@ -3,8 +3,8 @@
 // border, threshold).  HBM traffic: 4 B/pixel read; candidates are ~1 % of pixels.
 //
 // One workgroup (512 threads on the fast path, 256 on the generic one) owns a 128x32 tile.  The score tile (+r halo, -inf outside the
-// image) is staged in LDS, a separable max (row pass into a second LDS plane, column pass in
-// registers) gives the (2r+1)^2 window maximum.  Survivors are packed into 64-bit keys
+// image) is staged in LDS, a separable max (row pass in place on the fast path, into a second LDS plane on
+// the generic one; column pass in registers) gives the (2r+1)^2 window maximum.  Survivors are packed into 64-bit keys
 // (score bits high, inverted linear index low) and written to the tile's OWN segment of the
 // candidate buffer (4096 slots = every pixel of the tile, so it cannot overflow) with the
 // count in count[img][tile]: no global atomics, no pre-zeroed counters, and the later top-k
@@ -17,7 +17,7 @@ namespace {
 
 constexpr int NT_W = 128, NT_H = 32;
 constexpr int SEG_CAP = NT_W * NT_H;  // slots per tile segment
-constexpr int NMS_THREADS = 512;      // fast kernel: 8 waves share the tile's 46 KB of LDS (3 workgroups per CU)
+constexpr int NMS_THREADS = 512;      // fast kernel: 8 waves per 128x32 tile, 24 KB of LDS (4 workgroups = 32 waves per CU)
 
 __device__ __forceinline__ uint64_t make_key(float m, uint32_t lin) {
   return ((uint64_t)__float_as_uint(m) << 32) | (uint64_t)(0xFFFFFFFFu - lin);
