@@ -86,6 +86,24 @@ def test_nms_mask_golden_and_oracle(mods):
         assert np.array_equal(mods["apply_nms_maxpool"](gpu(sc), r).cpu().numpy(), O.nms_mask(sc, r))
 
 
+@pytest.mark.parametrize("radius", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_nms_fast_kernel_every_radius(mods, radius):
+    """The one-plane fast kernel (w % 4 == 0, r <= 8), mask and candidate modes, on maps with negative values,
+    plateaus, ragged tile edges and several images; against the oracle."""
+    rng = np.random.default_rng(radius)
+    for (n, h, w) in ((2, 75, 132), (1, 32, 128), (3, 97, 260), (1, 5, 8)):
+        sc = rng.standard_normal((n, h, w)).astype(np.float32)
+        sc[:, : h // 2] = np.round(sc[:, : h // 2] * 2) / 2                     # exact ties in the upper half
+        got = mods["apply_nms_maxpool"](gpu(sc), radius).cpu().numpy()
+        ref = O.nms_mask(sc, radius)
+        assert np.array_equal(got, ref), (radius, n, h, w)
+        k = min(64, h * w)
+        for thr, margin in ((0.0, 0), (0.25, 3)):
+            kp_ref, sc_ref, _ = O.select_topk_keypoints(sc, ref, k, thr, margin)
+            kp, ks = mods["detect_keypoints"](gpu(sc), radius, k, thr, margin)
+            assert np.array_equal(kp.cpu().numpy(), kp_ref) and np.array_equal(ks.cpu().numpy(), sc_ref), (radius, h, w, thr)
+
+
 def test_topk_golden_tie_free(mods):
     g = load_golden("nms_topk")
     s = gpu(g["uniq_scores"])
