@@ -60,7 +60,9 @@ __device__ __forceinline__ void corner_compute(const float4 *__restrict__ tile, 
   const int x = x0 + 4 * tx;
   const int ybase = y0 + ty * R;
   if (x >= w || ybase >= h) return;
-  // image-border handling only exists on border tiles (workgroup-uniform branches)
+  // image-border handling only exists on border tiles (workgroup-uniform branches; the empty asm keeps the
+  // compiler from flattening them into per-row selects that every tile would execute)
+#define MI_KEEP_BRANCH() asm volatile("")
   const bool tile_left = (x0 == 0), tile_right = (x0 + TW >= w);
   const bool tile_top = (y0 == 0), tile_bottom = (y0 + TH + HP > h);
   const bool left_edge = (x == 0);
@@ -87,9 +89,11 @@ __device__ __forceinline__ void corner_compute(const float4 *__restrict__ tile, 
       // replicate padding of the IMAGE in x: chunks left/right of the image take the edge pixel
       // (the register-staged kernel already stored them that way; LDS-DMA cannot splat)
       if (tile_left) {
+        MI_KEEP_BRANCH();
         if (left_edge) { d[0] = d[4]; d[1] = d[4]; d[2] = d[4]; d[3] = d[4]; }
       }
       if (tile_right) {
+        MI_KEEP_BRANCH();
         if (right_edge) { d[8] = d[7]; d[9] = d[7]; d[10] = d[7]; d[11] = d[7]; }
       }
     }
@@ -127,12 +131,14 @@ __device__ __forceinline__ void corner_compute(const float4 *__restrict__ tile, 
     }
     // replicate padding of the PRODUCT maps == gradients taken at the clamped column
     if (tile_left) {
+      MI_KEEP_BRANCH();
       if (left_edge) {
 #pragma unroll
         for (int j = 0; j < HP; ++j) { gx_[j] = gx_[HP]; gy_[j] = gy_[HP]; }
       }
     }
     if (tile_right) {
+      MI_KEEP_BRANCH();
       if (right_edge) {
 #pragma unroll
         for (int j = 0; j < HP; ++j) { gx_[4 + HP + j] = gx_[3 + HP]; gy_[4 + HP + j] = gy_[3 + HP]; }
@@ -222,8 +228,9 @@ __device__ __forceinline__ void corner_compute(const float4 *__restrict__ tile, 
     float out[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) out[i] = lambda_min(acc[0][i], acc[1][i], acc[2][i]);
-    float *dst = score + ((size_t)img * h + (ybase + orow)) * w + x;
-    *reinterpret_cast<float4 *>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+    // scalar base (the image plane) + 32-bit byte offset: no 64-bit address arithmetic per row
+    char *plane = reinterpret_cast<char *>(score + (size_t)img * h * w);
+    *reinterpret_cast<float4 *>(plane + (uint32_t)((ybase + orow) * w + x) * 4u) = make_float4(out[0], out[1], out[2], out[3]);
   }
 }
 
