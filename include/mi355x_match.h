@@ -182,14 +182,19 @@ int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, float dustbi
  * mi_sinkhorn_dots runs the same iterations as mi_sinkhorn but rebuilds
  *     z = -max(|a|^2 + |b|^2 - 2 * dot * s_a * s_b, 0) * (1/epsilon)
  * in registers on every pass: 2 bytes per matrix element per iteration instead of 4.
- * m <= 1024 (mi_sinkhorn_dots_workspace_bytes returns 0 otherwise: use the fp32 form). */
+ * m <= 1024 (mi_sinkhorn_dots_workspace_bytes returns 0 otherwise: use the fp32 form).
+ * sqnorm_bound: an upper bound of every squared norm in row_info / col_info (1 for `normalized`
+ * descriptors, num_bits otherwise), or 0 if unknown.  With a bound small enough that
+ * 2 * sqnorm_bound / epsilon < ~62 the row pass shifts every row of a pair by one analytic bound
+ * instead of each row's own maximum (same result to fp32 rounding, fewer instructions); a bound the
+ * data exceeds is a contract violation (exponent overflow).  0 always takes the per-row-maximum path. */
 int mi_cost_dots_bits(const uint32_t *bits1, const uint32_t *bits2, int batch, int n, int m, int num_bits,
                       int normalized, uint16_t *dots, int pitch, float *row_info, float *col_info,
                       mi_stream_t stream);
 size_t mi_sinkhorn_dots_workspace_bytes(int batch, int n, int m);
 int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch, int n,
-                     int m, int pitch, double epsilon, double unused_score, int iterations, float *u,
-                     float *v, float *p, void *workspace, size_t workspace_bytes, mi_stream_t stream);
+                     int m, int pitch, double epsilon, double unused_score, double sqnorm_bound, int iterations,
+                     float *u, float *v, float *p, void *workspace, size_t workspace_bytes, mi_stream_t stream);
 
 /* ---- matching/sinkhorn.py:317-465  SinkhornMatcherWithFilters (filter stage) -----------------
  * In place on p (batch, n+1, m+1): per row i < n, best/second-best core probability and the

@@ -26,10 +26,32 @@ constexpr float SKD_L2E = 1.4426950408889634f, SKD_LN2 = 0.6931471805599453f;
 struct ZParams {
   float neg_inv_eps;   // -1/epsilon
   float dust;          // -unused_score/epsilon
+  float g_bound;       // G (bounded-shift path only)
+  float d_bound;       // D
 };
 
 __device__ __forceinline__ float z_of(float dot, float2 row, float2 col, float neg_inv_eps) {
   return mi_z_from_dot(dot, row, col, neg_inv_eps);
+}
+
+// Bounded-shift row pass.  When the caller can bound the squared norms y of the scaled descriptors
+// (sqnorm_bound; 1 for unit descriptors), every dot_ij * t_j * g_i is <= G = 2/eps * sqnorm_bound (for bit
+// vectors dot <= min(pop_i, pop_j) <= sqrt(pop_i pop_j)) and every -c_i is <= D = sqnorm_bound/eps, so
+//     S = max(max_j wp_j + G, dust + v_m + D)
+// is an upper bound of every exponent of the pair: used as the shift of EVERY row, nothing overflows, and a
+// row's largest term is >= 2^(-G log2 e), so with G log2 e < SKD_FAST_LIMIT all sums stay far inside the
+// normal range (unit descriptors: down to eps ~ 0.03).  The per-row maximum -- a max per element, a wave
+// reduction per row and the shift fma ahead of every v_exp_f32 -- disappears.  max_j wp_j comes from the
+// column kernels: SKD_AUX block maxima per pair in the workspace.  Otherwise the per-row-maximum kernel runs.
+constexpr int SKD_AUX = 8;
+constexpr float SKD_FAST_LIMIT = 90.0f;
+
+__device__ __forceinline__ float block_max_256(float x) {     // all 256 threads; result valid in thread 0
+  __shared__ float wmx[4];
+  x = wave_max_dpp(x);
+  if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = x;
+  __syncthreads();
+  return fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
 }
 
 // v_j <- v_j + log nu_j - log(sum of the bands' P_ij + exp(B_j))   (B_j: dustbin row, log domain)
@@ -71,14 +93,15 @@ __device__ __forceinline__ float combine_column(const float *__restrict__ part_b
 // re-enters in u_i and in the dustbin-column entry.  Per-column data come from aligned, padded
 // arrays (16-byte loads): tp = t_j (0 in the padding), wp = nie*nb_j + v_j (-inf in the padding:
 // such a column contributes nowhere), the latter rebuilt by the combine kernel every iteration.
-template <int E8, int RW, int NW>
+template <int E8, int RW, int NW, bool FAST>
 __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *__restrict__ dots, int n, int m,
                                                                int pitch, const float2 *__restrict__ row_info,
                                                                ZParams zp, const float *__restrict__ v,
                                                                float *__restrict__ u, float *__restrict__ part,
                                                                float log_m, int v_is_zero,
                                                                const float *__restrict__ wp,
-                                                               const float *__restrict__ tp, int cpitch) {
+                                                               const float *__restrict__ tp, int cpitch,
+                                                               const float *__restrict__ aux) {
   constexpr int BAND = NW * RW;   // NW waves x RW rows each
   constexpr int NT = 64 * NW;
   constexpr int NC = 512 * E8;    // columns covered by one wave
@@ -144,6 +167,20 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
   }
   const float xd0 = dust + vd;
 
+  // Bounded-shift path: one shift S for every row of the pair, known before the row is read; wq becomes
+  // wq*log2(e) - S*log2(e) once per wave and x lands in the exponent's units.
+  float nm_pair = 0.0f;          // -S * log2(e)
+  if constexpr (FAST) {
+    const float *ab = aux + (size_t)b * SKD_AUX;
+    const float wmax = fmaxf(fmaxf(fmaxf(ab[0], ab[1]), fmaxf(ab[2], ab[3])), fmaxf(fmaxf(ab[4], ab[5]), fmaxf(ab[6], ab[7])));
+    const float S = fmaxf(wmax + zp.g_bound, xd0 + zp.d_bound);
+    nm_pair = -(S * SKD_L2E);
+#pragma unroll
+    for (int e = 0; e < E8; ++e)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) wq[e][q] = __builtin_fmaf(wq[e][q], SKD_L2E, nm_pair);
+  }
+
   float colsum[E8][8];
 #pragma unroll
   for (int e = 0; e < E8; ++e)
@@ -152,7 +189,7 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
   float dustcol = 0.0f;          // sum of P_i,dustbin over this wave's rows (wave-uniform)
   // The RW rows of the wave go through the three phases together, so that their wave-wide
   // reductions are done four at a time (wave_max4 / wave_sum4).
-  float x[RW][E8][8];            // (z_ij - c_i) + v_j, then e_ij in place
+  float x[RW][E8][8];            // (z_ij - c_i) + v_j (in the exponent's units, shifted, on the fast path), then e_ij in place
   float mx[RW], xd[RW], ci[RW];
   bool live[RW];
 #pragma unroll
@@ -160,10 +197,10 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
     const int i = row0 + r;
     live[r] = i < n;
     const float2 ri = row_info[(size_t)b * n + min(i, n - 1)];                     // wave-uniform
-    const float gi = -2.0f * zp.neg_inv_eps * ri.x;
+    const float g0 = -2.0f * zp.neg_inv_eps * ri.x;
+    const float gi = FAST ? g0 * SKD_L2E : g0;
     ci[r] = ri.y * zp.neg_inv_eps;
     xd[r] = xd0 - ci[r];
-    mx[r] = xd[r];
 #pragma unroll
     for (int e = 0; e < E8; ++e) {
       const uint32_t w4[4] = {raw[r][e].x, raw[r][e].y, raw[r][e].z, raw[r][e].w};
@@ -172,32 +209,48 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
         const float dot = (float)((q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu));
         x[r][e][q] = __builtin_fmaf(dot * tq[e][q], gi, wq[e][q]);
       }
-      mx[r] = fmaxf(mx[r], fmaxf(fmaxf(fmaxf(x[r][e][0], x[r][e][1]), fmaxf(x[r][e][2], x[r][e][3])),
-                                 fmaxf(fmaxf(x[r][e][4], x[r][e][5]), fmaxf(x[r][e][6], x[r][e][7]))));
+      if constexpr (!FAST)
+        mx[r] = fmaxf(e == 0 ? xd[r] : mx[r], fmaxf(fmaxf(fmaxf(x[r][e][0], x[r][e][1]), fmaxf(x[r][e][2], x[r][e][3])),
+                                                    fmaxf(fmaxf(x[r][e][4], x[r][e][5]), fmaxf(x[r][e][6], x[r][e][7]))));
     }
-  }
-  if constexpr (RW % 4 == 0) {
-#pragma unroll
-    for (int r = 0; r < RW; r += 4) wave_max4(mx + r);
-  } else {
-#pragma unroll
-    for (int r = 0; r < RW; ++r) mx[r] = wave_max_dpp(mx[r]);
   }
   // shift and 2^x scaling in one fma; u is taken from the same shift, so the row is normalised by
   // exactly what was summed (same scheme as sk_band_p2_kernel)
   float nm[RW], s[RW], ed[RW];
+  if constexpr (FAST) {
 #pragma unroll
-  for (int r = 0; r < RW; ++r) {
-    nm[r] = -(mx[r] * SKD_L2E);
-    s[r] = 0.0f;
+    for (int r = 0; r < RW; ++r) {
+      nm[r] = nm_pair;
+      s[r] = 0.0f;
 #pragma unroll
-    for (int e = 0; e < E8; ++e) {
+      for (int e = 0; e < E8; ++e) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        x[r][e][q] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[r][e][q], SKD_L2E, nm[r]));     // 0 outside the matrix
-      s[r] += ((x[r][e][0] + x[r][e][1]) + (x[r][e][2] + x[r][e][3])) + ((x[r][e][4] + x[r][e][5]) + (x[r][e][6] + x[r][e][7]));
+        for (int q = 0; q < 8; ++q) x[r][e][q] = __builtin_amdgcn_exp2f(x[r][e][q]);           // 0 outside the matrix
+        s[r] += ((x[r][e][0] + x[r][e][1]) + (x[r][e][2] + x[r][e][3])) + ((x[r][e][4] + x[r][e][5]) + (x[r][e][6] + x[r][e][7]));
+      }
+      ed[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(xd[r], SKD_L2E, nm[r]));                   // dustbin column entry
     }
-    ed[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(xd[r], SKD_L2E, nm[r]));                     // dustbin column entry
+  } else {
+    if constexpr (RW % 4 == 0) {
+#pragma unroll
+      for (int r = 0; r < RW; r += 4) wave_max4(mx + r);
+    } else {
+#pragma unroll
+      for (int r = 0; r < RW; ++r) mx[r] = wave_max_dpp(mx[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      nm[r] = -(mx[r] * SKD_L2E);
+      s[r] = 0.0f;
+#pragma unroll
+      for (int e = 0; e < E8; ++e) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          x[r][e][q] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[r][e][q], SKD_L2E, nm[r]));   // 0 outside the matrix
+        s[r] += ((x[r][e][0] + x[r][e][1]) + (x[r][e][2] + x[r][e][3])) + ((x[r][e][4] + x[r][e][5]) + (x[r][e][6] + x[r][e][7]));
+      }
+      ed[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(xd[r], SKD_L2E, nm[r]));                   // dustbin column entry
+    }
   }
   if constexpr (RW % 4 == 0) {
 #pragma unroll
@@ -239,26 +292,36 @@ __global__ __launch_bounds__(256) void sk_vcombine_dots_kernel(const float *__re
                                                                float *__restrict__ v, float log_n,
                                                                int v_is_zero, const float2 *__restrict__ col_info,
                                                                float neg_inv_eps, float *__restrict__ wp,
-                                                               int cpitch) {
+                                                               int cpitch, float *__restrict__ aux) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j > m) return;
-  const float vold = v_is_zero ? 0.0f : v[(size_t)b * (m + 1) + j];
-  const float vnew = combine_column(part + (size_t)b * nparts * (size_t)(m + 1), nparts, m, j, vold, log_n);
-  v[(size_t)b * (m + 1) + j] = vnew;
-  if (j < m) wp[(size_t)b * cpitch + j] = col_info[(size_t)b * m + j].y * neg_inv_eps + vnew;
+  float w = -INFINITY;
+  if (j <= m) {
+    const float vold = v_is_zero ? 0.0f : v[(size_t)b * (m + 1) + j];
+    const float vnew = combine_column(part + (size_t)b * nparts * (size_t)(m + 1), nparts, m, j, vold, log_n);
+    v[(size_t)b * (m + 1) + j] = vnew;
+    if (j < m) {
+      w = col_info[(size_t)b * m + j].y * neg_inv_eps + vnew;
+      wp[(size_t)b * cpitch + j] = w;
+    }
+  }
+  w = block_max_256(w);                        // this block's share of max_j wp_j for the next row pass
+  if (threadIdx.x == 0) aux[(size_t)b * SKD_AUX + blockIdx.x] = w;
 }
 
 // first-iteration column data: tp = column scale, wp = nie * squared norm (v = 0); padding 0 / -inf
 __global__ __launch_bounds__(256) void sk_dots_init_kernel(const float2 *__restrict__ col_info, int m, int cpitch,
                                                            float neg_inv_eps, float *__restrict__ wp,
-                                                           float *__restrict__ tp) {
+                                                           float *__restrict__ tp, float *__restrict__ aux) {
   const int b = blockIdx.y;
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= cpitch) return;
+  const int j = blockIdx.x * 256 + threadIdx.x;      // the grid covers cpitch exactly (a multiple of 256)
   const float2 c = (j < m) ? col_info[(size_t)b * m + j] : make_float2(0.0f, 0.0f);
+  const float w = (j < m) ? c.y * neg_inv_eps : -INFINITY;
   tp[(size_t)b * cpitch + j] = c.x;
-  wp[(size_t)b * cpitch + j] = (j < m) ? c.y * neg_inv_eps : -INFINITY;
+  wp[(size_t)b * cpitch + j] = w;
+  const float wm = block_max_256(w);
+  if (threadIdx.x == 0) aux[(size_t)b * SKD_AUX + blockIdx.x] = wm;
+  if (blockIdx.x == 0 && threadIdx.x >= gridDim.x && threadIdx.x < SKD_AUX) aux[(size_t)b * SKD_AUX + threadIdx.x] = -INFINITY;
 }
 
 // P = exp(Z + u + v) over the augmented matrix; one wave per row
@@ -302,14 +365,14 @@ ForkJoin &fork_join() {
   return fj;
 }
 
-template <int E8, int RW, int NW>
+template <int E8, int RW, int NW, bool FAST>
 void launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int batch, int n, int m, int pitch,
-                 ZParams zp, int iterations, float *u, float *v, float *part, float *wp, float *tp, float log_m,
-                 float log_n, hipStream_t s) {
+                 ZParams zp, int iterations, float *u, float *v, float *part, float *wp, float *tp, float *aux,
+                 float log_m, float log_n, hipStream_t s) {
   const int nb = ceil_div(n, NW * RW);
   constexpr int CP = 512 * E8;    // padded column count of wp / tp
-  hipLaunchKernelGGL(sk_dots_init_kernel, dim3(ceil_div(CP, 256), batch), dim3(256), 0, s, ci, m, CP, zp.neg_inv_eps,
-                     wp, tp);
+  hipLaunchKernelGGL(sk_dots_init_kernel, dim3(CP / 256, batch), dim3(256), 0, s, ci, m, CP, zp.neg_inv_eps, wp, tp,
+                     aux);
   // An iteration is a big row kernel and a tiny column kernel that depend on each other, so between them
   // the GPU drains and refills (about 5 us per iteration).  With enough pairs the batch is cut into parts
   // on separate streams: while one part is in its column kernel / launch gap another part's row kernel
@@ -332,11 +395,11 @@ void launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int b
       const float2 *ri0 = ri + (size_t)b0 * n, *ci0 = ci + (size_t)b0 * m;
       float *u0 = u + (size_t)b0 * (n + 1), *v0 = v + (size_t)b0 * (m + 1);
       float *part0 = part + (size_t)b0 * (nb + 1) * (size_t)(m + 1);
-      float *wp0 = wp + (size_t)b0 * CP, *tp0 = tp + (size_t)b0 * CP;
-      hipLaunchKernelGGL((sk_band_dots_kernel<E8, RW, NW>), dim3(nb + 1, nbatch), dim3(64 * NW), 0, st, d0, n, m, pitch,
-                         ri0, zp, v0, u0, part0, log_m, vz, wp0, tp0, CP);
+      float *wp0 = wp + (size_t)b0 * CP, *tp0 = tp + (size_t)b0 * CP, *aux0 = aux + (size_t)b0 * SKD_AUX;
+      hipLaunchKernelGGL((sk_band_dots_kernel<E8, RW, NW, FAST>), dim3(nb + 1, nbatch), dim3(64 * NW), 0, st, d0, n, m, pitch,
+                         ri0, zp, v0, u0, part0, log_m, vz, wp0, tp0, CP, aux0);
       hipLaunchKernelGGL(sk_vcombine_dots_kernel, dim3(ceil_div(m + 1, 256), nbatch), dim3(256), 0, st, part0, m, nb + 1,
-                         v0, log_n, vz, ci0, zp.neg_inv_eps, wp0, CP);
+                         v0, log_n, vz, ci0, zp.neg_inv_eps, wp0, CP, aux0);
     }
   }
   for (int q = 1; q < parts; ++q) {
@@ -359,12 +422,12 @@ int dots_cpitch(int m) { return m <= 512 ? 512 : 1024; }
 extern "C" size_t mi_sinkhorn_dots_workspace_bytes(int batch, int n, int m) {
   const int band = dots_rows_per_band(m);
   if (batch <= 0 || n <= 0 || m <= 0 || band == 0) return 0;
-  return dots_partials_bytes(batch, n, m, band) + 2 * (size_t)batch * dots_cpitch(m) * sizeof(float);
+  return dots_partials_bytes(batch, n, m, band) + (2 * (size_t)batch * dots_cpitch(m) + (size_t)batch * SKD_AUX) * sizeof(float);
 }
 
 extern "C" int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch,
-                                int n, int m, int pitch, double epsilon, double unused_score, int iterations,
-                                float *u, float *v, float *p, void *workspace, size_t workspace_bytes,
+                                int n, int m, int pitch, double epsilon, double unused_score, double sqnorm_bound,
+                                int iterations, float *u, float *v, float *p, void *workspace, size_t workspace_bytes,
                                 mi_stream_t stream) {
   if (!dots || !row_info || !col_info || !u || !v || !workspace) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
@@ -384,8 +447,15 @@ extern "C" int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, con
   float *wp = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) +
                                         dots_partials_bytes(batch, n, m, dots_rows_per_band(m)));
   float *tp = wp + (size_t)batch * dots_cpitch(m);
-  if (m <= 512) launch_dots<1, 4, 8>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, wp, tp, log_m, log_n, s);
-  else launch_dots<2, 2, 8>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, wp, tp, log_m, log_n, s);
+  float *aux = tp + (size_t)batch * dots_cpitch(m);
+  // bounded-shift row pass when the caller's norm bound makes it safe (see SKD_AUX)
+  zp.g_bound = (float)(2.0 / epsilon * sqnorm_bound);
+  zp.d_bound = (float)(sqnorm_bound / epsilon);
+  const bool fast = sqnorm_bound > 0.0 && (double)zp.g_bound * 1.4426950408889634 < (double)SKD_FAST_LIMIT;
+#define SKD_LAUNCH(E8, RW, FAST) launch_dots<E8, RW, 8, FAST>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, wp, tp, aux, log_m, log_n, s)
+  if (m <= 512) { if (fast) SKD_LAUNCH(1, 4, true); else SKD_LAUNCH(1, 4, false); }
+  else { if (fast) SKD_LAUNCH(2, 2, true); else SKD_LAUNCH(2, 2, false); }
+#undef SKD_LAUNCH
   if (p) {
     hipLaunchKernelGGL(sk_exp_dots_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, dots, n, m, pitch, ri, ci,
                        zp, u, v, p);

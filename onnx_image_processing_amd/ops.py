@@ -282,8 +282,8 @@ def sinkhorn_bits(bits1: torch.Tensor, bits2: torch.Tensor, normalized: bool, ep
     p = torch.empty((b, n + 1, m + 1), dtype=F32, device=dev) if want_p else None
     work = torch.empty(((wbytes + 7) // 8,), dtype=torch.int64, device=dev)
     N.call("mi_sinkhorn_dots", dots.data_ptr(), row_info.data_ptr(), col_info.data_ptr(), b, n, m, pitch,
-           float(epsilon), float(unused_score), int(iterations), u.data_ptr(), v.data_ptr(),
-           p.data_ptr() if p is not None else None, work.data_ptr(), wbytes, N.stream_ptr())
+           float(epsilon), float(unused_score), 1.0 if normalized else float(words * 32), int(iterations),
+           u.data_ptr(), v.data_ptr(), p.data_ptr() if p is not None else None, work.data_ptr(), wbytes, N.stream_ptr())
     if return_state:
         return p, u, v, (dots, row_info, col_info, pitch)
     return (p, u, v) if (return_duals or not want_p) else p
