@@ -220,6 +220,43 @@ def test_sinkhorn_bits_vs_float_vs_oracle(mods, n, m, d):
             assert ok, (name, normalized, worst)
 
 
+@pytest.mark.parametrize("eps,unused", [(0.035, 1.0), (0.05, 0.2), (0.2, 1.0), (1.0, 3.0), (0.03, 1.0)])
+def test_sinkhorn_dots_bounded_shift_vs_row_maximum(mods, eps, unused):
+    """The bounded-shift row pass (one analytic shift per pair; taken when 2*sqnorm_bound/eps*log2(e) < 90) and
+    the per-row-maximum kernel (sqnorm_bound = 0) against the fp64 oracle and against each other, from an
+    easy regime to the edge of the fast path's range (eps = 0.035; eps = 0.03 is past it: both calls take
+    the row-maximum kernel).  Includes empty descriptors and duplicated ones (cos = 1)."""
+    from onnx_image_processing_amd import _native as N, ops
+    rng = np.random.default_rng(int(eps * 1000))
+    n, m, d = 200, 333, 256
+    b1 = rng.random((2, n, d)) < 0.3
+    b2 = rng.random((2, m, d)) < 0.3
+    b2[:, :100] = b1[:, :100]
+    b1[0, 5] = False
+    b2[1, 7] = False
+
+    def desc(bits):
+        f = bits.astype(np.float32)
+        return f / np.maximum(np.sqrt(f.sum(-1, keepdims=True, dtype=np.float32)), np.float32(1e-12))
+    ref = O.sinkhorn_match(desc(b1).astype(np.float64), desc(b2).astype(np.float64), 20, eps, unused, dtype=np.float64)
+    t1, t2 = gpu(O.pack_bits(b1).view(np.int32)), gpu(O.pack_bits(b2).view(np.int32))
+    p_fast = ops.sinkhorn_bits(t1, t2, True, eps, unused, 20)
+    ok, worst = p_close(p_fast.cpu().numpy(), ref)
+    assert ok, worst
+    # the same call with the bound withheld: per-row maxima
+    _, _, _, (dots, ri, ci, pitch) = ops.sinkhorn_bits(t1, t2, True, eps, unused, 20, return_state=True)
+    wbytes = int(N.load().mi_sinkhorn_dots_workspace_bytes(2, n, m))
+    work = torch.empty((wbytes + 7) // 8, dtype=torch.int64, device=DEV)
+    u = torch.empty((2, n + 1), device=DEV)
+    v = torch.empty((2, m + 1), device=DEV)
+    p_slow = torch.empty((2, n + 1, m + 1), device=DEV)
+    N.call("mi_sinkhorn_dots", dots.data_ptr(), ri.data_ptr(), ci.data_ptr(), 2, n, m, pitch, float(eps), float(unused),
+           0.0, 20, u.data_ptr(), v.data_ptr(), p_slow.data_ptr(), work.data_ptr(), wbytes, N.stream_ptr())
+    ok, worst = p_close(p_slow.cpu().numpy(), ref)
+    assert ok, worst
+    assert float(((p_fast - p_slow).abs() / p_slow.abs().clamp(min=1.0)).max()) < 2e-5      # relative on the dustbin entries
+
+
 @pytest.mark.parametrize("n,m", [(512, 512), (97, 301), (5, 3), (700, 1000), (64, 1500)])
 def test_sinkhorn_fused_equals_two_pass(mods, n, m):
     """The band-fused iteration (Z read once) and the two-pass form agree to fp32 rounding, and both
