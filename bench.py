@@ -37,15 +37,17 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-
 def pmc_traffic(kernel_prefix: str, pairs_per_gpu: int):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
     (profiles/*_bench_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
-    script at 256 pairs per GPU, reads doubled per the gfx950 note).  None when no matching profile exists."""
+    script at the recorded pairs per GPU, reads doubled per the gfx950 note).  None when no profile of this batch
+    size exists."""
     import glob
-    if pairs_per_gpu != 256:
-        return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_pmc_traffic.json")))
     if not files:
         return None, None
     try:
-        kernels = json.load(open(files[-1]))["kernels"]
+        prof = json.load(open(files[-1]))
+        if int(prof.get("pairs_per_gpu", 256)) != pairs_per_gpu:
+            return None, None
+        kernels = prof["kernels"]
         for name, row in kernels.items():
             if name.startswith(kernel_prefix):
                 return row["total_MB"] * 1e6, os.path.relpath(files[-1], ROOT)
@@ -144,7 +146,9 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-gpu", type=int, default=256)
+    ap.add_argument("--pairs-per-gpu", type=int, default=448,
+                    help="pairs resident per GPU and processed per step (448: the Sinkhorn row kernel's workgroups of "
+                         "each half-batch fill whole rounds of the 256 CUs, and top-k runs two workgroups per CU)")
     ap.add_argument("--cpu-pairs", type=int, default=192, help="oracle sample size for cpu_baseline (0 = skip)")
     ap.add_argument("--two-step", action="store_true",
                     help="materialise P and run the extractor on it (default: matches straight from the duals)")

@@ -31,13 +31,13 @@ def short(name):
 
 
 line = open(os.path.join(SRC, "bench.json")).read().strip().splitlines()[-1]
-json.loads(line)
+PAIRS = int(json.loads(line)["config"]["pairs_per_gpu_per_step"])
 open(os.path.join(dst, f"{tag}_bench.json"), "w").write(line + "\n")
 
 db = sqlite3.connect(os.path.join(SRC, "stats", "stats_results.db"))
 with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-pairs 0   "
-            "(1 x MI355X, 256 pairs/step)\n# name, calls, total_ms, avg_us, pct\n")
+            f"(1 x MI355X, {PAIRS} pairs/step)\n# name, calls, total_ms, avg_us, pct\n")
     for name, calls, total, avg, pct in db.execute("select * from top_kernels"):
         f.write(f"{short(name)}, {calls}, {total / 1e3:.3f}, {avg:.2f}, {pct:.2f}\n")
 
@@ -55,9 +55,9 @@ for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         traffic[k][counter + "_KB_raw_per_launch"] = sum(v) / len(v)
         traffic[k]["launches"] = len(v)
 out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1` "
-               "(256 pairs = 2 x 256 images per step); per-launch averages; counters are KB; reads doubled per the gfx950 "
+               f"({PAIRS} pairs = 2 x {PAIRS} images per step); per-launch averages; counters are KB; reads doubled per the gfx950 "
                "note in MI355X_MICROARCH.md (FETCH_SIZE reports half of wide coalesced reads)",
-       "kernels": {}}
+       "pairs_per_gpu": PAIRS, "kernels": {}}
 for k, v in sorted(traffic.items(), key=lambda kv: -kv[1].get("FETCH_SIZE_KB_raw_per_launch", 0)):
     if k.startswith("at::") or k.startswith("__amd") or "elementwise" in k or "Cat" in k or "reduce_kernel" in k:
         continue
