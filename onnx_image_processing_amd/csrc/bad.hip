@@ -84,6 +84,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const int words = 2 * groups;
   constexpr int GMAX = GROUPS ? GROUPS : 16;
 
+  if (!plan->geometry_ok) {                                    // a plan whose geometry check failed must not be used:
+    if (lane == 0) status[flat] = 0;                           // hand the keypoint to the general kernel
+    return;
+  }
   if (!(ky >= 0.0f)) {                                         // invalid keypoint: zero descriptor (bad.py:461,570)
     if (bits) for (int q = lane; q < words; q += 64) bits[(size_t)flat * words + q] = 0u;
     if (desc) for (int q = lane; q < num_pairs; q += 64) desc[(size_t)flat * num_pairs + q] = 0.0f;
@@ -382,12 +386,6 @@ __global__ __launch_bounds__(64) void bad_plan_kernel(const uint32_t *__restrict
   }
 }
 
-__global__ void bad_plan_gate_kernel(const BadPlan *__restrict__ plan, uint8_t *__restrict__ status, int total) {
-  // a plan whose geometry check failed must not be used: hand every keypoint to the general kernel
-  if (plan->geometry_ok) return;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) status[i] = 0;
-}
-
 }  // namespace
 
 extern "C" size_t mi_bad_plan_bytes(int num_pairs) {
@@ -428,7 +426,6 @@ extern "C" int mi_sparse_bad(const float *image, int n, int h, int w, const floa
     auto fast_kernel = num_pairs == 512 ? bad_fast_kernel<8> : num_pairs == 256 ? bad_fast_kernel<4> : bad_fast_kernel<0>;
     hipLaunchKernelGGL(fast_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, s, image, h, w, keypoints,
                        k, total, num_pairs, normalize, bp, pair_geom, desc, bits, status);
-    hipLaunchKernelGGL(bad_plan_gate_kernel, dim3(64), dim3(256), 0, s, bp, status, total);
     constexpr int CHUNK = 16;
     hipLaunchKernelGGL(sparse_bad_kernel, dim3((unsigned)ceil_div(total, CHUNK)), dim3(64), 0, s, image, h, w,
                        keypoints, k, total, pair_geom, pair_thr, num_pairs, mode, temperature, normalize, scale_y,

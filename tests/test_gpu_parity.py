@@ -184,6 +184,26 @@ def test_sparse_bad_fast_path_equals_general(mods):
         assert np.array_equal(bf.cpu().numpy().view(np.uint32), O.pack_bits(aux["bits"]))
 
 
+def test_sparse_bad_plan_with_bad_geometry_is_not_used(mods):
+    """A pair table with a box that leaves the 32x32 patch fails the plan's geometry check: the fast kernel
+    must hand every keypoint to the general kernel (same output as without a plan)."""
+    from onnx_image_processing_amd import ops
+    a, _ = synth_batch(911, 1, 120, 160)
+    rng = np.random.default_rng(5)
+    kp = np.stack([rng.integers(0, 120, (1, 64)), rng.integers(0, 160, (1, 64))], -1).astype(np.float32)
+    m = mods["SparseBAD"](512, binarize=True, soft_binarize=False).to(DEV)
+    geom = m.pair_geom.clone()
+    q = int(geom[3].item()) & 0xFFFFFFFF
+    q = (q & ~(31 | (15 << 20))) | 31 | (7 << 20)                # pair 3: x offset +15, radius 7 -> box past the patch edge
+    geom[3] = q if q < 2 ** 31 else q - 2 ** 32
+    plan = ops.bad_plan(geom, m.pair_thr)
+    _, with_plan = ops.sparse_bad(gpu(a), gpu(kp), geom, m.pair_thr, m.mode, m.temperature, True, want_desc=False,
+                                  want_bits=True, plan=plan)
+    _, without = ops.sparse_bad(gpu(a), gpu(kp), geom, m.pair_thr, m.mode, m.temperature, True, want_desc=False,
+                                want_bits=True, plan=None)
+    assert torch.equal(with_plan, without)
+
+
 # ------------------------------------------------------------------ K5 / K6
 def test_sinkhorn_unit_golden(mods):
     g = load_golden("sinkhorn_unit")
