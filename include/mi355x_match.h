@@ -288,6 +288,39 @@ int mi_fast_score(const float *image, int n, int h, int w, float threshold, floa
 int mi_dog_responses(const float *image, int n, int h, int w, const float *weights_1d, int num_scales,
                      int kernel_size, float *out, float *score, mi_stream_t stream);
 
+/* ---- feature_detection/match_extraction_wrapper.py:82-113 over shi_tomasi_sparse_bad_sinkhorn.py:79-182
+ * The whole path for `batch` image pairs in one call: image1[b] vs image2[b], (batch,1,h,w) f32 each ->
+ * keypoints1/2 (batch,K,2) as (y,x), matched1/2 (batch,max_matches,2), match_scores (batch,max_matches),
+ * match_valid (batch,max_matches) bytes, match_ij (batch,max_matches,2) int32 or NULL.  Hard-binarised
+ * descriptors, L2 cost, matches straight from the Sinkhorn duals (P is never written); K <= 1024.
+ * It sequences mi_corner_response, mi_nms_candidates, mi_topk_keypoints, mi_sparse_bad (twice each),
+ * mi_cost_dots_bits, mi_sinkhorn_dots and mi_mnn_from_duals_dots on `stream`, with every intermediate in
+ * `workspace` (mi_match_pairs_workspace_bytes, 16-byte aligned): nothing is allocated, nothing synchronises.
+ * Results are bit-identical to calling those entry points one by one (what the Python modules do).
+ * pair_geom / pair_thr / bad_plan: device pointers as for mi_sparse_bad (bad_plan may be NULL). */
+typedef struct mi_match_params {
+  int block_size;            /* ShiTomasiScore(block_size), 3 in the export CLI */
+  int nms_radius;            /* apply_nms_maxpool radius */
+  int max_keypoints;         /* K */
+  float score_threshold;     /* select_topk_keypoints */
+  int border_margin;         /* select_topk_keypoints; the matcher's default is the descriptor's max radius (7) */
+  int num_pairs;             /* BAD pairs P: 256 or 512 with the reference tables */
+  const uint32_t *pair_geom; /* device, P words */
+  const float *pair_thr;     /* device, P floats */
+  const void *bad_plan;      /* device, mi_bad_plan_build output, or NULL */
+  int normalize_descriptors; /* SparseBAD(normalize_descriptors=...) */
+  double epsilon;            /* SinkhornMatcher */
+  double unused_score;
+  int sinkhorn_iterations;
+  int max_matches;           /* MutualNearestNeighborMatcher */
+  float match_threshold;
+} mi_match_params;
+size_t mi_match_pairs_workspace_bytes(int batch, int h, int w, const mi_match_params *params);
+int mi_match_pairs(const float *image1, const float *image2, int batch, int h, int w,
+                   const mi_match_params *params, float *keypoints1, float *keypoints2, float *matched1,
+                   float *matched2, float *match_scores, uint8_t *match_valid, int32_t *match_ij,
+                   void *workspace, size_t workspace_bytes, mi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,7 +70,21 @@ SIGNATURES = {
     "mi_akaze_orientation_at_keypoints": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                           c_void_p],
 }
-_RESTYPE = {"mi_error_string": c_char_p, "mi_sinkhorn_workspace_bytes": c_size_t, "mi_bad_plan_bytes": c_size_t,
+
+
+class MatchParams(ctypes.Structure):
+    """mi_match_params (include/mi355x_match.h): the hyper-parameters of the whole path for mi_match_pairs."""
+    _fields_ = [("block_size", c_int), ("nms_radius", c_int), ("max_keypoints", c_int), ("score_threshold", c_float),
+                ("border_margin", c_int), ("num_pairs", c_int), ("pair_geom", c_void_p), ("pair_thr", c_void_p),
+                ("bad_plan", c_void_p), ("normalize_descriptors", c_int), ("epsilon", c_double),
+                ("unused_score", c_double), ("sinkhorn_iterations", c_int), ("max_matches", c_int),
+                ("match_threshold", c_float)]
+
+
+SIGNATURES["mi_match_pairs_workspace_bytes"] = [c_int, c_int, c_int, ctypes.POINTER(MatchParams)]
+SIGNATURES["mi_match_pairs"] = [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(MatchParams), c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+_RESTYPE = {"mi_match_pairs_workspace_bytes": c_size_t, "mi_error_string": c_char_p, "mi_sinkhorn_workspace_bytes": c_size_t, "mi_bad_plan_bytes": c_size_t,
             "mi_sinkhorn_dots_workspace_bytes": c_size_t, "mi_mnn_duals_workspace_bytes": c_size_t}
 
 MI_BAD_RAW, MI_BAD_SOFT, MI_BAD_HARD = 0, 1, 2
@@ -128,11 +142,15 @@ def dev(t: torch.Tensor, dtype: torch.dtype, what: str) -> int:
 _timers: dict | None = None
 
 
-def enable_timing(on: bool) -> None:
-    """Bracket every C-ABI call with HIP events on the launch stream (bench.py's per-kernel
-    clock).  Off by default: no events, no overhead."""
-    global _timers
+_timed_names = None
+
+
+def enable_timing(on: bool, only=None) -> None:
+    """Bracket C-ABI calls with HIP events on the launch stream (bench.py's per-kernel clock): every call, or
+    only the entry points named in `only`.  Off by default: no events, no overhead."""
+    global _timers, _timed_names
     _timers = {} if on else None
+    _timed_names = set(only) if (on and only) else None
 
 
 def timings_ms() -> dict:
@@ -143,7 +161,7 @@ def timings_ms() -> dict:
 
 def call(name: str, *args) -> None:
     fn = getattr(load(), name)
-    if _timers is None:
+    if _timers is None or (_timed_names is not None and name not in _timed_names):
         check(fn(*args), name)
         return
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

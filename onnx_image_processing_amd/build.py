@@ -20,7 +20,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libmi355x_match.so")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 
-SOURCES = ["corner.hip", "nms.hip", "topk.hip", "bad.hip", "bad_oriented.hip", "bad_dense.hip", "orient.hip", "cost.hip", "sinkhorn.hip", "sinkhorn_dots.hip", "mnn.hip", "akaze.hip", "essential.hip", "detectors.hip"]
+SOURCES = ["corner.hip", "nms.hip", "topk.hip", "bad.hip", "bad_oriented.hip", "bad_dense.hip", "orient.hip", "cost.hip", "sinkhorn.hip", "sinkhorn_dots.hip", "mnn.hip", "akaze.hip", "essential.hip", "detectors.hip", "match_pairs.hip"]
 # -ffp-contract=off: the corner response must not fuse a*b+c (bit parity with the reference's
 # op-by-op fp32); IEEE sqrt/div are hipcc's defaults and are relied upon.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",

@@ -487,3 +487,39 @@ def core_maxima(p: torch.Tensor):
     c = torch.empty((b, m), dtype=F32, device=pp.device)
     N.call("mi_core_maxima", N.dev(pp, F32, "P"), b, n, m, r.data_ptr(), c.data_ptr(), N.stream_ptr())
     return r, c
+
+
+def match_pairs(image1: torch.Tensor, image2: torch.Tensor, *, block_size: int, nms_radius: int, max_keypoints: int,
+                score_threshold: float, border_margin: int, pair_geom: torch.Tensor, pair_thr: torch.Tensor,
+                plan: torch.Tensor | None, normalize_descriptors: bool, epsilon: float, unused_score: float,
+                sinkhorn_iterations: int, max_matches: int, match_threshold: float, want_ij: bool = False):
+    """The whole path in ONE C-ABI call (`mi_match_pairs`): what MatchExtractionWrapper(ShiTomasiSparseBADSinkhornMatcher)
+    computes for hard-binarised descriptors and the L2 cost, bit-identical to the module path.
+    -> (keypoints1, keypoints2, matched1, matched2, scores, valid[, match_ij])."""
+    a, b2 = _images(image1, "image1"), _images(image2, "image2")
+    if a.shape != b2.shape:
+        raise RuntimeError(f"image shapes differ: {tuple(a.shape)} vs {tuple(b2.shape)}")
+    n, _, h, w = a.shape
+    dev = a.device
+    prm = N.MatchParams(int(block_size), int(nms_radius), int(max_keypoints), float(score_threshold), int(border_margin),
+                        int(pair_geom.numel()), N.dev(pair_geom, torch.int32, "pair_geom"), N.dev(pair_thr, F32, "pair_thr"),
+                        plan.data_ptr() if plan is not None else None, int(bool(normalize_descriptors)), float(epsilon),
+                        float(unused_score), int(sinkhorn_iterations), int(max_matches), float(match_threshold))
+    import ctypes
+    wbytes = int(N.load().mi_match_pairs_workspace_bytes(n, h, w, ctypes.byref(prm)))
+    if wbytes == 0:
+        raise RuntimeError("mi_match_pairs does not cover these parameters (K <= 1024, P % 64 == 0, odd block size ...)")
+    work = torch.empty(((wbytes + 7) // 8,), dtype=torch.int64, device=dev)
+    k, mx = int(max_keypoints), int(max_matches)
+    kp1 = torch.empty((n, k, 2), dtype=F32, device=dev)
+    kp2 = torch.empty((n, k, 2), dtype=F32, device=dev)
+    mk1 = torch.empty((n, mx, 2), dtype=F32, device=dev)
+    mk2 = torch.empty((n, mx, 2), dtype=F32, device=dev)
+    sc = torch.empty((n, mx), dtype=F32, device=dev)
+    valid = torch.empty((n, mx), dtype=torch.bool, device=dev)
+    ij = torch.empty((n, mx, 2), dtype=torch.int32, device=dev) if want_ij else None
+    N.call("mi_match_pairs", N.dev(a, F32, "image1"), N.dev(b2, F32, "image2"), n, h, w, ctypes.byref(prm), kp1.data_ptr(),
+           kp2.data_ptr(), mk1.data_ptr(), mk2.data_ptr(), sc.data_ptr(), valid.data_ptr(),
+           ij.data_ptr() if ij is not None else None, work.data_ptr(), wbytes, N.stream_ptr())
+    out = (kp1, kp2, mk1, mk2, sc, valid)
+    return out + (ij,) if want_ij else out

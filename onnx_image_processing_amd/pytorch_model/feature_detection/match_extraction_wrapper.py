@@ -33,3 +33,25 @@ class MatchExtractionWrapper(nn.Module):
             return sol.mutual_matches(k1, k2, self.match_extractor.max_matches, self.match_extractor.threshold)
         out = self.feature_matcher(image1, image2)
         return self.match_extractor(out[2], out[0], out[1])
+
+    @torch.no_grad()
+    def forward_single_call(self, image1: torch.Tensor, image2: torch.Tensor, want_keypoints: bool = False):
+        """forward() as ONE C-ABI call (`mi_match_pairs`): the entry point a non-Python host binds.  Requires a
+        ShiTomasiSparseBADSinkhornMatcher with hard-binarised descriptors and the L2 cost; same outputs bit for bit.
+        want_keypoints: also return (keypoints1, keypoints2)."""
+        fm = self.feature_matcher
+        from .shi_tomasi_sparse_bad_sinkhorn import ShiTomasiSparseBADSinkhornMatcher
+        from ... import _native as N
+        if not isinstance(fm, ShiTomasiSparseBADSinkhornMatcher) or fm.descriptor.mode != N.MI_BAD_HARD \
+                or fm.matcher.distance_type != "l2" or fm.descriptor.sampling_mode != "nearest":
+            raise RuntimeError("forward_single_call covers ShiTomasiSparseBADSinkhornMatcher(binarize=True, soft_binarize=False, "
+                               "distance_type='l2', sampling_mode='nearest')")
+        d = fm.descriptor
+        d._check(image1, None)
+        out = ops.match_pairs(image1, image2, block_size=fm.corner_detector.block_size, nms_radius=fm.nms_radius,
+                              max_keypoints=fm.max_keypoints, score_threshold=fm.score_threshold,
+                              border_margin=fm.border_margin, pair_geom=d.pair_geom, pair_thr=d.pair_thr, plan=d._get_plan(),
+                              normalize_descriptors=d.normalize_descriptors, epsilon=fm.matcher.epsilon,
+                              unused_score=fm.matcher.unused_score, sinkhorn_iterations=fm.matcher.iterations,
+                              max_matches=self.match_extractor.max_matches, match_threshold=self.match_extractor.threshold)
+        return out if want_keypoints else out[2:]
