@@ -56,8 +56,10 @@ def pmc_traffic(kernel_prefix: str, pairs_per_gpu: int):
     return None, None
 
 
-def cpu_baseline(pairs: int) -> dict:
-    """The oracle (numpy port of the reference algorithm) on this host's cores, same workload."""
+def cpu_baseline(pairs: int, gpu_records=None) -> dict:
+    """The oracle (numpy port of the reference algorithm) on this host's cores, same workload.  gpu_records: the
+    (pairs, max_matches, 6) match records the GPU path produced for the same pairs (rank 0's first `pairs` pairs);
+    when given, the oracle's outputs are compared with them after the clock stops ("parity")."""
     from oracle import numpy_oracle as O
     from onnx_image_processing_amd.synth import synth_batch
     try:
@@ -69,14 +71,41 @@ def cpu_baseline(pairs: int) -> dict:
     kw = {k: v for k, v in CFG.items() if k not in ("num_pairs", "sampling_mode")}
     a, b = synth_batch(1000, pairs, H, W)
     O.match_pair(a[:1], b[:1], t["box_512"], t["thr_512"], K, **kw)          # warm-up
+    results = []
     t0 = time.perf_counter()
     for i in range(pairs):
         k1, k2, p = O.match_pair(a[i:i + 1], b[i:i + 1], t["box_512"], t["thr_512"], K, **kw)
-        O.mnn_extract(p, k1, k2, **MNN)
+        results.append(O.mnn_extract(p, k1, k2, **MNN))
     dt = time.perf_counter() - t0
-    return {"value": pairs / dt, "unit": "image-pairs/sec", "cores": int(threads), "kind": "port",
-            "sample": f"{pairs} pairs 640x480 K=512 (seeds 1000..{999 + pairs}), oracle/numpy_oracle.py, one pair "
-                      f"at a time; BLAS matmul uses {threads} threads, the rest is single-threaded numpy"}
+    out = {"value": pairs / dt, "unit": "image-pairs/sec", "cores": int(threads), "kind": "port",
+           "sample": f"{pairs} pairs 640x480 K=512 (seeds 1000..{999 + pairs}), oracle/numpy_oracle.py, one pair "
+                     f"at a time; BLAS matmul uses {threads} threads, the rest is single-threaded numpy"}
+    if gpu_records is not None:
+        # match-set parity of the very pairs just timed: same matched coordinates, same validity, scores within 1e-4
+        # A pair with more than max_matches mutual matches keeps the max_matches best: two scores closer than the 1e-4
+        # bound that straddle that cut may legitimately swap ("cut ties"); anything else is a real difference.
+        same, cut, other, worst, nmatch = 0, 0, 0, 0.0, 0
+        for i, (mk1, mk2, sc, valid, _) in enumerate(results):
+            g = gpu_records[i]
+            gv = g[:, 5] > 0.5
+            want = {(*mk1[0, j], *mk2[0, j]): float(sc[0, j]) for j in np.nonzero(valid[0])[0]}
+            got = {tuple(g[j, 0:4]): float(g[j, 4]) for j in np.nonzero(gv)[0]}
+            nmatch += len(want)
+            worst = max([worst] + [abs(want[k] - got[k]) for k in set(want) & set(got)])
+            if set(want) == set(got):
+                same += 1
+                continue
+            full = len(want) == MNN["max_matches"] and len(got) == MNN["max_matches"]
+            lo = min(min(want.values()), min(got.values()))
+            odd = [k for k in set(want) ^ set(got) if abs({**want, **got}[k] - lo) > 1e-4]
+            if full and not odd:
+                cut += 1
+            else:
+                other += 1
+        out["parity"] = {"pairs_checked": pairs, "pairs_with_identical_match_set": same,
+                         "pairs_differing_only_by_ties_at_the_max_matches_cut": cut, "pairs_differing_otherwise": other,
+                         "matches_checked": nmatch, "max_abs_score_diff": worst, "bound": 1e-4}
+    return out
 
 
 def side_workload(args, rank, world, dev) -> None:
@@ -280,7 +309,8 @@ def main() -> None:
             },
         }
         if world == 1 and args.cpu_pairs > 0:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_pairs, out[:args.cpu_pairs].cpu().numpy()
+                                                if args.cpu_pairs <= B else None)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
