@@ -107,10 +107,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   int *isat = sat_all[wave];
   const int half = lane >> 5, c = lane & 31;
   // lane = (half, column c): 16 rows of its column, all loads issued before use
-  const int gx = clampi(ox + c, 0, w - 1);
+  // scalar base + 32-bit byte offsets.  Interior windows lie inside the image: one multiply for the lane's first
+  // row, then a scalar row step per load; only windows that touch the border pay the per-row clamp and multiply
+  // (the kernel is bound by VALU issue: the clamped form was a quarter of its instruction slots).
+  // (`interior` allows ky = 15 or ky = h - 15, whose window has one row or column outside the image that no
+  // box uses: those take the clamped form too)
+  const bool window_inside = ky >= 16.0f && ky <= (float)(h - 16) && kx >= 16.0f && kx <= (float)(w - 16);
+  uint32_t off[16];
+  if (window_inside) {                                         // wave-uniform
+    const uint32_t first = (uint32_t)((oy + 16 * half) * w + ox + c) * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) off[r] = first + (uint32_t)(r * w) * 4u;
+  } else {
+    const int gx = clampi(ox + c, 0, w - 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) off[r] = (uint32_t)(clampi(oy + 16 * half + r, 0, h - 1) * w + gx) * 4u;
+  }
   float px[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) px[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(im) + (uint32_t)(clampi(oy + 16 * half + r, 0, h - 1) * w + gx) * 4u);   // scalar base + 32-bit byte offset
+  for (int r = 0; r < 16; ++r) px[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(im) + off[r]);
   const uint4 *plan_offs = reinterpret_cast<const uint4 *>(plan + 1);
   const int *plan_tint = reinterpret_cast<const int *>(plan_offs + num_pairs);
   // the first pair-table words ride behind the window gather instead of waiting for the table build
