@@ -96,7 +96,10 @@ int mi_topk_keypoints(const uint64_t *cand, const uint32_t *count, int segments,
  * with integer coordinates inside the image that sit on an integer-valued (uint8) patch take an
  * int32 fast path (precomputed table corners when >= 15 px from the border); results are identical.
  * status (optional, required for the fast path): n*k bytes of workspace; the fast kernel marks
- * the keypoints it handled and the general kernel visits the rest. */
+ * the keypoints it handled and the general kernel visits the rest.
+ * mi_bad_plan_build is the one set-up call of this ABI that synchronises: it reads the table back,
+ * orders every pair's table-corner reads on the host so that the fast kernel's LDS gathers hit as few
+ * banks twice as possible, and uploads the plan (two stream synchronisations; not hipGraph-capturable). */
 size_t mi_bad_plan_bytes(int num_pairs);
 int mi_bad_plan_build(const uint32_t *pair_geom, const float *pair_thr, int num_pairs, void *plan,
                       mi_stream_t stream);
