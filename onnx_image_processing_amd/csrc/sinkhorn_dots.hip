@@ -42,16 +42,15 @@ __device__ __forceinline__ float z_of(float dot, float2 row, float2 col, float n
 // row's largest term is >= 2^(-G log2 e), so with G log2 e < SKD_FAST_LIMIT all sums stay far inside the
 // normal range (unit descriptors: down to eps ~ 0.03).  The per-row maximum -- a max per element, a wave
 // reduction per row and the shift fma ahead of every v_exp_f32 -- disappears.  max_j wp_j comes from the
-// column kernels: SKD_AUX block maxima per pair in the workspace.  Otherwise the per-row-maximum kernel runs.
-constexpr int SKD_AUX = 8;
+// column kernels: one maximum per wave of theirs (SKD_AUX slots per pair in the workspace; no barrier in those
+// latency-bound kernels).  Otherwise the per-row-maximum kernel runs.
+constexpr int SKD_AUX = 20;      // up to 5 blocks (m <= 1024) x 4 waves
 constexpr float SKD_FAST_LIMIT = 90.0f;
 
-__device__ __forceinline__ float block_max_256(float x) {     // all 256 threads; result valid in thread 0
-  __shared__ float wmx[4];
+// wave w of block k of a column kernel publishes the maximum of its 64 columns in slot 4k + w
+__device__ __forceinline__ void publish_wave_max(float x, float *__restrict__ aux_pair) {
   x = wave_max_dpp(x);
-  if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = x;
-  __syncthreads();
-  return fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
+  if ((threadIdx.x & 63) == 0) aux_pair[blockIdx.x * 4 + (threadIdx.x >> 6)] = x;
 }
 
 // v_j <- v_j + log nu_j - log(sum of the bands' P_ij + exp(B_j))   (B_j: dustbin row, log domain)
@@ -172,7 +171,9 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
   float nm_pair = 0.0f;          // -S * log2(e)
   if constexpr (FAST) {
     const float *ab = aux + (size_t)b * SKD_AUX;
-    const float wmax = fmaxf(fmaxf(fmaxf(ab[0], ab[1]), fmaxf(ab[2], ab[3])), fmaxf(fmaxf(ab[4], ab[5]), fmaxf(ab[6], ab[7])));
+    float wmax = ab[0];
+#pragma unroll
+    for (int k = 1; k < SKD_AUX; ++k) wmax = fmaxf(wmax, ab[k]);
     const float S = fmaxf(wmax + zp.g_bound, xd0 + zp.d_bound);
     nm_pair = -(S * SKD_L2E);
 #pragma unroll
@@ -305,8 +306,7 @@ __global__ __launch_bounds__(256) void sk_vcombine_dots_kernel(const float *__re
       wp[(size_t)b * cpitch + j] = w;
     }
   }
-  w = block_max_256(w);                        // this block's share of max_j wp_j for the next row pass
-  if (threadIdx.x == 0) aux[(size_t)b * SKD_AUX + blockIdx.x] = w;
+  publish_wave_max(w, aux + (size_t)b * SKD_AUX);   // this wave's share of max_j wp_j for the next row pass
 }
 
 // first-iteration column data: tp = column scale, wp = nie * squared norm (v = 0); padding 0 / -inf
@@ -319,9 +319,9 @@ __global__ __launch_bounds__(256) void sk_dots_init_kernel(const float2 *__restr
   const float w = (j < m) ? c.y * neg_inv_eps : -INFINITY;
   tp[(size_t)b * cpitch + j] = c.x;
   wp[(size_t)b * cpitch + j] = w;
-  const float wm = block_max_256(w);
-  if (threadIdx.x == 0) aux[(size_t)b * SKD_AUX + blockIdx.x] = wm;
-  if (blockIdx.x == 0 && threadIdx.x >= gridDim.x && threadIdx.x < SKD_AUX) aux[(size_t)b * SKD_AUX + threadIdx.x] = -INFINITY;
+  publish_wave_max(w, aux + (size_t)b * SKD_AUX);
+  // slots no block of this kernel owns: the column kernel has one block more when m is a multiple of 256 (column m)
+  if (blockIdx.x == 0 && threadIdx.x >= 4 * gridDim.x && threadIdx.x < SKD_AUX) aux[(size_t)b * SKD_AUX + threadIdx.x] = -INFINITY;
 }
 
 // P = exp(Z + u + v) over the augmented matrix; one wave per row
