@@ -58,18 +58,27 @@ __device__ __forceinline__ float combine_column(const float *__restrict__ part_b
                                                 float vold, float log_n) {
   const float *p = part_b + j;
   const size_t stride = (size_t)(m + 1);
-  // the bands' sums, added in band order; loads issued eight at a time (one L2 round trip, not nparts)
+  // the bands' sums, added in band order.  This kernel is a dependency between two row kernels, so its own
+  // latency is on the iteration's critical path: the dustbin row and sixteen bands at a time are requested
+  // before anything is added (one L2 round trip for n = 512; eight at a time cost two and a third).
+  const float bj = p[(size_t)(nparts - 1) * stride];
   float s = 0.0f;
   int k = 0;
-  for (; k + 8 <= nparts - 1; k += 8) {
-    float t[8];
+  for (; k + 16 <= nparts - 1; k += 16) {
+    float t[16];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) t[q] = p[(size_t)(k + q) * stride];
+    for (int q = 0; q < 16; ++q) t[q] = p[(size_t)(k + q) * stride];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s += t[q];
+    for (int q = 0; q < 16; ++q) s += t[q];
+  }
+  for (; k + 4 <= nparts - 1; k += 4) {
+    float t[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = p[(size_t)(k + q) * stride];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s += t[q];
   }
   for (; k < nparts - 1; ++k) s += p[(size_t)k * stride];
-  const float bj = p[(size_t)(nparts - 1) * stride];
   // log(s + exp(bj)) as a two-term log-sum-exp; s == 0 (everything underflowed) leaves bj.
   // v_log_f32 / v_exp_f32 (1 ulp): this runs at the head of every workgroup of the iteration kernel.
   const float a = s > 0.0f ? __builtin_amdgcn_logf(s) * SKD_LN2 : -INFINITY;
