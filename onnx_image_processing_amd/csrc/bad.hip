@@ -14,7 +14,7 @@
 //    the border, on an integer-valued (uint8) patch.  Then no box centre is clamped, every box
 //    lies in the 32x32 window [k-16, k+15], the four table corners of each box are the same for
 //    every keypoint (precomputed byte offsets), sums are exact int32 and the sign test is
-//    D <= floor(thr*area).  4 keypoints per 256-thread workgroup, wave-private LDS (4.3 KiB per
+//    D <= floor(thr*area).  4 keypoints per 256-thread workgroup, wave-private LDS (4.5 KiB per
 //    wave) and no workgroup barrier, so occupancy is high.  Keypoints it cannot take are flagged.
 //  * sparse_bad_kernel (general): 34x34 window, fp64 table (exact for integer images, ~1e-13
 //    otherwise), box centres through the exact grid_sample(nearest, border, align_corners)
@@ -41,7 +41,7 @@ constexpr int FW = 35;           // its row pitch: odd (the table build walks ro
                                  // 33..39, the pitch with the fewest bank-conflict passes of the pair gathers (-8 % vs 33)
 
 // Device-resident plan for the fast path, built once per pair table by mi_bad_plan_build:
-// header, then uint4 offs[P] (eight 16-bit BYTE offsets into the int32 33x33 table: the four corners that
+// header, then uint4 offs[P] (eight 16-bit BYTE offsets into the int32 table of 33 rows, pitch FW: the four corners that
 // enter s1 - s2 with + in x, y, the four with - in z, w, low half first, in the order order_reads chose), then
 // int tint[P] = floor(thr * area).
 struct BadPlan {
