@@ -186,15 +186,24 @@ __global__ __launch_bounds__(64 * NW) void mnn_band_kernel(SRC src, int n, int m
   const int b = blockIdx.y, band = blockIdx.x, nb = gridDim.x;
   const int row0 = band * BAND + wave * RW;
 
+  // per-column data: the workgroup fetches v and col_info once with coalesced loads and every lane picks its
+  // eight consecutive columns out of LDS (sixteen strided 4- and 8-byte loads per lane otherwise: the address
+  // unit, not the data, was what this prologue cost)
+  __shared__ float s_v[NC];
+  __shared__ float2 s_ci[NC];
+  for (int c = threadIdx.x; c < NC; c += 64 * NW) {
+    s_v[c] = c < m ? v[(size_t)b * (m + 1) + c] : 0.0f;
+    s_ci[c] = (col_info && c < m) ? col_info[(size_t)b * m + c] : make_float2(0.f, 0.f);
+  }
+  __syncthreads();
   float vv[E8][8];
   float2 ci[E8][8];
 #pragma unroll
   for (int e = 0; e < E8; ++e)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const int j = e * 512 + lane * 8 + q;
-      vv[e][q] = j < m ? v[(size_t)b * (m + 1) + j] : 0.0f;
-      ci[e][q] = (col_info && j < m) ? col_info[(size_t)b * m + j] : make_float2(0.f, 0.f);
+      vv[e][q] = s_v[e * 512 + lane * 8 + q];
+      ci[e][q] = s_ci[e * 512 + lane * 8 + q];
     }
 
   float cbest[E8][8];      // per-lane column winners over this wave's rows: rows ascend, strict > keeps the first
