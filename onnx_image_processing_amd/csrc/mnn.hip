@@ -140,15 +140,23 @@ __global__ __launch_bounds__(MX_THREADS) void mnn_select_kernel(
 struct ZSourceF32 {
   const float *z;       // (batch, n, pitch)
   int pitch;
-  __device__ __forceinline__ void load(int b, int n, int i, int j, int m, float (&out)[8]) const {
+  struct Raw { float4 a, c; };
+  struct Row {};
+  __device__ __forceinline__ Raw load_raw(int b, int n, int i, int j, int m) const {
     const float *src = z + ((size_t)b * n + i) * pitch + j;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-    if (j < m) a = *reinterpret_cast<const float4 *>(src);             // pitch % 4 == 0
-    if (j + 4 < m) c = *reinterpret_cast<const float4 *>(src + 4);
-    out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
-    out[4] = c.x; out[5] = c.y; out[6] = c.z; out[7] = c.w;
+    Raw r;
+    r.a = make_float4(0.f, 0.f, 0.f, 0.f);
+    r.c = r.a;
+    if (j < m) r.a = *reinterpret_cast<const float4 *>(src);           // pitch % 4 == 0
+    if (j + 4 < m) r.c = *reinterpret_cast<const float4 *>(src + 4);
+    return r;
   }
-  __device__ __forceinline__ void begin_row(int, int, int) {}
+  __device__ __forceinline__ void decode(const Raw &r, float (&out)[8]) const {
+    out[0] = r.a.x; out[1] = r.a.y; out[2] = r.a.z; out[3] = r.a.w;
+    out[4] = r.c.x; out[5] = r.c.y; out[6] = r.c.z; out[7] = r.c.w;
+  }
+  __device__ __forceinline__ Row load_row(int, int, int) const { return Row(); }
+  __device__ __forceinline__ void begin_row(const Row &) {}
   __device__ __forceinline__ float col(int, int) const { return 0.0f; }
   __device__ __forceinline__ void finish(float (&)[8], const float2 (&)[8]) const {}
 };
@@ -159,14 +167,20 @@ struct ZSourceDots {
   const float2 *row_info, *col_info;
   float neg_inv_eps;
   float2 ri;
-  __device__ __forceinline__ void load(int b, int n, int i, int j, int m, float (&out)[8]) const {
+  typedef uint4 Raw;
+  typedef float2 Row;
+  __device__ __forceinline__ Raw load_raw(int b, int n, int i, int j, int m) const {
     uint4 r = make_uint4(0u, 0u, 0u, 0u);
     if (j < m) r = *reinterpret_cast<const uint4 *>(dots + ((size_t)b * n + i) * pitch + j);   // pitch % 8 == 0
+    return r;
+  }
+  __device__ __forceinline__ void decode(const Raw &r, float (&out)[8]) const {
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
     for (int q = 0; q < 8; ++q) out[q] = (float)((q & 1) ? (w[q >> 1] >> 16) : (w[q >> 1] & 0xFFFFu));
   }
-  __device__ __forceinline__ void begin_row(int b, int n, int i) { ri = row_info[(size_t)b * n + i]; }
+  __device__ __forceinline__ Row load_row(int b, int n, int i) const { return row_info[(size_t)b * n + i]; }
+  __device__ __forceinline__ void begin_row(const Row &r) { ri = r; }
   __device__ __forceinline__ void finish(float (&x)[8], const float2 (&ci)[8]) const {
 #pragma unroll
     for (int q = 0; q < 8; ++q) x[q] = mi_z_from_dot(x[q], ri, ci[q], neg_inv_eps);
@@ -213,19 +227,31 @@ __global__ __launch_bounds__(64 * NW) void mnn_band_kernel(SRC src, int n, int m
 #pragma unroll
     for (int q = 0; q < 8; ++q) { cbest[e][q] = -1.0f; cidx[e][q] = 0; }
 
+  // all rows of the wave are requested before the first is evaluated (a load issued where it is used costs the
+  // wave one memory round trip per row)
+  typename SRC::Raw raw[RW][E8];
+  typename SRC::Row rowd[RW];
+  float uis[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int ic = min(row0 + r, n - 1);
+    uis[r] = u[(size_t)b * (n + 1) + ic];
+    rowd[r] = src.load_row(b, n, ic);
+#pragma unroll
+    for (int e = 0; e < E8; ++e) raw[r][e] = src.load_raw(b, n, ic, e * 512 + lane * 8, m);
+  }
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
     const int i = row0 + r;
     const bool live = i < n;
-    const int ic = live ? i : n - 1;
-    const float ui = u[(size_t)b * (n + 1) + ic];
-    src.begin_row(b, n, ic);
+    const float ui = uis[r];
+    src.begin_row(rowd[r]);
     float rbest = -1.0f;   // per-lane row winner: columns ascend within a lane
     int rj = 0;
 #pragma unroll
     for (int e = 0; e < E8; ++e) {
       float x[8];
-      src.load(b, n, ic, e * 512 + lane * 8, m, x);
+      src.decode(raw[r][e], x);
       src.finish(x, ci[e]);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
