@@ -12,6 +12,9 @@
 // for the k-th largest key straight from global memory, then sort only the k survivors.
 #include "common.h"
 
+// test hook (key 9): 1 = radix-select the k-th key and sort only the k selected keys whenever n > k
+int mi_g_topk_select = 1;
+
 namespace {
 
 constexpr int TK_THREADS = 1024;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
                                                           const uint32_t *__restrict__ count, int segments,
                                                           uint32_t seg_cap, int w, int k,
                                                           float *__restrict__ kpts,
-                                                          float *__restrict__ kscores) {
+                                                          float *__restrict__ kscores, int select_mode) {
   __shared__ uint64_t keys[TK_MAX];
   __shared__ uint64_t keys2[TK_MAX];      // second buffer of the register sort's cross-wave stages
   __shared__ uint32_t seg_cnt[TK_SEGS], seg_base[TK_SEGS];
@@ -177,11 +180,88 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
     int npad = 2;
     while (npad < (int)n) npad <<= 1;
     __syncthreads();
+    if (select_mode && n > (uint32_t)k && 4 * k <= TK_MAX) {
+      // Far fewer keys are wanted than there are candidates (512 of ~3300 at 640x480): find the k-th largest key
+      // by MSB radix select on register copies of the LDS keys (at most 8 passes of 8 bits, typically 4: the
+      // passes stop as soon as a whole bin is wanted), move the k winners to the second buffer and sort only
+      // those -- 45 stages on 512 keys instead of 78 on 4096.
+      uint64_t r[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[q] = (uint32_t)(t + q * TK_THREADS) < n ? keys[t + q * TK_THREADS] : 0ull;
+      if (t == 0) { s_prefix = 0ull; s_krem = (uint32_t)k; s_fill = 0u; s_done = 0u; }
+      uint64_t mask = 0ull;
+      for (int shift = 56; shift >= 0; shift -= 8) {
+        if (t < 256) hist[t] = 0u;
+        __syncthreads();
+        const uint64_t prefix = s_prefix;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool act = r[q] != 0ull && ((r[q] & mask) == prefix);
+          const uint32_t digit = (uint32_t)(r[q] >> shift) & 255u;
+          // wave-level aggregation: the leading digits are shared by almost every key
+          const unsigned long long am = __ballot(act);
+          if (am) {
+            const int leader = __ffsll((long long)am) - 1;
+            const uint32_t d0 = __shfl(digit, leader, 64);
+            const unsigned long long same = __ballot(act && digit == d0);
+            if (lane == leader) atomicAdd(&hist[d0], (uint32_t)__popcll(same));
+            if (act && digit != d0) atomicAdd(&hist[digit], 1u);
+          }
+        }
+        __syncthreads();
+        if (t < 64) {
+          // lane l owns bins 255-4l .. 252-4l (descending); find the bin holding the krem-th key
+          const uint32_t krem = s_krem;
+          uint32_t c[4], tot = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { c[q] = hist[255 - 4 * t - q]; tot += c[q]; }
+          uint32_t incl = tot;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if (t >= o) incl += up;
+          }
+          uint32_t above = incl - tot;
+          if (above < krem && krem <= incl) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (krem <= above + c[q]) {
+                s_prefix = prefix | ((uint64_t)(255 - 4 * t - q) << shift);
+                s_krem = krem - above;
+                if (krem - above == c[q]) s_done = 1u;      // the whole bin is wanted: no further digit needed
+                break;
+              }
+              above += c[q];
+            }
+          }
+        }
+        mask |= (0xFFull << shift);
+        __syncthreads();
+        if (s_done) break;                // workgroup-uniform
+      }
+      const uint64_t kth = s_prefix;      // keys are distinct: exactly k keys are >= kth
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (r[q] != 0ull && r[q] >= kth) {
+          const uint32_t slot = atomicAdd(&s_fill, 1u);
+          if (slot < (uint32_t)TK_MAX) keys2[slot] = r[q];
+        }
+      __syncthreads();
+      nsel = (int)(s_fill < (uint32_t)k ? s_fill : (uint32_t)k);
+      int kpad = 2;
+      while (kpad < k) kpad <<= 1;
+      for (int i = nsel + t; i < kpad; i += TK_THREADS) keys2[i] = 0ull;
+      __syncthreads();
+      bitonic_sort_desc(keys2, kpad, t);
+      for (int i = t; i < nsel; i += TK_THREADS) keys[i] = keys2[i];      // the epilogue reads `keys`
+      __syncthreads();
+    } else {
     for (int i = (int)n + t; i < npad; i += TK_THREADS) keys[i] = 0ull;
     __syncthreads();
     if (npad == TK_MAX) bitonic_sort_desc_4096(keys, keys2, t);
     else bitonic_sort_desc(keys, npad, t);
     nsel = (int)n < k ? (int)n : k;
+    }
   } else if (n <= (uint32_t)TK_MAX) {
     // more segments than slot-table entries (very large images): a wave walks whole segments
     for (int s = wave; s < segments; s += TK_WAVES) {
@@ -311,6 +391,6 @@ extern "C" int mi_topk_keypoints(const uint64_t *cand, const uint32_t *count, in
   if (k <= 0 || k > TK_MAX) return MI_E_PARAM;
   if (segment_capacity <= 0) return MI_E_CAPACITY;
   hipLaunchKernelGGL(topk_kernel, dim3(n), dim3(TK_THREADS), 0, (hipStream_t)stream, cand, count, segments,
-                     (uint32_t)segment_capacity, w, k, keypoints, kscores);
+                     (uint32_t)segment_capacity, w, k, keypoints, kscores, mi_g_topk_select);
   return mi_launch_status();
 }
