@@ -58,17 +58,50 @@ __global__ __launch_bounds__(256) void cost_bits_kernel(const uint32_t *__restri
   const uint32_t *a_g = bits1 + (size_t)b * n * words;
   const uint32_t *b_g = bits2 + (size_t)b * m * words;
 
-  for (int i = t; i < CB_T * words; i += 256) {
-    const int r = i / words, c = i - r * words;
-    sa[r * wp + c] = (i0 + r < n) ? a_g[(size_t)(i0 + r) * words + c] : 0u;
-    sb[r * wp + c] = (j0 + r < m) ? b_g[(size_t)(j0 + r) * words + c] : 0u;
+  if ((words & 3) == 0 && words <= 32 && (((uintptr_t)bits1 | (uintptr_t)bits2) & 15) == 0) {
+    // a tile's 128 descriptors are one contiguous block of global memory: 16-byte chunks, all of a thread's
+    // loads issued before the first LDS store (one round trip; no per-word division)
+    const int cpr = words >> 2;                      // chunks per descriptor
+    const int chunks = CB_T * cpr;
+    uint4 va[4], vb[4];                              // words <= 32: at most 4 chunks per thread and tile
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = t + 256 * q;
+      const int r = ch / cpr;
+      va[q] = make_uint4(0u, 0u, 0u, 0u);
+      vb[q] = va[q];
+      if (ch < chunks && i0 + r < n) va[q] = reinterpret_cast<const uint4 *>(a_g + (size_t)i0 * words)[ch];
+      if (ch < chunks && j0 + r < m) vb[q] = reinterpret_cast<const uint4 *>(b_g + (size_t)j0 * words)[ch];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ch = t + 256 * q;
+      if (ch < chunks) {
+        const int r = ch / cpr, c = (ch - r * cpr) * 4;
+        uint32_t *da = sa + r * wp + c, *db = sb + r * wp + c;
+        da[0] = va[q].x; da[1] = va[q].y; da[2] = va[q].z; da[3] = va[q].w;
+        db[0] = vb[q].x; db[1] = vb[q].y; db[2] = vb[q].z; db[3] = vb[q].w;
+      }
+    }
+  } else {
+    for (int i = t; i < CB_T * words; i += 256) {
+      const int r = i / words, c = i - r * words;
+      sa[r * wp + c] = (i0 + r < n) ? a_g[(size_t)(i0 + r) * words + c] : 0u;
+      sb[r * wp + c] = (j0 + r < m) ? b_g[(size_t)(j0 + r) * words + c] : 0u;
+    }
   }
   __syncthreads();
   {
     const int r = t & 127;
     const uint32_t *src = (t < 128 ? sa : sb) + r * wp;
     int pop = 0;
-    for (int c = 0; c < words; ++c) pop += __popc(src[c]);
+    for (int c0 = 0; c0 < words; c0 += 8) {          // eight LDS reads in flight, not one round trip per word
+      uint32_t wv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) wv[q] = (c0 + q < words) ? src[c0 + q] : 0u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) pop += __popc(wv[q]);
+    }
     float inv = 1.0f, nrm = (float)pop;
     if (normalized) {
       // F.normalize: bit / max(sqrt(pop), 1e-12); squared norm re-formed in fp32 like sinkhorn.py:98
@@ -90,6 +123,7 @@ __global__ __launch_bounds__(256) void cost_bits_kernel(const uint32_t *__restri
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0;
 
+#pragma unroll 4
   for (int ks = 0; ks < words; ++ks) {
     v4i fa[2], fb[2];
 #pragma unroll
