@@ -285,7 +285,15 @@ __global__ __launch_bounds__(256) void mnn_colmerge_kernel(const uint64_t *__res
   const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
   if (j >= m) return;
   uint64_t k = 0ull;
-  for (int band = 0; band < nb; ++band) {
+  int band = 0;
+  for (; band + 8 <= nb; band += 8) {              // eight loads in flight (one round trip, not eight)
+    uint64_t c[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) c[q] = col_part[((size_t)b * nb + band + q) * m + j];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) k = c[q] > k ? c[q] : k;
+  }
+  for (; band < nb; ++band) {
     const uint64_t c = col_part[((size_t)b * nb + band) * m + j];
     k = c > k ? c : k;
   }

@@ -114,7 +114,9 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
   constexpr int NT = 64 * NW;
   constexpr int NC = 512 * E8;    // columns covered by one wave
   __shared__ float red[NW][NC + 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave index is uniform: readfirstlane lets the compiler keep row numbers, row_info and the live flags in
+  // SGPRs (scalar loads) instead of per-lane copies
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.y, band = blockIdx.x, nb = gridDim.x - 1;
   const float *vb = v + (size_t)b * (m + 1);
   float *pb = part + ((size_t)b * (nb + 1) + band) * (size_t)(m + 1);
@@ -147,6 +149,16 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
     return;
   }
 
+  // column data (aligned, padded arrays) and the wave's rows: every load is issued before any of them is used
+  float4 tl[E8][2], wl[E8][2];
+#pragma unroll
+  for (int e = 0; e < E8; ++e) {
+    const int j = e * 512 + lane * 8;
+    tl[e][0] = *reinterpret_cast<const float4 *>(tp + (size_t)b * cpitch + j);
+    tl[e][1] = *reinterpret_cast<const float4 *>(tp + (size_t)b * cpitch + j + 4);
+    wl[e][0] = *reinterpret_cast<const float4 *>(wp + (size_t)b * cpitch + j);
+    wl[e][1] = *reinterpret_cast<const float4 *>(wp + (size_t)b * cpitch + j + 4);
+  }
   uint4 raw[RW][E8];
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
@@ -154,25 +166,27 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
     const uint16_t *src = dots + ((size_t)b * n + i) * pitch;
 #pragma unroll
     for (int e = 0; e < E8; ++e) {
+      // no branch around the load (a branch ends the run of loads in flight: the rows were fetched two at a
+      // time, one memory round trip per pair); lanes past the matrix read a valid chunk and drop it
       const int j = e * 512 + lane * 8;
-      raw[r][e] = make_uint4(0u, 0u, 0u, 0u);
-      if (j < m) raw[r][e] = *reinterpret_cast<const uint4 *>(src + j);   // pitch >= round_up(m,8)
+      raw[r][e] = *reinterpret_cast<const uint4 *>(src + min(j, pitch - 8));   // pitch >= round_up(m,8)
     }
   }
 
   float tq[E8][8], wq[E8][8];
 #pragma unroll
   for (int e = 0; e < E8; ++e) {
-    const int j = e * 512 + lane * 8;
-    const float4 t0 = *reinterpret_cast<const float4 *>(tp + (size_t)b * cpitch + j);
-    const float4 t1 = *reinterpret_cast<const float4 *>(tp + (size_t)b * cpitch + j + 4);
-    const float4 w0 = *reinterpret_cast<const float4 *>(wp + (size_t)b * cpitch + j);
-    const float4 w1 = *reinterpret_cast<const float4 *>(wp + (size_t)b * cpitch + j + 4);
+    const float4 t0 = tl[e][0], t1 = tl[e][1], w0 = wl[e][0], w1 = wl[e][1];
     tq[e][0] = t0.x; tq[e][1] = t0.y; tq[e][2] = t0.z; tq[e][3] = t0.w;
     tq[e][4] = t1.x; tq[e][5] = t1.y; tq[e][6] = t1.z; tq[e][7] = t1.w;
     wq[e][0] = w0.x; wq[e][1] = w0.y; wq[e][2] = w0.z; wq[e][3] = w0.w;
     wq[e][4] = w1.x; wq[e][5] = w1.y; wq[e][6] = w1.z; wq[e][7] = w1.w;
   }
+#pragma unroll
+  for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int e = 0; e < E8; ++e)
+      if (e * 512 + lane * 8 >= m) raw[r][e] = make_uint4(0u, 0u, 0u, 0u);
   const float xd0 = dust + vd;
 
   // Bounded-shift path: one shift S for every row of the pair, known before the row is read; wq becomes
