@@ -170,9 +170,10 @@ struct ZSourceDots {
   typedef uint4 Raw;
   typedef float2 Row;
   __device__ __forceinline__ Raw load_raw(int b, int n, int i, int j, int m) const {
-    uint4 r = make_uint4(0u, 0u, 0u, 0u);
-    if (j < m) r = *reinterpret_cast<const uint4 *>(dots + ((size_t)b * n + i) * pitch + j);   // pitch % 8 == 0
-    return r;
+    // no branch around the load (it would end the run of loads in flight); lanes past the matrix read a valid
+    // chunk of the row and drop it
+    const uint4 got = *reinterpret_cast<const uint4 *>(dots + ((size_t)b * n + i) * pitch + min(j, pitch - 8));   // pitch % 8 == 0
+    return j < m ? got : make_uint4(0u, 0u, 0u, 0u);
   }
   __device__ __forceinline__ void decode(const Raw &r, float (&out)[8]) const {
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
@@ -196,18 +197,44 @@ __global__ __launch_bounds__(64 * NW) void mnn_band_kernel(SRC src, int n, int m
   constexpr int BAND = NW * RW;
   constexpr int NC = 512 * E8;
   __shared__ uint64_t red[NW][NC];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: rows in SGPRs
   const int b = blockIdx.y, band = blockIdx.x, nb = gridDim.x;
   const int row0 = band * BAND + wave * RW;
 
+  // all rows of the wave are requested before anything else (a load issued where it is used costs the wave one
+  // memory round trip per row), ahead of the column data's trip through LDS
+  typename SRC::Raw raw[RW][E8];
+  typename SRC::Row rowd[RW];
+  float uis[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int ic = min(row0 + r, n - 1);
+    uis[r] = u[(size_t)b * (n + 1) + ic];
+    rowd[r] = src.load_row(b, n, ic);
+#pragma unroll
+    for (int e = 0; e < E8; ++e) raw[r][e] = src.load_raw(b, n, ic, e * 512 + lane * 8, m);
+  }
   // per-column data: the workgroup fetches v and col_info once with coalesced loads and every lane picks its
   // eight consecutive columns out of LDS (sixteen strided 4- and 8-byte loads per lane otherwise: the address
   // unit, not the data, was what this prologue cost)
   __shared__ float s_v[NC];
   __shared__ float2 s_ci[NC];
-  for (int c = threadIdx.x; c < NC; c += 64 * NW) {
-    s_v[c] = c < m ? v[(size_t)b * (m + 1) + c] : 0.0f;
-    s_ci[c] = (col_info && c < m) ? col_info[(size_t)b * m + c] : make_float2(0.f, 0.f);
+  {
+    constexpr int PER = NC / (64 * NW);            // columns per thread (1 or 2): both loads issued, then both stores
+    float tv[PER];
+    float2 tc[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int c = threadIdx.x + q * 64 * NW;
+      tv[q] = c < m ? v[(size_t)b * (m + 1) + c] : 0.0f;
+      tc[q] = (col_info && c < m) ? col_info[(size_t)b * m + c] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int c = threadIdx.x + q * 64 * NW;
+      s_v[c] = tv[q];
+      s_ci[c] = tc[q];
+    }
   }
   __syncthreads();
   float vv[E8][8];
@@ -227,19 +254,6 @@ __global__ __launch_bounds__(64 * NW) void mnn_band_kernel(SRC src, int n, int m
 #pragma unroll
     for (int q = 0; q < 8; ++q) { cbest[e][q] = -1.0f; cidx[e][q] = 0; }
 
-  // all rows of the wave are requested before the first is evaluated (a load issued where it is used costs the
-  // wave one memory round trip per row)
-  typename SRC::Raw raw[RW][E8];
-  typename SRC::Row rowd[RW];
-  float uis[RW];
-#pragma unroll
-  for (int r = 0; r < RW; ++r) {
-    const int ic = min(row0 + r, n - 1);
-    uis[r] = u[(size_t)b * (n + 1) + ic];
-    rowd[r] = src.load_row(b, n, ic);
-#pragma unroll
-    for (int e = 0; e < E8; ++e) raw[r][e] = src.load_raw(b, n, ic, e * 512 + lane * 8, m);
-  }
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
     const int i = row0 + r;
