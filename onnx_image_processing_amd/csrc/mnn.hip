@@ -171,9 +171,9 @@ struct ZSourceDots {
   typedef float2 Row;
   __device__ __forceinline__ Raw load_raw(int b, int n, int i, int j, int m) const {
     // no branch around the load (it would end the run of loads in flight); lanes past the matrix read a valid
-    // chunk of the row and drop it
-    const uint4 got = *reinterpret_cast<const uint4 *>(dots + ((size_t)b * n + i) * pitch + min(j, pitch - 8));   // pitch % 8 == 0
-    return j < m ? got : make_uint4(0u, 0u, 0u, 0u);
+    // chunk of the row
+    // (their values are never used: the kernel replaces p by -1 for j >= m)
+    return *reinterpret_cast<const uint4 *>(dots + ((size_t)b * n + i) * pitch + min(j, pitch - 8));   // pitch % 8 == 0
   }
   __device__ __forceinline__ void decode(const Raw &r, float (&out)[8]) const {
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};

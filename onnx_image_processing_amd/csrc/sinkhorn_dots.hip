@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
 #pragma unroll
     for (int e = 0; e < E8; ++e) {
       // no branch around the load (a branch ends the run of loads in flight: the rows were fetched two at a
-      // time, one memory round trip per pair); lanes past the matrix read a valid chunk and drop it
+      // time, one memory round trip per pair); lanes past the matrix read a valid chunk of the row
       const int j = e * 512 + lane * 8;
       raw[r][e] = *reinterpret_cast<const uint4 *>(src + min(j, pitch - 8));   // pitch >= round_up(m,8)
     }
@@ -182,11 +182,8 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
     wq[e][0] = w0.x; wq[e][1] = w0.y; wq[e][2] = w0.z; wq[e][3] = w0.w;
     wq[e][4] = w1.x; wq[e][5] = w1.y; wq[e][6] = w1.z; wq[e][7] = w1.w;
   }
-#pragma unroll
-  for (int r = 0; r < RW; ++r)
-#pragma unroll
-    for (int e = 0; e < E8; ++e)
-      if (e * 512 + lane * 8 >= m) raw[r][e] = make_uint4(0u, 0u, 0u, 0u);
+  // (lanes past the matrix hold some other chunk of the row: harmless, their tq is 0 and their wq -inf, so every
+  // x of theirs is -inf and every e 0 whatever the finite dot value)
   const float xd0 = dust + vd;
 
   // Bounded-shift path: one shift S for every row of the pair, known before the row is read; wq becomes
@@ -194,9 +191,10 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
   float nm_pair = 0.0f;          // -S * log2(e)
   if constexpr (FAST) {
     const float *ab = aux + (size_t)b * SKD_AUX;
-    float wmax = ab[0];
+    float wmax = ab[0];                          // one slot per 64 columns: (m + 63) / 64 of them matter
 #pragma unroll
-    for (int k = 1; k < SKD_AUX; ++k) wmax = fmaxf(wmax, ab[k]);
+    for (int k = 1; k < SKD_AUX; ++k)
+      if (k * 64 < m) wmax = fmaxf(wmax, ab[k]);   // wave-uniform (scalar branch)
     const float S = fmaxf(wmax + zp.g_bound, xd0 + zp.d_bound);
     nm_pair = -(S * SKD_L2E);
 #pragma unroll
