@@ -200,3 +200,23 @@ def test_argument_validation_of_the_widened_entries(lib_path):
     lib.mi_sparse_bad_oriented.argtypes = [vp, ci, ci, ci, vp, ci, vp, vp, vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, vp]
     assert lib.mi_sparse_bad_oriented(p, 1, 64, 64, p, 4, p, p, p, p, 256, 2, 10.0, 1, 0, p, None, None, None) == -1   # two angle sources
     assert lib.mi_sparse_bad_oriented(p, 1, 64, 64, p, 4, p, None, p, p, 100, 2, 10.0, 1, 0, p, None, None, None) == -3  # pairs % 64
+
+
+def test_match_pairs_host_side_checks(lib_path):
+    """mi_match_pairs_workspace_bytes and the argument checks of mi_match_pairs run on the host (no GPU touched)."""
+    from onnx_image_processing_amd import _native as N
+    lib = N.load()
+    fake = ctypes.create_string_buffer(64)
+    ptr = ctypes.cast(fake, ctypes.c_void_p).value
+    prm = N.MatchParams(3, 5, 512, 0.0, 7, 512, ptr, ptr, None, 1, 0.05, 1.0, 20, 100, 0.1)
+    per_pair = lib.mi_match_pairs_workspace_bytes(1, 480, 640, ctypes.byref(prm))
+    assert 4_000_000 < per_pair < 6_000_000                      # score map 1.2 MB + candidates 2.4 MB + dots 0.5 MB + ...
+    assert lib.mi_match_pairs_workspace_bytes(8, 480, 640, ctypes.byref(prm)) >= 8 * (per_pair - 4096)
+    for field, bad in (("max_keypoints", 2000), ("num_pairs", 100), ("block_size", 4), ("sinkhorn_iterations", 0),
+                       ("epsilon", 0.0), ("max_matches", 0)):
+        good = getattr(prm, field)
+        setattr(prm, field, bad)
+        assert lib.mi_match_pairs_workspace_bytes(1, 480, 640, ctypes.byref(prm)) == 0, field
+        setattr(prm, field, good)
+    assert lib.mi_match_pairs(None, None, 1, 480, 640, ctypes.byref(prm), None, None, None, None, None, None, None, None,
+                              0, None) == -1                     # MI_E_NULL before anything else
