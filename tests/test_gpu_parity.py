@@ -131,6 +131,26 @@ def test_topk_plateaus_vs_oracle(mods):
         assert np.array_equal(kp.cpu().numpy(), kp_ref) and np.array_equal(sc.cpu().numpy(), sc_ref)
 
 
+def test_topk_select_path_equals_full_sort(mods):
+    """k << candidates: the radix-select + sort-k path and the full bitonic sort return the same keypoints and
+    scores (640x480: ~3300 candidates per image, k = 512 and k = 100; a plateau map with massive ties too)."""
+    from onnx_image_processing_amd import _native as N, ops
+    a, _ = synth_batch(3100, 3, 480, 640)
+    sc = ops.corner_response(gpu(a), 3).squeeze(1)
+    g = load_golden("nms_topk")
+    plateau = gpu(np.tile(g["plateau_scores"], (1, 4, 4))[:, :150, :200].copy())
+    try:
+        for scores, r, ks in ((sc, 5, (512, 100, 7)), (plateau, 1, (512, 64))):
+            for k in ks:
+                N.load().mi_debug_set(9, 0)
+                kp0, s0 = ops.nms_topk(scores, r, k, 0.0, 0)
+                N.load().mi_debug_set(9, 1)
+                kp1, s1 = ops.nms_topk(scores, r, k, 0.0, 0)
+                assert torch.equal(kp0, kp1) and torch.equal(s0, s1), (r, k)
+    finally:
+        N.load().mi_debug_set(9, 1)
+
+
 def test_topk_errors_and_empty(mods):
     s = torch.zeros(1, 16, 16, device=DEV)
     kp, sc = mods["detect_keypoints"](s, 2, 10, 0.0, 0)
