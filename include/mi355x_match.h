@@ -9,8 +9,16 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer (hipMalloc'd / torch.Tensor.data_ptr() on ROCm);
- *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
- *     enqueued asynchronously on it, nothing synchronises, nothing allocates;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued
+ *     asynchronously and is ordered as if it ran on `stream` (after earlier work on it, before later
+ *     work), nothing synchronises, nothing allocates device memory.  mi_sinkhorn_dots (and
+ *     mi_match_pairs through it) overlaps the halves of a batch of >= 64 pairs on helper streams
+ *     joined back into `stream` by events; those helpers belong to the calling (device, stream) and
+ *     are created on its first such call (mi_release_stream_resources frees them);
+ *   - threads and devices: the device of `stream` must be the calling thread's current device.  Calls
+ *     on DIFFERENT streams may run concurrently from different host threads; calls on the SAME
+ *     stream must be serialised by the caller (as for any HIP stream).  The library holds no other
+ *     mutable state (include/mi355x_match_debug.h's test hook aside);
  *   - tensors are dense row-major float32 unless stated; images are (n, 1, h, w);
  *   - return value: 0 = launched; > 0 = hipError_t of the failed launch; < 0 = MI_E_*
  *     argument error detected on the host before any launch.
@@ -40,18 +48,15 @@ enum {
 enum { MI_BAD_RAW = 0, MI_BAD_SOFT = 1, MI_BAD_HARD = 2 };
 /* distance types (reference matching/sinkhorn.py:95-108) */
 enum { MI_DIST_L2 = 0, MI_DIST_L1 = 1 };
+/* smallest epsilon of the packed (uint16 dot product) Sinkhorn form, see mi_sinkhorn_dots */
+#define MI_DOTS_MIN_EPSILON 0.005
 
 int mi_abi_version(void);
 const char *mi_error_string(int code);
-/* Development/test hook: choose between equivalent kernel implementations (results are
- * identical).  key 1: corner response, 0 = streaming LDS-DMA kernel (default), 1 = register-
- * staged tile kernel.  key 2: rows per thread of the streaming corner kernel (4, 5 or 8).
- * key 6: number of batch parts mi_sinkhorn_dots runs on separate streams (1..4, default 2).
- * key 9: top-k, 1 = radix-select the k-th key and sort only the k winners when k << candidates
- * (default), 0 = always sort every candidate.
- * key 4: Sinkhorn band kernel, 0 = probability form, lean instruction stream (default), 2 = first
- * probability-form kernel, 1 = log-domain (max,sum) partials (results agree to fp32 rounding). */
-int mi_debug_set(int key, int value);
+/* Frees the helper streams / events held for (current device, stream), see the conventions above.  Call it
+ * before destroying a stream that was passed to mi_sinkhorn_dots / mi_match_pairs with >= 64 pairs; the
+ * stream's helper work must have completed (synchronise the stream first). */
+int mi_release_stream_resources(mi_stream_t stream);
 
 /* ---- detector/shi_tomasi.py:66-112  ShiTomasiScore.forward ---------------------------------
  * score[n,1,h,w] = max(0, (a+c)/2 - sqrt(((a-c)/2)^2 + b^2 + 1e-10)) of the Sobel structure
@@ -188,6 +193,11 @@ int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, float dustbi
  *     z = -max(|a|^2 + |b|^2 - 2 * dot * s_a * s_b, 0) * (1/epsilon)
  * in registers on every pass: 2 bytes per matrix element per iteration instead of 4.
  * m <= 1024 (mi_sinkhorn_dots_workspace_bytes returns 0 otherwise: use the fp32 form).
+ * epsilon >= MI_DOTS_MIN_EPSILON: the factored z drops the reference's clamp(cost, min=0) (sinkhorn.py:103),
+ * which only acts on the rounding noise of identical normalised descriptors (cost = -O(3e-7)); that noise
+ * enters z as +O(3e-7/epsilon), inside the 1e-4 parity bound down to epsilon = 0.005 and not below --
+ * smaller epsilon is refused with MI_E_PARAM (mi_match_pairs_workspace_bytes returns 0): use the fp32-Z
+ * form, which clamps.
  * sqnorm_bound: an upper bound of every squared norm in row_info / col_info (1 for `normalized`
  * descriptors, num_bits otherwise), or 0 if unknown.  With a bound small enough that
  * 2 * sqnorm_bound / epsilon < ~62 the row pass shifts every row of a pair by one analytic bound

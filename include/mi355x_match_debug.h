@@ -1,0 +1,27 @@
+/*
+ * mi355x_match_debug.h -- development / test hooks of libmi355x_match.so.  NOT part of the product ABI
+ * (include/mi355x_match.h): nothing here changes results, only which of two equivalent kernel
+ * implementations runs, and the setting is process-wide (atomics), so a product binding must not call it.
+ * tests/ use it to compare the alternatives bit for bit; tools/kbench.py to time them.
+ */
+#ifndef MI355X_MATCH_DEBUG_H
+#define MI355X_MATCH_DEBUG_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Choose between equivalent kernel implementations (results are
+ * identical).  key 1: corner response, 0 = streaming LDS-DMA kernel (default), 1 = register-
+ * staged tile kernel.  key 2: rows per thread of the streaming corner kernel (4, 5 or 8).
+ * key 6: number of batch parts mi_sinkhorn_dots runs on separate streams (1..4, default 2).
+ * key 9: top-k, 1 = radix-select the k-th key and sort only the k winners when k << candidates
+ * (default), 0 = always sort every candidate.
+ * key 4: Sinkhorn band kernel, 0 = probability form, lean instruction stream (default), 2 = first
+ * probability-form kernel, 1 = log-domain (max,sum) partials (results agree to fp32 rounding). */
+int mi_debug_set(int key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355X_MATCH_DEBUG_H */

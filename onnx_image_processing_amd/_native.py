@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("MI355X_MATCH_LIB") or os.path.join(_PKG, "lib", "libm
 SIGNATURES = {
     "mi_abi_version": [],
     "mi_error_string": [c_int],
-    "mi_debug_set": [c_int, c_int],
+    "mi_release_stream_resources": [c_void_p],
     "mi_corner_response": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mi_nms_mask": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mi_candidate_layout": [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
@@ -84,6 +84,8 @@ class MatchParams(ctypes.Structure):
 SIGNATURES["mi_match_pairs_workspace_bytes"] = [c_int, c_int, c_int, ctypes.POINTER(MatchParams)]
 SIGNATURES["mi_match_pairs"] = [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(MatchParams), c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+# include/mi355x_match_debug.h: test / tooling hooks, not part of the product ABI (nothing in this package calls them)
+DEBUG_SIGNATURES = {"mi_debug_set": [c_int, c_int]}
 _RESTYPE = {"mi_match_pairs_workspace_bytes": c_size_t, "mi_error_string": c_char_p, "mi_sinkhorn_workspace_bytes": c_size_t, "mi_bad_plan_bytes": c_size_t,
             "mi_sinkhorn_dots_workspace_bytes": c_size_t, "mi_mnn_duals_workspace_bytes": c_size_t}
 
@@ -103,15 +105,10 @@ def load() -> ctypes.CDLL:
                 "`python -m onnx_image_processing_amd.build` (there is no CPU fallback)."
             )
         lib = ctypes.CDLL(LIB_PATH)
-        for name, argtypes in SIGNATURES.items():
+        for name, argtypes in {**SIGNATURES, **DEBUG_SIGNATURES}.items():
             fn = getattr(lib, name)            # AttributeError if the ABI and the binding diverge
             fn.argtypes = argtypes
             fn.restype = _RESTYPE.get(name, c_int)
-        # development hook: MI_DEBUG_SET="key=value,key=value" selects between equivalent kernel implementations
-        for item in filter(None, os.environ.get("MI_DEBUG_SET", "").split(",")):
-            key, value = item.split("=")
-            if lib.mi_debug_set(int(key), int(value)) != 0:
-                raise RuntimeError(f"MI_DEBUG_SET: mi_debug_set({key}, {value}) was refused")
         _lib = lib
     return _lib
 

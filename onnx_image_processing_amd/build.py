@@ -8,6 +8,7 @@ a source or header is newer.
 """
 from __future__ import annotations
 
+import glob
 import os
 import subprocess
 import sys
@@ -46,7 +47,7 @@ def _newer(target: str, deps: list[str]) -> bool:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "mi355x_match.h"), os.path.abspath(__file__)]
+    headers = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))) + [os.path.abspath(__file__)]
     hipcc = _hipcc()
     jobs = []
     objs = []

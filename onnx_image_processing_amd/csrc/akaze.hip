@@ -213,6 +213,7 @@ int grid_for(int n, int h, int w, int &tiles_x, int &tiles_y) {
 
 extern "C" int mi_akaze_diffuse(const float *l_in, int n, int h, int w, float kappa, float dt, float *l_out,
                                 mi_stream_t stream) {
+  MI_ENTER();
   if (!l_in || !l_out || l_in == l_out) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
   if (!(kappa > 0.0f)) return MI_E_PARAM;
@@ -226,6 +227,7 @@ extern "C" int mi_akaze_diffuse(const float *l_in, int n, int h, int w, float ka
 
 extern "C" int mi_akaze_hessian_scores(const float *l, int n, int h, int w, float threshold, int nms_size,
                                        float *scores, mi_stream_t stream) {
+  MI_ENTER();
   if (!l || !scores) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
   if (nms_size <= 0 || (nms_size & 1) == 0 || nms_size > 15) return MI_E_PARAM;
@@ -242,6 +244,7 @@ extern "C" int mi_akaze_hessian_scores(const float *l, int n, int h, int w, floa
 
 extern "C" int mi_akaze_combine(const float *scale_scores, const float *scale_orientations, int num_scales, int n,
                                 int h, int w, float *scores, float *orientations, mi_stream_t stream) {
+  MI_ENTER();
   if (!scale_scores || !scores) return MI_E_NULL;
   if (orientations && !scale_orientations) return MI_E_NULL;
   if (num_scales <= 0 || n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
@@ -256,6 +259,7 @@ extern "C" int mi_akaze_combine(const float *scale_scores, const float *scale_or
 extern "C" int mi_akaze_orientation_at_keypoints(const float *scale_scores, const float *scale_theta,
                                                  int num_scales, int n, int h, int w, const float *keypoints,
                                                  int k, float *theta, mi_stream_t stream) {
+  MI_ENTER();
   if (!scale_scores || !scale_theta || !keypoints || !theta) return MI_E_NULL;
   if (num_scales <= 0 || n <= 0 || h <= 0 || w <= 0 || k <= 0 || (long long)n * k > 0x7fffffffLL) return MI_E_SHAPE;
   hipLaunchKernelGGL(combine_kp_kernel, dim3(ceil_div(n * k, 256)), dim3(256), 0, (hipStream_t)stream, scale_scores,

@@ -459,6 +459,7 @@ extern "C" size_t mi_bad_plan_bytes(int num_pairs) {
 
 extern "C" int mi_bad_plan_build(const uint32_t *pair_geom, const float *pair_thr, int num_pairs, void *plan,
                                  mi_stream_t stream) {
+  MI_ENTER();
   // Set-up call, once per pair table: it copies the table to the host, builds the plan there (see order_reads)
   // and uploads it, synchronising `stream` twice.  Not capturable into a hipGraph; everything else is.
   if (!pair_geom || !pair_thr || !plan) return MI_E_NULL;
@@ -523,6 +524,7 @@ extern "C" int mi_sparse_bad(const float *image, int n, int h, int w, const floa
                              const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
                              float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
                              uint8_t *status, mi_stream_t stream) {
+  MI_ENTER();
   if (!image || !keypoints || !pair_geom || !pair_thr) return MI_E_NULL;
   if (!desc && !bits) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0 || k <= 0) return MI_E_SHAPE;

@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256) void gather_desc_kernel(const float *__restric
 extern "C" int mi_bad_dense(const float *image, int n, int h, int w, const uint32_t *pair_geom,
                             const float *pair_thr, int num_pairs, int mode, float temperature, float *out,
                             mi_stream_t stream) {
+  MI_ENTER();
   if (!image || !pair_geom || !pair_thr || !out) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
   if (num_pairs <= 0 || num_pairs > 1024) return MI_E_PARAM;
@@ -222,6 +223,7 @@ extern "C" int mi_bad_dense(const float *image, int n, int h, int w, const uint3
 extern "C" int mi_bad_dense_oriented(const float *image, const float *orientation, int n, int h, int w,
                                      const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
                                      float temperature, float *out, mi_stream_t stream) {
+  MI_ENTER();
   if (!image || !orientation || !pair_geom || !pair_thr || !out) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
   if (num_pairs <= 0 || num_pairs > 1024) return MI_E_PARAM;
@@ -240,6 +242,7 @@ extern "C" int mi_bad_dense_oriented(const float *image, const float *orientatio
 extern "C" int mi_gather_descriptors(const float *descriptor_map, int batch, int d, int h, int w,
                                      const float *keypoints, int nk, int bilinear, float *out,
                                      mi_stream_t stream) {
+  MI_ENTER();
   if (!descriptor_map || !keypoints || !out) return MI_E_NULL;
   if (batch <= 0 || d <= 0 || h <= 0 || w <= 0 || nk <= 0 || batch > 65535) return MI_E_SHAPE;
   hipLaunchKernelGGL(gather_desc_kernel, dim3(nk, batch), dim3(256), 0, (hipStream_t)stream, descriptor_map, d, h, w,

@@ -203,6 +203,7 @@ extern "C" int mi_sparse_bad_oriented(const float *image, int n, int h, int w, c
                                       const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
                                       float temperature, int normalize, int bilinear, float *desc,
                                       uint32_t *bits, uint8_t *status, mi_stream_t stream) {
+  MI_ENTER();
   if (!image || !keypoints || !pair_geom || !pair_thr) return MI_E_NULL;
   if (!orientation_map == !keypoint_angles) return MI_E_NULL;          // exactly one angle source
   if (!desc && !bits) return MI_E_NULL;

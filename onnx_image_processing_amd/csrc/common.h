@@ -7,10 +7,19 @@
 
 #define MI_WAVE 64
 
+// Every launching entry point starts with MI_ENTER(): hipGetLastError() also reports (and clears) an error left
+// behind by an unrelated earlier HIP call of this thread, which would otherwise be blamed on this entry point.
+#define MI_ENTER() (void)hipGetLastError()
 static inline int mi_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MI_OK : (int)e;
 }
+// inside multi-launch sequences: stop at the first launch that failed
+#define MI_CHECK_LAUNCH()                          \
+  do {                                             \
+    const int _mi_e = mi_launch_status();          \
+    if (_mi_e != MI_OK) return _mi_e;              \
+  } while (0)
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
@@ -117,8 +126,10 @@ __device__ __forceinline__ float mi_prob_exp(float t) { return __builtin_amdgcn_
 
 // log-score of the packed-descriptor (uint16 dot product) form, shared by K6 and K7 so that both
 // rebuild the same bits: z = nie*(na + nb) + dot*sb*(-2*nie*sa), nie = -1/epsilon, (scale, squared
-// norm) pairs per descriptor (reference matching/sinkhorn.py:101-103,178; the cost's clamp at 0 only
-// acts on rounding noise of identical descriptors and is dropped, see sinkhorn_dots.hip).
+// norm) pairs per descriptor (reference matching/sinkhorn.py:101-103,178).  The cost's clamp at 0 only acts on
+// the rounding noise of identical descriptors and is dropped: that noise (<= ~3e-7 for unit descriptors, exactly
+// 0 for unnormalised bit vectors) enters z divided by epsilon, which is why the entry points of this form refuse
+// epsilon < MI_DOTS_MIN_EPSILON (the fp32-Z form clamps).
 __device__ __forceinline__ float mi_z_from_dot(float dot, float2 row, float2 col, float neg_inv_eps) {
   return __builtin_fmaf(dot * col.x, -2.0f * neg_inv_eps * row.x, col.y * neg_inv_eps) + row.y * neg_inv_eps;
 }

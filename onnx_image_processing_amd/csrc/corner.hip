@@ -13,9 +13,13 @@
 
 #pragma clang fp contract(off)
 
-extern int mi_g_sinkhorn_log_partials;
-extern int mi_g_sinkhorn_split;      // defined in sinkhorn_dots.hip
-extern int mi_g_topk_select;         // defined in topk.hip
+#include <atomic>
+
+#include "../../include/mi355x_match_debug.h"
+
+extern std::atomic<int> mi_g_sinkhorn_log_partials;   // defined in sinkhorn.hip
+extern std::atomic<int> mi_g_sinkhorn_split;          // defined in sinkhorn_dots.hip
+extern std::atomic<int> mi_g_topk_select;             // defined in topk.hip
 
 namespace {
 
@@ -432,12 +436,13 @@ int launch_stream(const float *image, int n, int h, int w, float *score, hipStre
   return mi_launch_status();
 }
 
-int g_corner_impl = 0;   // 0 = streaming (LDS-DMA) kernel, 1 = register-staged tile kernel
-int g_corner_rows = 4;   // rows per thread of the streaming kernel (tile height = 8 * rows)
+std::atomic<int> g_corner_impl{0};   // 0 = streaming (LDS-DMA) kernel, 1 = register-staged tile kernel
+std::atomic<int> g_corner_rows{4};   // rows per thread of the streaming kernel (tile height = 8 * rows)
 
 }  // namespace
 
-// Development/test hook: select between equivalent kernel implementations (results identical).
+// Development/test hook (include/mi355x_match_debug.h, not part of the product ABI): select between equivalent
+// kernel implementations (results identical).  Process-wide atomics: a value set here is seen by every later call.
 extern "C" int mi_debug_set(int key, int value) {
   if (key == 1) { g_corner_impl = value; return MI_OK; }
   if (key == 4) { mi_g_sinkhorn_log_partials = value; return MI_OK; }
@@ -449,15 +454,17 @@ extern "C" int mi_debug_set(int key, int value) {
 
 extern "C" int mi_corner_response(const float *image, int n, int h, int w, int block_size, float *score,
                                   mi_stream_t stream) {
+  MI_ENTER();
   if (!image || !score) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
   if (block_size <= 0 || (block_size & 1) == 0) return MI_E_PARAM;
   hipStream_t s = (hipStream_t)stream;
   const bool aligned = (w % 4 == 0) && (((uintptr_t)image | (uintptr_t)score) % 16 == 0);
   if (aligned && h >= 4 && w >= 8) {
-    if (block_size == 3 && g_corner_impl == 0) {
-      if (g_corner_rows == 4) return launch_stream<3, 4>(image, n, h, w, score, s);
-      if (g_corner_rows == 5) return launch_stream<3, 5>(image, n, h, w, score, s);
+    const int rows = g_corner_rows.load(std::memory_order_relaxed);
+    if (block_size == 3 && g_corner_impl.load(std::memory_order_relaxed) == 0) {
+      if (rows == 4) return launch_stream<3, 4>(image, n, h, w, score, s);
+      if (rows == 5) return launch_stream<3, 5>(image, n, h, w, score, s);
       return launch_stream<3, 8>(image, n, h, w, score, s);
     }
     if (block_size == 3) return launch_tile<3, 8>(image, n, h, w, score, s);

@@ -389,6 +389,7 @@ int check_z(const void *a, const void *b, const void *z, int batch, int n, int m
 extern "C" int mi_cost_logscores_bits(const uint32_t *bits1, const uint32_t *bits2, int batch, int n, int m,
                                       int num_bits, int normalized, double epsilon, float *z, int pitch,
                                       mi_stream_t stream) {
+  MI_ENTER();
   int e = check_z(bits1, bits2, z, batch, n, m, pitch, epsilon);
   if (e) return e;
   if (num_bits <= 0 || num_bits % 32 != 0 || num_bits > 4096) return MI_E_PARAM;
@@ -403,6 +404,7 @@ extern "C" int mi_cost_logscores_bits(const uint32_t *bits1, const uint32_t *bit
 extern "C" int mi_cost_dots_bits(const uint32_t *bits1, const uint32_t *bits2, int batch, int n, int m,
                                  int num_bits, int normalized, uint16_t *dots, int pitch, float *row_info,
                                  float *col_info, mi_stream_t stream) {
+  MI_ENTER();
   if (!bits1 || !bits2 || !dots || !row_info || !col_info) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
   if (pitch < m || pitch % 8 != 0 || ((uintptr_t)dots % 16) != 0 || ((uintptr_t)row_info % 8) != 0 ||
@@ -422,6 +424,7 @@ extern "C" int mi_cost_dots_bits(const uint32_t *bits1, const uint32_t *bits2, i
 
 extern "C" int mi_cost_logscores_f32(const float *desc1, const float *desc2, int batch, int n, int m, int d,
                                      int distance, double epsilon, float *z, int pitch, mi_stream_t stream) {
+  MI_ENTER();
   int e = check_z(desc1, desc2, z, batch, n, m, pitch, epsilon);
   if (e) return e;
   if (d <= 0) return MI_E_SHAPE;

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void dog_kernel(const float *__restrict__ imag
 
 extern "C" int mi_fast_score(const float *image, int n, int h, int w, float threshold, float *score,
                              mi_stream_t stream) {
+  MI_ENTER();
   if (!image || !score) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
   const int tiles_x = ceil_div(w, FT_W), tiles_y = ceil_div(h, FT_H);
@@ -151,6 +152,7 @@ extern "C" int mi_fast_score(const float *image, int n, int h, int w, float thre
 
 extern "C" int mi_dog_responses(const float *image, int n, int h, int w, const float *weights_1d, int num_scales,
                                 int kernel_size, float *out, float *score, mi_stream_t stream) {
+  MI_ENTER();
   if (!image || !weights_1d || (!out && !score)) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
   if (num_scales < 2 || num_scales > DG_MAXS || kernel_size <= 0 || (kernel_size & 1) == 0 ||

@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void em_normalise_kernel(const float *__restri
 
 extern "C" int mi_normalise_keypoints(const float *keypoints, long long count, const float *k_inv, float *points,
                                       mi_stream_t stream) {
+  MI_ENTER();
   if (!keypoints || !k_inv || !points) return MI_E_NULL;
   if (count <= 0 || count > 0x7fffffffLL * 256LL) return MI_E_SHAPE;
   hipLaunchKernelGGL(em_normalise_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -296,6 +297,7 @@ extern "C" int mi_normalise_keypoints(const float *keypoints, long long count, c
 extern "C" int mi_essential_matrix(const float *p, int batch, int n, int m, const float *pts1, const float *pts2,
                                    const uint8_t *valid1, const uint8_t *valid2, int top_k, int n_iter,
                                    int n_iter_manifold, float *e, mi_stream_t stream) {
+  MI_ENTER();
   if (!p || !pts1 || !pts2 || !e) return MI_E_NULL;
   if ((valid1 == nullptr) != (valid2 == nullptr)) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0) return MI_E_SHAPE;

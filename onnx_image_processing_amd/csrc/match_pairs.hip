@@ -75,7 +75,7 @@ int check_params(const mi_match_params *p) {
   if (!p || !p->pair_geom || !p->pair_thr) return MI_E_NULL;
   if (p->block_size <= 0 || p->block_size % 2 == 0 || p->nms_radius < 0 || p->max_keypoints <= 0) return MI_E_PARAM;
   if (p->num_pairs <= 0 || p->num_pairs % 64 != 0 || p->num_pairs > 1024) return MI_E_PARAM;
-  if (p->sinkhorn_iterations <= 0 || !(p->epsilon > 0.0) || p->max_matches <= 0) return MI_E_PARAM;
+  if (p->sinkhorn_iterations <= 0 || !(p->epsilon >= MI_DOTS_MIN_EPSILON) || p->max_matches <= 0) return MI_E_PARAM;
   return MI_OK;
 }
 
@@ -92,6 +92,7 @@ extern "C" int mi_match_pairs(const float *image1, const float *image2, int batc
                               const mi_match_params *params, float *keypoints1, float *keypoints2,
                               float *matched1, float *matched2, float *match_scores, uint8_t *match_valid,
                               int32_t *match_ij, void *workspace, size_t workspace_bytes, mi_stream_t stream) {
+  MI_ENTER();
   if (!image1 || !image2 || !keypoints1 || !keypoints2 || !matched1 || !matched2 || !match_scores || !match_valid ||
       !workspace)
     return MI_E_NULL;

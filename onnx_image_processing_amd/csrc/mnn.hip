@@ -367,6 +367,7 @@ extern "C" int mi_mnn_from_duals(const float *z, int batch, int n, int m, int pi
                                  const float *kpts1, const float *kpts2, int max_matches, float threshold,
                                  void *workspace, size_t workspace_bytes, float *mk1, float *mk2, float *scores,
                                  uint8_t *valid, int32_t *match_ij, mi_stream_t stream) {
+  MI_ENTER();
   if (!z) return MI_E_NULL;
   if (pitch < m || pitch % 4 != 0 || ((uintptr_t)z % 16) != 0) return MI_E_ALIGN;
   ZSourceF32 src;
@@ -381,6 +382,7 @@ extern "C" int mi_mnn_from_duals_dots(const uint16_t *dots, const float *row_inf
                                       const float *kpts1, const float *kpts2, int max_matches, float threshold,
                                       void *workspace, size_t workspace_bytes, float *mk1, float *mk2,
                                       float *scores, uint8_t *valid, int32_t *match_ij, mi_stream_t stream) {
+  MI_ENTER();
   if (!dots || !row_info || !col_info) return MI_E_NULL;
   if (pitch < m || pitch % 8 != 0 || ((uintptr_t)dots % 16) != 0) return MI_E_ALIGN;
   if (!(epsilon > 0.0)) return MI_E_PARAM;
@@ -399,6 +401,7 @@ extern "C" int mi_mnn_extract(const float *p, int batch, int n, int m, const flo
                               int max_matches, float threshold, uint64_t *row_best, uint64_t *col_best,
                               float *mk1, float *mk2, float *scores, uint8_t *valid, int32_t *match_ij,
                               mi_stream_t stream) {
+  MI_ENTER();
   if (!p || !kpts1 || !kpts2 || !row_best || !col_best || !mk1 || !mk2 || !scores || !valid) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
   if (n > MX_MAX || max_matches <= 0) return MI_E_PARAM;
@@ -451,6 +454,7 @@ __global__ __launch_bounds__(256) void match_filters_kernel(float *__restrict__ 
 
 extern "C" int mi_match_filters(float *p, int batch, int n, int m, float ratio_threshold, float dustbin_margin,
                                 uint8_t *valid, mi_stream_t stream) {
+  MI_ENTER();
   if (!p || !valid) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
   hipLaunchKernelGGL(match_filters_kernel, dim3(ceil_div(n, 4), batch), dim3(256), 0, (hipStream_t)stream, p, n, m,
@@ -484,6 +488,7 @@ __global__ __launch_bounds__(256) void core_colmax_kernel(const float *__restric
 
 extern "C" int mi_core_maxima(const float *p, int batch, int n, int m, float *row_max, float *col_max,
                               mi_stream_t stream) {
+  MI_ENTER();
   if (!p || !row_max || !col_max) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
   hipLaunchKernelGGL(core_rowmax_kernel, dim3(ceil_div(n, 4), batch), dim3(256), 0, (hipStream_t)stream, p, n, m, row_max);

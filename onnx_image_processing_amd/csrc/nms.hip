@@ -434,6 +434,7 @@ extern "C" int mi_candidate_layout(int h, int w, int *segments, int *segment_cap
 
 extern "C" int mi_nms_mask(const float *score, int n, int h, int w, int radius, float *mask,
                            mi_stream_t stream) {
+  MI_ENTER();
   int e = check_common(score, mask, n, h, w);
   if (e) return e;
   if (radius < 0 || radius > 24) return MI_E_PARAM;
@@ -449,6 +450,7 @@ extern "C" int mi_nms_mask(const float *score, int n, int h, int w, int radius, 
 
 extern "C" int mi_nms_candidates(const float *score, int n, int h, int w, int radius, float score_threshold,
                                  int border_margin, uint64_t *cand, uint32_t *count, mi_stream_t stream) {
+  MI_ENTER();
   int e = check_common(score, cand, n, h, w);
   if (e) return e;
   if (!count) return MI_E_NULL;
@@ -468,6 +470,7 @@ extern "C" int mi_nms_candidates(const float *score, int n, int h, int w, int ra
 extern "C" int mi_select_candidates(const float *score, const float *mask, int n, int h, int w,
                                     float score_threshold, int border_margin, uint64_t *cand,
                                     uint32_t *count, mi_stream_t stream) {
+  MI_ENTER();
   int e = check_common(score, mask, n, h, w);
   if (e) return e;
   if (!cand || !count) return MI_E_NULL;

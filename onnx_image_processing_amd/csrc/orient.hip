@@ -103,6 +103,7 @@ __global__ __launch_bounds__(64) void angle_kp_kernel(const float *__restrict__ 
 
 extern "C" int mi_angle_map(const float *image, int n, int h, int w, int patch_size, const float *moment_kernels,
                             float *angle, mi_stream_t stream) {
+  MI_ENTER();
   if (!image || !moment_kernels || !angle) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
   if (patch_size <= 0 || (patch_size & 1) == 0 || patch_size > MAX_PS) return MI_E_PARAM;
@@ -119,6 +120,7 @@ extern "C" int mi_angle_map(const float *image, int n, int h, int w, int patch_s
 extern "C" int mi_angle_at_keypoints(const float *image, int n, int h, int w, const float *keypoints, int k,
                                      int patch_size, const float *moment_kernels, float *theta,
                                      mi_stream_t stream) {
+  MI_ENTER();
   if (!image || !keypoints || !moment_kernels || !theta) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0 || k <= 0 || (long long)n * k > 0x7fffffffLL) return MI_E_SHAPE;
   if (patch_size <= 0 || (patch_size & 1) == 0 || patch_size > MAX_PS) return MI_E_PARAM;

@@ -15,9 +15,11 @@
 
 #include <math.h>
 
-// test hook (mi_debug_set key 4): 0 = probability-form band kernel, lean instruction stream (default);
+#include <atomic>
+
+// test hook (mi_debug_set key 4, include/mi355x_match_debug.h): 0 = probability-form band kernel, lean instruction stream (default);
 // 2 = the first probability-form kernel; 1 = log-domain (max, sum) band partials, two exps per element
-int mi_g_sinkhorn_log_partials = 0;
+std::atomic<int> mi_g_sinkhorn_log_partials{0};
 
 namespace {
 
@@ -735,13 +737,14 @@ void launch_fused(const float *z, int batch, int n, int m, int pitch, float dust
   constexpr int NC = 256 * E4;
   for (int it = 0; it < iterations; ++it) {
     const int vz = it == 0 ? 1 : 0;
-    if (mi_g_sinkhorn_log_partials == 0) {
+    const int band_form = mi_g_sinkhorn_log_partials.load(std::memory_order_relaxed);
+    if (band_form == 0) {
       float *pf = reinterpret_cast<float *>(part);
       hipLaunchKernelGGL((sk_band_p2_kernel<E4, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, z, n, m, pitch,
                          dust, vp, NC + 4, u, pf, log_m, vz);
       hipLaunchKernelGGL(sk_vcombine_p2_kernel, dim3(ceil_div(NC + 1, 256), batch), dim3(256), 0, s, pf, m, nb + 1, v,
                          vp, NC + 4, NC, log_n, vz);
-    } else if (mi_g_sinkhorn_log_partials == 1) {
+    } else if (band_form == 1) {
       hipLaunchKernelGGL((sk_band_kernel<E4, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, z, n, m, pitch, dust,
                          v, u, part, log_m, vz);
       hipLaunchKernelGGL(sk_vcombine_kernel, dim3(ceil_div(m + 1, 256), batch), dim3(256), 0, s, part, m, nb + 1,
@@ -780,6 +783,7 @@ extern "C" size_t mi_sinkhorn_workspace_bytes(int batch, int n, int m) {
 extern "C" int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, float dustbin_logscore,
                            int iterations, float *u, float *v, float *p, void *workspace,
                            size_t workspace_bytes, mi_stream_t stream) {
+  MI_ENTER();
   if (!z || !u || !v) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
   if (pitch < m || pitch % 4 != 0 || ((uintptr_t)z % 16) != 0) return MI_E_ALIGN;

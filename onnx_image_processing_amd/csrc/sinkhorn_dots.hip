@@ -11,11 +11,15 @@
 // row pass leaves P_ij = e_ij / s_i in registers, the column update is v_j += log nu_j -
 // log(sum_i P_ij), the dustbin row is merged in the log domain).
 #include "common.h"
+#include "stream_registry.h"
 
 #include <math.h>
 
-// test hook (mi_debug_set key 6): number of batch parts run on separate streams (1 = one stream)
-int mi_g_sinkhorn_split = 2;           // whole bench step: 1.88 / 1.82 / 1.92 ms with 1 / 2 / 3 parts of 256 pairs
+#include <atomic>
+
+// test hook (mi_debug_set key 6, include/mi355x_match_debug.h): number of batch parts run on separate
+// streams (1 = one stream).  Whole bench step: 1.88 / 1.82 / 1.92 ms with 1 / 2 / 3 parts of 256 pairs.
+std::atomic<int> mi_g_sinkhorn_split{2};
 
 namespace {
 
@@ -367,9 +371,12 @@ __global__ __launch_bounds__(256) void sk_exp_dots_kernel(const uint16_t *__rest
   }
 }
 
-// helper streams for the split schedule below (created once; fork/join by events, so the caller's
-// stream semantics are unchanged: everything is ordered after earlier work on `s` and before later work)
+// Helper streams for the split schedule below.  Fork/join by events, so the caller's stream semantics are
+// unchanged: everything is ordered after earlier work on `s` and before later work on it.  The streams and
+// events belong to ONE caller (device, stream) -- stream_registry.h says why -- and are created on the first
+// call with >= 64 pairs on that stream; at most SK_MAX_CALLERS callers get them, later ones run unforked.
 constexpr int SK_MAX_PARTS = 4;
+constexpr size_t SK_MAX_CALLERS = 64;
 struct ForkJoin {
   hipStream_t side[SK_MAX_PARTS - 1] = {};
   hipEvent_t fork = nullptr, join[SK_MAX_PARTS - 1] = {};
@@ -380,14 +387,34 @@ struct ForkJoin {
       ok = ok && hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) == hipSuccess &&
            hipEventCreateWithFlags(&join[i], hipEventDisableTiming) == hipSuccess;
   }
+  ~ForkJoin() {
+    for (int i = 0; i < SK_MAX_PARTS - 1; ++i) {
+      if (join[i]) (void)hipEventDestroy(join[i]);
+      if (side[i]) (void)hipStreamDestroy(side[i]);
+    }
+    if (fork) (void)hipEventDestroy(fork);
+  }
+  ForkJoin(const ForkJoin &) = delete;
+  ForkJoin &operator=(const ForkJoin &) = delete;
 };
-ForkJoin &fork_join() {
-  static ForkJoin fj;
-  return fj;
+using ForkJoinKey = std::pair<int, hipStream_t>;   // (device, caller stream)
+mi::KeyedRegistry<ForkJoinKey, ForkJoin> &fork_join_registry() {
+  // leaked on purpose: destroying streams from a static destructor races with the HIP runtime's own teardown
+  static auto *reg = new mi::KeyedRegistry<ForkJoinKey, ForkJoin>(SK_MAX_CALLERS);
+  return *reg;
+}
+ForkJoin *fork_join_for(hipStream_t s) {
+  int device = -1;
+  if (hipGetDevice(&device) != hipSuccess) return nullptr;     // launches on `s` need its device current anyway
+  return fork_join_registry().get(ForkJoinKey(device, s), []() {
+    std::unique_ptr<ForkJoin> fj(new ForkJoin());
+    if (!fj->ok) fj.reset();
+    return fj;
+  });
 }
 
 template <int E8, int RW, int NW, bool FAST>
-void launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int batch, int n, int m, int pitch,
+int launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int batch, int n, int m, int pitch,
                  ZParams zp, int iterations, float *u, float *v, float *part, float *wp, float *tp, float *aux,
                  float log_m, float log_n, hipStream_t s) {
   const int nb = ceil_div(n, NW * RW);
@@ -398,20 +425,27 @@ void launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int b
   // the GPU drains and refills (about 5 us per iteration).  With enough pairs the batch is cut into parts
   // on separate streams: while one part is in its column kernel / launch gap another part's row kernel
   // keeps the CUs busy.  The parts are independent problems, so results do not change.
-  ForkJoin &fj = fork_join();
-  int parts = mi_g_sinkhorn_split;
+  MI_CHECK_LAUNCH();
+  int parts = mi_g_sinkhorn_split.load(std::memory_order_relaxed);
   if (parts > SK_MAX_PARTS) parts = SK_MAX_PARTS;
-  if (parts < 1 || !fj.ok || batch < 32 * parts) parts = 1;
+  if (parts < 1 || batch < 32 * parts) parts = 1;
+  ForkJoin *fj = parts > 1 ? fork_join_for(s) : nullptr;
+  if (!fj) parts = 1;
   if (parts > 1) {
-    (void)hipEventRecord(fj.fork, s);
-    for (int q = 1; q < parts; ++q) (void)hipStreamWaitEvent(fj.side[q - 1], fj.fork, 0);
+    // any failure here leaves the side streams unused: run unforked (a side stream that already waits is harmless)
+    bool forked = hipEventRecord(fj->fork, s) == hipSuccess;
+    for (int q = 1; forked && q < parts; ++q) forked = hipStreamWaitEvent(fj->side[q - 1], fj->fork, 0) == hipSuccess;
+    if (!forked) {
+      (void)hipGetLastError();
+      parts = 1;
+    }
   }
   // enqueue iteration by iteration so that no stream runs far ahead of the others
   for (int it = 0; it < iterations; ++it) {
     const int vz = it == 0 ? 1 : 0;
     for (int q = 0; q < parts; ++q) {
       const int b0 = (int)((long long)batch * q / parts), nbatch = (int)((long long)batch * (q + 1) / parts) - b0;
-      hipStream_t st = q ? fj.side[q - 1] : s;
+      hipStream_t st = q ? fj->side[q - 1] : s;
       const uint16_t *d0 = dots + (size_t)b0 * n * pitch;
       const float2 *ri0 = ri + (size_t)b0 * n, *ci0 = ci + (size_t)b0 * m;
       float *u0 = u + (size_t)b0 * (n + 1), *v0 = v + (size_t)b0 * (m + 1);
@@ -423,10 +457,13 @@ void launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int b
                          v0, log_n, vz, ci0, zp.neg_inv_eps, wp0, CP, aux0);
     }
   }
+  // join: without it later work on `s` would not be ordered after the side streams, so a failure is an error
   for (int q = 1; q < parts; ++q) {
-    (void)hipEventRecord(fj.join[q - 1], fj.side[q - 1]);
-    (void)hipStreamWaitEvent(s, fj.join[q - 1], 0);
+    hipError_t e = hipEventRecord(fj->join[q - 1], fj->side[q - 1]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, fj->join[q - 1], 0);
+    if (e != hipSuccess) return (int)e;
   }
+  return mi_launch_status();
 }
 
 int dots_rows_per_band(int m) { return m <= 512 ? 32 : (m <= 1024 ? 16 : 0); }   // 8 rows per wave measured slower
@@ -446,14 +483,24 @@ extern "C" size_t mi_sinkhorn_dots_workspace_bytes(int batch, int n, int m) {
   return dots_partials_bytes(batch, n, m, band) + (2 * (size_t)batch * dots_cpitch(m) + (size_t)batch * SKD_AUX) * sizeof(float);
 }
 
+// see include/mi355x_match.h: a caller that destroys a stream it passed to mi_sinkhorn_dots / mi_match_pairs
+// releases the helper streams and events held for it (they would otherwise live until process exit)
+extern "C" int mi_release_stream_resources(mi_stream_t stream) {
+  int device = -1;
+  if (hipGetDevice(&device) != hipSuccess) return MI_E_PARAM;
+  fork_join_registry().release(ForkJoinKey(device, (hipStream_t)stream));
+  return MI_OK;
+}
+
 extern "C" int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch,
                                 int n, int m, int pitch, double epsilon, double unused_score, double sqnorm_bound,
                                 int iterations, float *u, float *v, float *p, void *workspace, size_t workspace_bytes,
                                 mi_stream_t stream) {
+  MI_ENTER();
   if (!dots || !row_info || !col_info || !u || !v || !workspace) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
   if (pitch < m || pitch % 8 != 0 || ((uintptr_t)dots % 16) != 0 || ((uintptr_t)workspace % 16) != 0) return MI_E_ALIGN;
-  if (iterations <= 0 || !(epsilon > 0.0)) return MI_E_PARAM;
+  if (iterations <= 0 || !(epsilon >= MI_DOTS_MIN_EPSILON)) return MI_E_PARAM;   // below it: the fp32-Z form (clamped cost)
   const size_t need = mi_sinkhorn_dots_workspace_bytes(batch, n, m);
   if (need == 0) return MI_E_PARAM;                 // m > 1024: use the fp32 form
   if (workspace_bytes < need) return MI_E_CAPACITY;
@@ -474,9 +521,11 @@ extern "C" int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, con
   zp.d_bound = (float)(sqnorm_bound / epsilon);
   const bool fast = sqnorm_bound > 0.0 && (double)zp.g_bound * 1.4426950408889634 < (double)SKD_FAST_LIMIT;
 #define SKD_LAUNCH(E8, RW, FAST) launch_dots<E8, RW, 8, FAST>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, wp, tp, aux, log_m, log_n, s)
-  if (m <= 512) { if (fast) SKD_LAUNCH(1, 4, true); else SKD_LAUNCH(1, 4, false); }
-  else { if (fast) SKD_LAUNCH(2, 2, true); else SKD_LAUNCH(2, 2, false); }
+  int e;
+  if (m <= 512) e = fast ? SKD_LAUNCH(1, 4, true) : SKD_LAUNCH(1, 4, false);
+  else e = fast ? SKD_LAUNCH(2, 2, true) : SKD_LAUNCH(2, 2, false);
 #undef SKD_LAUNCH
+  if (e != MI_OK) return e;
   if (p) {
     hipLaunchKernelGGL(sk_exp_dots_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, dots, n, m, pitch, ri, ci,
                        zp, u, v, p);

@@ -12,8 +12,11 @@
 // for the k-th largest key straight from global memory, then sort only the k survivors.
 #include "common.h"
 
-// test hook (key 9): 1 = radix-select the k-th key and sort only the k selected keys whenever n > k
-int mi_g_topk_select = 1;
+#include <atomic>
+
+// test hook (mi_debug_set key 9, include/mi355x_match_debug.h): 1 = radix-select the k-th key and sort only
+// the k selected keys whenever n > k
+std::atomic<int> mi_g_topk_select{1};
 
 namespace {
 
@@ -386,11 +389,12 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
 extern "C" int mi_topk_keypoints(const uint64_t *cand, const uint32_t *count, int segments,
                                  int segment_capacity, int n, int w, int k, float *keypoints, float *kscores,
                                  mi_stream_t stream) {
+  MI_ENTER();
   if (!cand || !count || !keypoints || !kscores) return MI_E_NULL;
   if (n <= 0 || w <= 0 || segments <= 0) return MI_E_SHAPE;
   if (k <= 0 || k > TK_MAX) return MI_E_PARAM;
   if (segment_capacity <= 0) return MI_E_CAPACITY;
   hipLaunchKernelGGL(topk_kernel, dim3(n), dim3(TK_THREADS), 0, (hipStream_t)stream, cand, count, segments,
-                     (uint32_t)segment_capacity, w, k, keypoints, kscores, mi_g_topk_select);
+                     (uint32_t)segment_capacity, w, k, keypoints, kscores, mi_g_topk_select.load(std::memory_order_relaxed));
   return mi_launch_status();
 }

@@ -31,7 +31,9 @@ class GraphedModule:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # capture on the stream the warm-up ran on: per-stream helper resources of the C ABI (the fork/join
+        # streams of mi_sinkhorn_dots for >= 64 pairs) then already exist and nothing is created mid-capture
+        with torch.cuda.graph(self.graph, stream=side):
             self.static_outputs = model(*self.static_inputs)
 
     def __call__(self, *inputs: torch.Tensor):

@@ -252,8 +252,11 @@ def sinkhorn(z: torch.Tensor, m: int, pitch: int, dustbin_logscore: float, itera
     return (p, u, v) if (return_duals or not want_p) else p
 
 
-def dots_supported(b: int, n: int, m: int) -> bool:
-    return int(N.load().mi_sinkhorn_dots_workspace_bytes(b, n, m)) > 0
+DOTS_MIN_EPSILON = 0.005      # MI_DOTS_MIN_EPSILON (include/mi355x_match.h): below it the clamped fp32-Z form runs
+
+
+def dots_supported(b: int, n: int, m: int, epsilon: float = 1.0) -> bool:
+    return epsilon >= DOTS_MIN_EPSILON and int(N.load().mi_sinkhorn_dots_workspace_bytes(b, n, m)) > 0
 
 
 def sinkhorn_bits(bits1: torch.Tensor, bits2: torch.Tensor, normalized: bool, epsilon: float, unused_score: float,
@@ -264,10 +267,11 @@ def sinkhorn_bits(bits1: torch.Tensor, bits2: torch.Tensor, normalized: bool, ep
     b, n, words = bits1.shape
     m = bits2.shape[1]
     dev = bits1.device
-    wbytes = int(N.load().mi_sinkhorn_dots_workspace_bytes(b, n, m))
+    wbytes = int(N.load().mi_sinkhorn_dots_workspace_bytes(b, n, m)) if epsilon >= DOTS_MIN_EPSILON else 0
     if wbytes == 0:
         if return_state or not want_p:
-            raise RuntimeError(f"the dot-product Sinkhorn form supports M <= 1024, got M = {m}")
+            raise RuntimeError(f"the dot-product Sinkhorn form supports M <= 1024 and epsilon >= {DOTS_MIN_EPSILON}, "
+                               f"got M = {m}, epsilon = {epsilon}")
         z, pitch = cost_logscores_bits(bits1, bits2, normalized, epsilon)
         return sinkhorn(z, m, pitch, -unused_score / epsilon, iterations, return_duals=return_duals)
     pitch = (m + 7) // 8 * 8

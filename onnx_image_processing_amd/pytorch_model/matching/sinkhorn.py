@@ -67,7 +67,7 @@ class SinkhornMatcher(nn.Module):
         the dot products become exact integer popcounts (i8 MFMA).  L2 only."""
         if self.distance_type != "l2":
             raise RuntimeError("forward_bits implements the l2 cost only")
-        if self.use_dot_storage and ops.dots_supported(bits1.shape[0], bits1.shape[1], bits2.shape[1]):
+        if self.use_dot_storage and ops.dots_supported(bits1.shape[0], bits1.shape[1], bits2.shape[1], self.epsilon):
             return ops.sinkhorn_bits(bits1, bits2, normalized, self.epsilon, self.unused_score, self.iterations)
         z, pitch = ops.cost_logscores_bits(bits1, bits2, normalized, self.epsilon)
         return ops.sinkhorn(z, bits2.shape[1], pitch, self.dustbin_logscore, self.iterations)
@@ -85,7 +85,7 @@ class SinkhornMatcher(nn.Module):
         if self.distance_type != "l2":
             raise RuntimeError("solve_bits implements the l2 cost only")
         m = bits2.shape[1]
-        if self.use_dot_storage and ops.dots_supported(bits1.shape[0], bits1.shape[1], m):
+        if self.use_dot_storage and ops.dots_supported(bits1.shape[0], bits1.shape[1], m, self.epsilon):
             _, u, v, state = ops.sinkhorn_bits(bits1, bits2, normalized, self.epsilon, self.unused_score,
                                                self.iterations, want_p=False, return_state=True)
             return SinkhornSolution("dots", state, m, state[3], self.epsilon, u, v)
