@@ -217,6 +217,13 @@ int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, const float *c
  * failing rows get core * 0 and dustbin entry 1, as the reference writes them. */
 int mi_match_filters(float *p, int batch, int n, int m, float ratio_threshold, float dustbin_margin,
                      uint8_t *valid, mi_stream_t stream);
+/* ---- matching/outlier_filters.py:11-116  probability_ratio_filter / dustbin_margin_filter ------
+ * The same two tests as masks only (p is not modified): valid[b,i] for i < n.
+ * has_dustbin = 1: p is (batch, n+1, m+1) with the dustbin column (dustbin_margin_filter's argument; both tests
+ * available); 0: p is the (batch, n, m) core (probability_ratio_filter's argument; dustbin_margin must be < 0).
+ * ratio_threshold <= 0 / dustbin_margin < 0 disable a test. */
+int mi_match_filter_masks(const float *p, int batch, int n, int m, int has_dustbin, float ratio_threshold,
+                          float dustbin_margin, uint8_t *valid, mi_stream_t stream);
 
 /* ---- matching/match_extraction.py:72-181  MutualNearestNeighborMatcher.forward --------------
  * p (batch, n+1, m+1); kpts1 (batch,n,2); kpts2 (batch,m,2).  Workspace: row_best (batch*n) u64,

@@ -50,6 +50,7 @@ SIGNATURES = {
     "mi_sinkhorn_dots": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_int,
                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
     "mi_match_filters": [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p],
+    "mi_match_filter_masks": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p],
     "mi_mnn_extract": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mi_mnn_duals_workspace_bytes": [c_int, c_int, c_int],

@@ -419,13 +419,17 @@ extern "C" int mi_mnn_extract(const float *p, int batch, int n, int m, const flo
 // ratio_threshold) and (dustbin_margin < 0 or best - d >= dustbin_margin).  Rows that fail are
 // rewritten in place as the reference does (:441-463): core entries *0, dustbin entry 1.
 namespace {
-__global__ __launch_bounds__(256) void match_filters_kernel(float *__restrict__ p, int n, int m,
-                                                            float ratio_threshold, float dustbin_margin,
-                                                            uint8_t *__restrict__ valid) {
+// p: rows of `row_stride` floats, planes of `plane_stride`; the row's dustbin entry sits at column m when
+// HAS_DUST.  REWRITE: failing rows are rewritten in place (SinkhornMatcherWithFilters); otherwise p is only read
+// (the mask-only form of matching/outlier_filters.py).
+template <bool REWRITE, bool HAS_DUST>
+__global__ __launch_bounds__(256) void match_filters_kernel(float *__restrict__ p, int n, int m, size_t row_stride,
+                                                            size_t plane_stride, float ratio_threshold,
+                                                            float dustbin_margin, uint8_t *__restrict__ valid) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y, i = blockIdx.x * 4 + wave;
   if (i >= n) return;
-  float *pr = p + ((size_t)b * (n + 1) + i) * (size_t)(m + 1);
+  float *pr = p + (size_t)b * plane_stride + (size_t)i * row_stride;
   float a1 = -INFINITY, a2 = -INFINITY;             // lane-local two largest
   for (int j = lane; j < m; j += 64) {
     const float x = pr[j];
@@ -440,12 +444,12 @@ __global__ __launch_bounds__(256) void match_filters_kernel(float *__restrict__ 
   }
   const float best = a1;
   const float second = (m >= 2) ? a2 : 0.0f;        // sinkhorn.py:346-348
-  const float dust = pr[m];
+  const float dust = HAS_DUST ? pr[m] : 0.0f;
   bool ok = true;
   if (ratio_threshold > 0.0f) ok = ok && (best / (second + 1e-8f) >= ratio_threshold);   // :350-351
-  if (dustbin_margin >= 0.0f) ok = ok && ((best - dust) >= dustbin_margin);             // :384-386
+  if (HAS_DUST && dustbin_margin >= 0.0f) ok = ok && ((best - dust) >= dustbin_margin);  // :384-386
   if (lane == 0) valid[(size_t)b * n + i] = ok ? 1 : 0;
-  if (!ok) {
+  if (REWRITE && !ok) {
     for (int j = lane; j < m; j += 64) pr[j] = pr[j] * 0.0f;
     if (lane == 0) pr[m] = 1.0f + 0.0f * dust;
   }
@@ -457,8 +461,25 @@ extern "C" int mi_match_filters(float *p, int batch, int n, int m, float ratio_t
   MI_ENTER();
   if (!p || !valid) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
-  hipLaunchKernelGGL(match_filters_kernel, dim3(ceil_div(n, 4), batch), dim3(256), 0, (hipStream_t)stream, p, n, m,
-                     ratio_threshold, dustbin_margin, valid);
+  hipLaunchKernelGGL((match_filters_kernel<true, true>), dim3(ceil_div(n, 4), batch), dim3(256), 0, (hipStream_t)stream, p,
+                     n, m, (size_t)(m + 1), (size_t)(n + 1) * (size_t)(m + 1), ratio_threshold, dustbin_margin, valid);
+  return mi_launch_status();
+}
+
+extern "C" int mi_match_filter_masks(const float *p, int batch, int n, int m, int has_dustbin, float ratio_threshold,
+                                     float dustbin_margin, uint8_t *valid, mi_stream_t stream) {
+  MI_ENTER();
+  if (!p || !valid) return MI_E_NULL;
+  if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
+  if (!has_dustbin && dustbin_margin >= 0.0f) return MI_E_PARAM;       // a margin test needs the dustbin column
+  float *q = const_cast<float *>(p);                                    // REWRITE = false: only read
+  const dim3 grid(ceil_div(n, 4), batch);
+  if (has_dustbin)
+    hipLaunchKernelGGL((match_filters_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, q, n, m,
+                       (size_t)(m + 1), (size_t)(n + 1) * (size_t)(m + 1), ratio_threshold, dustbin_margin, valid);
+  else
+    hipLaunchKernelGGL((match_filters_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, q, n, m, (size_t)m,
+                       (size_t)n * (size_t)m, ratio_threshold, dustbin_margin, valid);
   return mi_launch_status();
 }
 

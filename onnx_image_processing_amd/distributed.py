@@ -14,7 +14,6 @@ import torch
 import torch.distributed as dist
 
 RECORD_FIELDS = 6  # y1, x1, y2, x2, score, valid
-_use_all_gather = False
 
 
 def env_world() -> tuple[int, int, int]:
@@ -57,23 +56,55 @@ def unpack_records(rec: torch.Tensor):
     return rec[..., 0:2], rec[..., 2:4], rec[..., 4], rec[..., 5] > 0.5
 
 
-def gather_records(rec: torch.Tensor, dst: int = 0) -> torch.Tensor | None:
-    """Gather equally-shaped per-rank record tensors to `dst`, concatenated in rank order
-    (= global pair order under shard_range with equal shard sizes).  Returns None elsewhere."""
+def shard_sizes(total: int, world: int) -> list[int]:
+    """Rows every rank holds under shard_range(total, rank, world)."""
+    return [e - b for b, e in (shard_range(total, r, world) for r in range(world))]
+
+
+def gather_records(rec: torch.Tensor, dst: int = 0, total: int | None = None,
+                   collective: str = "gather") -> torch.Tensor | None:
+    """Gather the per-rank record tensors to `dst`, concatenated in rank order (= global pair order under
+    shard_range).  Returns None on the other ranks.
+
+    total: the global number of pairs when the shards come from shard_range(total, rank, world) and may
+    differ by one row: every rank pads its slab to the largest shard (the collective needs equal shapes; the
+    padding is at most one record row per rank) and `dst` trims each slab back.  None: the caller guarantees
+    equal shapes on every rank.
+    collective: "gather" (each peer sends its slab straight to `dst`: one xGMI link each, no ring) or
+    "all_gather" (every rank receives everything; for backends without gather).  It is a parameter, chosen
+    identically on every rank by the caller -- never switched on a rank-local error, which would leave the
+    ranks issuing different collectives."""
+    if collective not in ("gather", "all_gather"):
+        raise ValueError(f"collective must be 'gather' or 'all_gather', got {collective!r}")
     if not dist.is_initialized() or dist.get_world_size() == 1:
+        if total is not None and rec.shape[0] != total:
+            raise ValueError(f"single process holds {rec.shape[0]} rows but total={total}")
         return rec
     world, rank = dist.get_world_size(), dist.get_rank()
-    global _use_all_gather
-    if not _use_all_gather:
-        try:
-            out = [torch.empty_like(rec) for _ in range(world)] if rank == dst else None
-            dist.gather(rec, out, dst=dst)
-            return torch.cat(out, dim=0) if rank == dst else None
-        except RuntimeError:                      # a backend without gather: every rank takes all slabs instead
-            _use_all_gather = True
-    full = torch.empty((world,) + tuple(rec.shape), dtype=rec.dtype, device=rec.device)
-    dist.all_gather_into_tensor(full, rec)
-    return full.reshape((-1,) + tuple(rec.shape[1:])) if rank == dst else None
+    sizes = None
+    if total is not None:
+        sizes = shard_sizes(total, world)
+        if rec.shape[0] != sizes[rank]:
+            raise ValueError(f"rank {rank} holds {rec.shape[0]} rows, shard_range({total}, {rank}, {world}) says {sizes[rank]}")
+        rows = max(sizes)
+        if rec.shape[0] < rows:
+            pad = torch.zeros((rows - rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
+            rec = torch.cat([rec, pad], dim=0)
+    rec = rec.contiguous()
+    if collective == "gather":
+        out = [torch.empty_like(rec) for _ in range(world)] if rank == dst else None
+        dist.gather(rec, out, dst=dst)
+        if rank != dst:
+            return None
+    else:
+        full = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
+        dist.all_gather_into_tensor(full, rec)               # concatenated along dim 0 (the form gloo and RCCL share)
+        if rank != dst:
+            return None
+        out = list(full.split(rec.shape[0], dim=0)) if rec.shape[0] > 0 else [rec] * world
+    if sizes is not None:
+        out = [slab[:sz] for slab, sz in zip(out, sizes)]
+    return torch.cat(out, dim=0)
 
 
 def barrier_max_ms(elapsed_ms: float, device: torch.device | str) -> float:

@@ -302,6 +302,16 @@ def match_filters(p: torch.Tensor, ratio_threshold: float, dustbin_margin: float
     return p, valid
 
 
+def match_filter_masks(p: torch.Tensor, has_dustbin: bool, ratio_threshold: float, dustbin_margin: float) -> torch.Tensor:
+    """Masks of the two outlier tests, P untouched: P (B,N+1,M+1) with has_dustbin, else the core (B,N,M) -> (B,N) bool."""
+    pp = p.float().contiguous()
+    b, n, m = pp.shape[0], pp.shape[1] - int(has_dustbin), pp.shape[2] - int(has_dustbin)
+    valid = torch.empty((b, n), dtype=torch.bool, device=pp.device)
+    N.call("mi_match_filter_masks", N.dev(pp, F32, "P"), b, n, m, int(has_dustbin), float(ratio_threshold),
+           float(dustbin_margin), valid.data_ptr(), N.stream_ptr())
+    return valid
+
+
 def mnn_extract(p: torch.Tensor, kpts1: torch.Tensor, kpts2: torch.Tensor, max_matches: int, threshold: float,
                 return_indices: bool = False):
     if p.dim() != 3:

@@ -363,6 +363,24 @@ def match_pair(
 # --------------------------------------------------------------------------
 # outlier filters: reference pytorch_model/matching/sinkhorn.py:317-465
 # --------------------------------------------------------------------------
+def probability_ratio_filter(p, ratio_threshold=2.0):
+    """matching/outlier_filters.py:11-64 on the core P (K, K): best / (second + 1e-8) >= ratio_threshold per row,
+    second = second entry of the descending sort (ties count); K < 2 accepts every row (:44-47)."""
+    p = np.asarray(p)
+    k = p.shape[0]
+    if k < 2:
+        return np.ones(k, dtype=bool)
+    srt = np.sort(p, axis=1)[:, ::-1]
+    return srt[:, 0] / (srt[:, 1] + 1e-8) >= ratio_threshold
+
+
+def dustbin_margin_filter(p, margin=0.3):
+    """matching/outlier_filters.py:67-116 on the full P (K+1, K+1): max_j P[i, :K] - P[i, K] >= margin for i < K."""
+    p = np.asarray(p)
+    k = p.shape[0] - 1
+    return p[:k, :k].max(axis=1) - p[:k, k] >= margin
+
+
 def match_filters(p, ratio_threshold=None, dustbin_margin=None):
     """SinkhornMatcherWithFilters' filter stage on P (B,N+1,M+1) -> (P_filtered, valid (B,N) bool).
     :337-351 top-2 ratio (with multiplicity; second = 0 when M == 1), :370-387 best - dustbin,

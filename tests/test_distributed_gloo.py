@@ -37,10 +37,10 @@ def _records_for(seeds):
         mk1, mk2, sc, valid, _ = O.mnn_extract(p, k1, k2, 16, 0.1)
         recs.append(D.pack_records(torch.from_numpy(mk1), torch.from_numpy(mk2), torch.from_numpy(sc),
                                    torch.from_numpy(valid)))
-    return torch.cat(recs, 0)
+    return torch.cat(recs, 0) if recs else torch.zeros((0, 16, 6), dtype=torch.float32)
 
 
-def _worker(rank, world, port, total, out_path):
+def _worker(rank, world, port, total, out_path, collective="gather"):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
@@ -50,7 +50,14 @@ def _worker(rank, world, port, total, out_path):
     assert (r, w) == (rank, world)
     begin, end = D.shard_range(total, rank, world)
     rec = _records_for(range(5000 + begin, 5000 + end))
-    gathered = D.gather_records(rec, dst=0)
+    assert rec.shape[0] == D.shard_sizes(total, world)[rank]
+    gathered = D.gather_records(rec, dst=0, total=total, collective=collective)
+    if total % world == 0:              # equal shards: the form without `total` gives the same
+        again = D.gather_records(rec, dst=0, collective=collective)
+        assert (again is None) == (rank != 0) and (rank != 0 or torch.equal(again, gathered))
+    else:                               # a wrong shard size is caught before the collective, on the rank that has it
+        with pytest.raises(ValueError):
+            D.gather_records(torch.cat([rec, rec[:1], torch.zeros(1, 16, 6)]), dst=0, total=total)
     slowest = D.barrier_max_ms(10.0 * (rank + 1), "cpu")
     assert slowest == 10.0 * world
     if rank == 0:
@@ -83,10 +90,23 @@ def test_record_pack_roundtrip():
     assert torch.equal(a, mk1) and torch.equal(b, mk2) and torch.equal(c, sc) and torch.equal(d, valid)
 
 
-def test_two_rank_gather_equals_single_process(tmp_path):
-    total, world = 4, 2
+@pytest.mark.parametrize("total,collective", [(4, "gather"), (5, "gather"), (5, "all_gather"), (1, "gather")])
+def test_two_rank_gather_equals_single_process(tmp_path, total, collective):
+    """4 pairs: equal shards.  5 pairs / 2 ranks: shards of 3 and 2 (padded for the collective, trimmed on rank 0),
+    through both collectives.  1 pair: rank 1 holds an empty shard."""
+    world = 2
     out = str(tmp_path / "gathered.pt")
-    mp.spawn(_worker, args=(world, _free_port(), total, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), total, out, collective), nprocs=world, join=True)
     gathered = torch.load(out)
     assert gathered.shape == (total, 16, 6)
     assert torch.equal(gathered, _records_for(range(5000, 5000 + total)))     # global pair order preserved
+
+
+def test_gather_records_argument_checks():
+    from onnx_image_processing_amd.distributed import gather_records
+    rec = torch.zeros(3, 4, 6)
+    assert gather_records(rec, total=3) is rec                                # single process: identity
+    with pytest.raises(ValueError):
+        gather_records(rec, total=4)
+    with pytest.raises(ValueError):
+        gather_records(rec, collective="ring")

@@ -264,3 +264,24 @@ def test_dots_form_refuses_small_epsilon(lib_path):
     assert ops.DOTS_MIN_EPSILON == 0.005
     hdr = open(HEADER).read()
     assert "#define MI_DOTS_MIN_EPSILON 0.005" in hdr
+
+
+def test_reference_import_lines_resolve_to_this_package(lib_path):
+    """`pytorch_model.*` (the reference's package name) aliases onnx_image_processing_amd.pytorch_model.*: same module
+    objects; the module names of feature_detection/__init__.py:4-9 exist; out-of-scope sub-packages are absent."""
+    import importlib
+    import onnx_image_processing_amd.pytorch_model.detector as real
+    alias = importlib.import_module("pytorch_model.detector")
+    assert alias is real
+    from pytorch_model.descriptor.bad import SparseBAD                                       # noqa: F401
+    from pytorch_model.feature_detection import ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix as A
+    from pytorch_model.feature_detection.akaze_sparse_bad_sinkhorn_essential_matrix import (  # noqa: F401
+        AKAZESparseBADSinkhornWithEssentialMatrix)
+    from pytorch_model.feature_detection.shi_tomasi_angle_sparse_bad_sinkhorn_essential_matrix import (
+        ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix as B)
+    from pytorch_model.matching.outlier_filters import dustbin_margin_filter, probability_ratio_filter  # noqa: F401
+    assert A is B
+    with pytest.raises(ImportError):
+        importlib.import_module("pytorch_model.vo")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        probability_ratio_filter(torch.rand(4, 4))

@@ -188,6 +188,24 @@ def test_ratio_filter_known_answers():
         assert valid[0].tolist() == expect
 
 
+KNOWN_DUSTBIN = [  # the example in the reference's docstring (outlier_filters.py:91-97): only point 0 passes
+    (np.array([[0.7, 0.1, 0.2], [0.2, 0.3, 0.5], [0.1, 0.6, 0.3]]), 0.3, [True, False]),
+]
+
+
+def test_outlier_filter_functions_known_answers():
+    """oracle restatement of matching/outlier_filters.py against the reference's own vectors, and against the
+    SinkhornMatcherWithFilters arithmetic (the two are the same tests, sinkhorn.py:337-387)."""
+    for core, thr, expect in KNOWN_RATIO:
+        assert O.probability_ratio_filter(core, thr).tolist() == expect
+    for full, margin, expect in KNOWN_DUSTBIN:
+        assert O.dustbin_margin_filter(full, margin).tolist() == expect
+    rng = np.random.default_rng(3)
+    p = rng.random((1, 41, 41)).astype(np.float32)
+    assert np.array_equal(O.probability_ratio_filter(p[0, :40, :40], 1.3), O.match_filters(p, 1.3, None)[1][0])
+    assert np.array_equal(O.dustbin_margin_filter(p[0], 0.2), O.match_filters(p, None, 0.2)[1][0])
+
+
 def test_filters_unit_vectors():
     g = load_golden("filters_unit")
     for i in range(5):
