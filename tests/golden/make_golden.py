@@ -22,12 +22,13 @@ import numpy as np
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
-sys.path.insert(0, ROOT)
-sys.path.insert(1, "/root/reference")
+# `pytorch_model` must be the REFERENCE here, not the repo's alias package of the same name: the reference's is a
+# namespace package (no __init__.py) and would lose against a regular package on sys.path, so it is imported before
+# the repository root becomes importable (later `pytorch_model.*` imports resolve through sys.modules)
+sys.path.insert(0, "/root/reference")
 
 import torch  # noqa: E402
 
-from onnx_image_processing_amd.synth import synth_batch, synth_image  # noqa: E402
 from pytorch_model.detector.shi_tomasi import ShiTomasiScore  # noqa: E402
 from pytorch_model.utils.keypoint_utils import apply_nms_maxpool, select_topk_keypoints  # noqa: E402
 from pytorch_model.descriptor.bad import SparseBAD  # noqa: E402
@@ -37,6 +38,12 @@ from pytorch_model.feature_detection.shi_tomasi_sparse_bad_sinkhorn import (  # 
     ShiTomasiSparseBADSinkhornMatcher,
 )
 
+sys.path.insert(1, ROOT)
+from onnx_image_processing_amd.synth import synth_batch, synth_image  # noqa: E402
+
+assert "/root/reference" in (sys.modules["pytorch_model"].__path__._path
+                             if hasattr(sys.modules["pytorch_model"].__path__, "_path")
+                             else list(sys.modules["pytorch_model"].__path__))[0], "not the reference package"
 torch.manual_seed(0)
 META = dict(torch_version=torch.__version__, threads=torch.get_num_threads())
 
@@ -410,8 +417,69 @@ def bilinear():
     save("bad_bilinear", **out)
 
 
+def round2():
+    """Full-size fixtures for BASELINE configs[2] and [3]: one 1920x1080 K=1024 pair through the
+    sparse pipeline (keypoints, packed bits, P by row/column maxima, marginals and hash, MNN matches) and one 640x480
+    K=512 pair through AKAZESparseBADSinkhornMatcher with the AKAZE export-CLI values (keypoints, scores, P in full)."""
+    from pytorch_model.feature_detection.akaze_sparse_bad_sinkhorn import AKAZESparseBADSinkhornMatcher
+    # ---- C3
+    seed, h, w, k = 4100, 1080, 1920, 1024
+    a, b = synth_batch(seed, 1, h, w)
+    model = ShiTomasiSparseBADSinkhornMatcher(max_keypoints=k, **EXPORT_CFG).eval()
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    with torch.no_grad():
+        k1, k2, p = model(ta, tb)
+        out = dict(seed=seed, h=h, w=w, k=k, cfg=np.array(repr(EXPORT_CFG)), kpts1=k1.numpy(), kpts2=k2.numpy())
+        for tag, im, kp in (("1", ta, k1), ("2", tb, k2)):
+            s = model.corner_detector(im).squeeze(1)
+            mask = apply_nms_maxpool(s, model.nms_radius)
+            out["nms_count" + tag] = int(mask.sum().item())
+            _, ksc = select_topk_keypoints(s, mask, k, model.score_threshold, model.border_margin)
+            out["kscores" + tag] = ksc.numpy()
+            d = model.descriptor(im, kp)
+            out["bits" + tag] = pack(d.numpy() != 0)
+            out["desc_sha" + tag] = np.array(sha(d.numpy()))
+        core = p[:, :k, :k]
+        rmax, rarg = core.max(2)
+        cmax, carg = core.max(1)
+        out.update(P_sha=np.array(sha(p.numpy())), P_rowsum=p.sum(-1).numpy(), P_colsum=p.sum(-2).numpy(),
+                   P_rowmax=rmax.numpy(), P_rowarg=rarg.numpy().astype(np.int32), P_colmax=cmax.numpy(),
+                   P_colarg=carg.numpy().astype(np.int32), P_dustcol=p[:, :, k].numpy(), P_dustrow=p[:, k, :].numpy(),
+                   P_rows_0_8=p[:, :8].numpy())
+        mnn = dict(max_matches=100, threshold=0.1)
+        mk1, mk2, sc, valid = MutualNearestNeighborMatcher(**mnn)(p, k1, k2)
+        out.update(mnn_cfg=np.array(repr(mnn)), mk1=mk1.numpy(), mk2=mk2.numpy(), mscores=sc.numpy(), mvalid=valid.numpy())
+    save("c3_pair_1080x1920_k1024", **out)
+    # ---- C4
+    seed, h, w, k = 1000, 480, 640, 512
+    cfg = dict(num_pairs=256, binarize=False, sinkhorn_iterations=20, epsilon=0.05, unused_score=1.0,
+               distance_type="l2", nms_radius=3, score_threshold=0.0, normalize_descriptors=True, sampling_mode="nearest")
+    a, b = synth_batch(seed, 1, h, w)
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    mm = AKAZESparseBADSinkhornMatcher(max_keypoints=k, **cfg).eval()
+    with torch.no_grad():
+        k1, k2, p = mm(ta, tb)
+        out = dict(seed=seed, h=h, w=w, k=k, cfg=np.array(repr(cfg)), k1=k1.numpy(), k2=k2.numpy(), P=p.numpy())
+        for t, im, kp in (("1", ta, k1), ("2", tb, k2)):
+            sc, ori = mm.detector(im)
+            _, ksc = select_topk_keypoints(sc.squeeze(1), apply_nms_maxpool(sc.squeeze(1), mm.nms_radius), k,
+                                           mm.score_threshold, mm.border_margin)
+            out[f"kscores{t}"] = ksc.numpy()
+            out[f"score_sha{t}"] = np.array(sha(sc.numpy()))
+            out[f"score_nonzero{t}"] = int((sc > 0).sum().item())
+            kk = kp[0].long().clamp(min=0)
+            out[f"theta{t}"] = ori[0, 0][kk[:, 0], kk[:, 1]].numpy()
+            out[f"desc{t}_first64"] = mm.descriptor(im, kp, ori).numpy()[:, :64]
+        mnn = dict(max_matches=100, threshold=0.1)
+        mk1, mk2, sc, valid = MutualNearestNeighborMatcher(**mnn)(p, k1, k2)
+        out.update(mnn_cfg=np.array(repr(mnn)), mk1=mk1.numpy(), mk2=mk2.numpy(), mscores=sc.numpy(), mvalid=valid.numpy())
+    save("akaze_c4_480x640_k512", **out)
+
+
 if __name__ == "__main__":
-    if "--dense-only" in sys.argv:
+    if "--round2-only" in sys.argv:
+        round2()
+    elif "--dense-only" in sys.argv:
         dense()
     elif "--bilinear-only" in sys.argv:
         bilinear()
@@ -434,3 +502,4 @@ if __name__ == "__main__":
         essential()
         detectors()
         bilinear()
+        round2()

@@ -1,11 +1,12 @@
 """Pins oracle/numpy_oracle.py against outputs of the reference itself
 (tests/golden/*.npz, produced by tests/golden/make_golden.py).  CPU only."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
 
-from helpers import bad_tables, cfg_of, load_golden, p_close, permute_p, tie_canonical_perm, unpack_bits
+from helpers import ALLOW, bad_tables, bits_mismatch, cfg_of, load_golden, p_close, permute_p, tie_canonical_perm, unpack_bits
 from onnx_image_processing_amd.synth import synth_batch, synth_image
 from oracle import numpy_oracle as O
 
@@ -114,7 +115,9 @@ def test_pipeline_matches_reference(name):
             # fp32 error of the threshold ("fragile"); SURVEY.md §8c.2
             for kk, pp in diff:
                 assert abs(bad["centered"][0, kk, pp]) < 5e-4, (kk, pp, bad["centered"][0, kk, pp])
-            assert len(diff) <= 4
+            if os.environ.get("MI_REPORT"):
+                print(f"[fragile] {name} image {tag}: {len(diff)}")
+            assert len(diff) <= ALLOW.get(f"fragile_{name}_{tag}", 0), (name, tag, len(diff))
             if len(diff) == 0 and cfg.get("normalize_descriptors", True):
                 d = aux["desc" + tag][0]
                 inv = np.argsort(perm)
@@ -249,7 +252,7 @@ def test_angle_pipeline_vs_reference(name):
     for t, pm in zip("12", perms):
         dref, dmine = g[f"{name}_desc{t}"][0][pm], aux["desc" + t][0]
         if name == "hard":
-            assert ((dref != 0) == (dmine != 0)).mean() >= 0.9999
+            bits_mismatch(dref != 0, dmine != 0, ALLOW[f"angle_hard_desc{t}"], f"angle hard desc{t}")
         else:
             np.testing.assert_allclose(dmine, dref, rtol=0, atol=3e-5)
     ok, worst = p_close(p[0], permute_p(g[name + "_P"][0], perms[0], perms[1]))
@@ -333,7 +336,7 @@ def test_akaze_pipeline_vs_reference(key, div):
     np.testing.assert_allclose(aux["scores1"], g[key + "_scoremap1"], rtol=1e-6, atol=0)
     assert np.abs(aux["ori2"] - g[key + "_orimap2"]).max() < 3e-4
     if cfg.get("binarize") and not cfg.get("soft_binarize", True):
-        assert ((aux["desc1"] != 0) == (g[key + "_desc1"] != 0)).mean() >= 0.9995
+        bits_mismatch(aux["desc1"] != 0, g[key + "_desc1"] != 0, ALLOW["akaze_" + key], "akaze " + key)
     else:
         np.testing.assert_allclose(aux["desc1"], g[key + "_desc1"], rtol=0, atol=1e-4)
     ok, worst = p_close(p, g[key + "_P"], atol=2e-4)
@@ -394,7 +397,7 @@ def test_sparse_bad_bilinear_oracle_vs_reference():
             d = O.sparse_bad_oriented(a, kpts, th, box, thr, sampling_mode="bilinear", **kw)
             ref = g[f"{name}_{tag}"]
             if name == "hard":
-                assert ((d != 0) == (ref != 0)).mean() >= 0.9995
+                bits_mismatch(d != 0, ref != 0, ALLOW[f"bilinear_{tag}"], f"bilinear hard {tag}")
             else:                               # the reference's fp32 box means are off by up to 2e-4 each
                 np.testing.assert_allclose(d, ref, rtol=0, atol=1e-3 if name == "raw" else 1e-4)
 
@@ -407,4 +410,65 @@ def test_dense_oriented_bad_oracle_vs_reference():
     box, thr = bad_tables(512)
     hard = O.bad_dense_oriented(small, g["dense_ang"], box, thr, binarize=True, soft_binarize=False)
     ref = np.unpackbits(g["dense_hard"])[: hard.size].reshape(hard.shape)
-    assert (ref == (hard != 0)).mean() >= 0.9995
+    bits_mismatch(ref, hard != 0, ALLOW["dense_oriented_hard"], "dense oriented hard")
+
+
+# ---------------------------------------------------------------- full-size fixtures of BASELINE configs[2] / [3]
+def check_c3_against_fixture(g, k1, k2, p, bits1=None, bits2=None):
+    """Shared by the oracle test here and the GPU test: keypoints bit-exact after tie canonicalisation, packed bits
+    equal, P through the recorded row / column maxima + argmaxima, dustbin row / column, marginals, the first 8 rows
+    in full, and the MNN match set."""
+    w, k = int(g["w"]), int(g["k"])
+    perms = [tie_canonical_perm(g["kpts" + t][0], g["kscores" + t][0], w) for t in "12"]
+    assert np.array_equal(k1[0], g["kpts1"][0][perms[0]]) and np.array_equal(k2[0], g["kpts2"][0][perms[1]])
+    for tag, bits, pm in (("1", bits1, perms[0]), ("2", bits2, perms[1])):
+        if bits is not None:
+            assert np.array_equal(np.asarray(bits).view(np.uint32)[0], g["bits" + tag][0][pm]), f"bits{tag}"
+    pr = p[0].astype(np.float64)
+    inv = [np.argsort(pm) for pm in perms]                       # fixture order <- canonical order
+    core = pr[:k, :k][np.ix_(inv[0], inv[1])]                    # back in the reference's keypoint order
+    tol = lambda ref: 1e-4 * np.maximum(1.0, np.abs(ref))        # noqa: E731
+    assert (np.abs(core.max(1) - g["P_rowmax"][0]) <= tol(g["P_rowmax"][0])).all()
+    assert (np.abs(core.max(0) - g["P_colmax"][0]) <= tol(g["P_colmax"][0])).all()
+    strong = g["P_rowmax"][0] > 0.5                              # a confident row has one clear winner
+    assert np.array_equal(core.argmax(1)[strong], g["P_rowarg"][0][strong])
+    strong = g["P_colmax"][0] > 0.5
+    assert np.array_equal(core.argmax(0)[strong], g["P_colarg"][0][strong])
+    dustcol = np.concatenate([pr[:k, k][inv[0]], pr[k:, k]])
+    dustrow = np.concatenate([pr[k, :k][inv[1]], pr[k:, k]])
+    assert (np.abs(dustcol - g["P_dustcol"][0]) <= tol(g["P_dustcol"][0])).all()
+    assert (np.abs(dustrow - g["P_dustrow"][0]) <= tol(g["P_dustrow"][0])).all()
+    rows = np.concatenate([pr[:k][inv[0]][:8][:, inv[1]], pr[:k][inv[0]][:8][:, k:]], axis=1)
+    assert (np.abs(rows - g["P_rows_0_8"][0]) <= tol(g["P_rows_0_8"][0])).all()
+    rowsum = np.concatenate([pr[:k].sum(1)[inv[0]], pr[k:].sum(1)])
+    assert np.abs(rowsum - g["P_rowsum"][0]).max() <= 1e-3 * max(1.0, float(np.abs(g["P_rowsum"][0]).max()))
+
+
+def test_c3_pair_1080p_k1024_vs_reference():
+    g = load_golden("c3_pair_1080x1920_k1024")
+    a, b = synth_batch(int(g["seed"]), 1, int(g["h"]), int(g["w"]))
+    cfg = cfg_of(g)
+    box, thr = bad_tables(cfg["num_pairs"])
+    kw = {k: v for k, v in cfg.items() if k not in ("num_pairs", "sampling_mode")}
+    k1, k2, p, aux = O.match_pair(a, b, box, thr, int(g["k"]), return_aux=True, **kw)
+    check_c3_against_fixture(g, k1, k2, p, O.pack_bits(aux["bad1"]["bits"]), O.pack_bits(aux["bad2"]["bits"]))
+    mk1, mk2, sc, valid, _ = O.mnn_extract(p, k1, k2, **cfg_of(g, "mnn_cfg"))
+    assert np.array_equal(valid, g["mvalid"])
+    want = {(tuple(x), tuple(y)) for x, y, v in zip(g["mk1"][0], g["mk2"][0], g["mvalid"][0]) if v}
+    assert {(tuple(x), tuple(y)) for x, y, v in zip(mk1[0], mk2[0], valid[0]) if v} == want
+
+
+def test_akaze_c4_480x640_k512_vs_reference():
+    """BASELINE configs[3] at its own size (AKAZE export-CLI values): keypoints and keypoint scores exact, P 5e-4
+    (VERDICT r1 next #3; measured 1.6e-6)."""
+    g = load_golden("akaze_c4_480x640_k512")
+    cfg = cfg_of(g)
+    a, b = synth_batch(int(g["seed"]), 1, int(g["h"]), int(g["w"]))
+    box, thr = bad_tables(cfg["num_pairs"])
+    kw = {k: v for k, v in cfg.items() if k not in ("num_pairs", "max_keypoints", "sampling_mode")}
+    k1, k2, p, aux = O.match_pair_akaze(a, b, box, thr, int(g["k"]), return_aux=True, **kw)
+    assert np.array_equal(k1, g["k1"]) and np.array_equal(k2, g["k2"])
+    assert np.array_equal(aux["kscores1"], g["kscores1"]) and np.array_equal(aux["kscores2"], g["kscores2"])
+    np.testing.assert_allclose(aux["desc1"][:, :64], g["desc1_first64"], rtol=0, atol=1e-5)
+    ok, worst = p_close(p, g["P"])
+    assert ok, worst
