@@ -64,6 +64,15 @@ int mi_release_stream_resources(mi_stream_t stream);
  * block_size: positive odd.  Bit-exact vs the reference for uint8-valued input, block 3. */
 int mi_corner_response(const float *image, int n, int h, int w, int block_size, float *score,
                        mi_stream_t stream);
+/* ---- u8 ingest (sample/visual_odometry.py:65-92 load_image_from_array, sample/image_matching.py:42-46: a uint8 gray
+ * frame is converted to float32 (1,1,H,W) on the host before the model sees it).  The _u8 entry points take the
+ * uint8 frame itself: the same results as the float32 entry point on the converted frame, bit for bit, with 1 instead
+ * of 4 bytes per pixel read (corner response: 5 instead of 8 B/px of HBM traffic; a pair costs 0.6 instead of
+ * 2.5 MB of PCIe when frames are streamed from the host).  mi_convert_u8_f32 is that conversion on the device, for
+ * the entry points that have no uint8 form. */
+int mi_corner_response_u8(const uint8_t *image, int n, int h, int w, int block_size, float *score,
+                          mi_stream_t stream);
+int mi_convert_u8_f32(const uint8_t *src, long long count, float *dst, mi_stream_t stream);
 
 /* ---- utils/keypoint_utils.py:12-44  apply_nms_maxpool ---------------------------------------
  * mask = 1.0f where score >= max over the (2r+1)^2 window (outside image = -inf) - 1e-7. */
@@ -114,6 +123,12 @@ int mi_sparse_bad(const float *image, int n, int h, int w, const float *keypoint
                   const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
                   float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
                   uint8_t *status, mi_stream_t stream);
+
+/* u8 ingest form of mi_sparse_bad (see mi_corner_response_u8): identical results from a uint8 image. */
+int mi_sparse_bad_u8(const uint8_t *image, int n, int h, int w, const float *keypoints, int k,
+                     const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
+                     float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
+                     uint8_t *status, mi_stream_t stream);
 
 /* ---- descriptor/bad.py:62-110,189-218  BADDescriptor.forward (dense, non-oriented) ------------
  * out (n, num_pairs, h, w): the BAD response at every pixel, raw / sigmoid(-c*T) / (c <= 0),
@@ -342,6 +357,12 @@ int mi_match_pairs(const float *image1, const float *image2, int batch, int h, i
                    const mi_match_params *params, float *keypoints1, float *keypoints2, float *matched1,
                    float *matched2, float *match_scores, uint8_t *match_valid, int32_t *match_ij,
                    void *workspace, size_t workspace_bytes, mi_stream_t stream);
+
+/* u8 ingest form of mi_match_pairs: uint8 frames (batch,1,h,w), same workspace, identical results. */
+int mi_match_pairs_u8(const uint8_t *image1, const uint8_t *image2, int batch, int h, int w,
+                      const mi_match_params *params, float *keypoints1, float *keypoints2, float *matched1,
+                      float *matched2, float *match_scores, uint8_t *match_valid, int32_t *match_ij,
+                      void *workspace, size_t workspace_bytes, mi_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,8 @@ SIGNATURES = {
     "mi_error_string": [c_int],
     "mi_release_stream_resources": [c_void_p],
     "mi_corner_response": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "mi_corner_response_u8": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "mi_convert_u8_f32": [c_void_p, ctypes.c_longlong, c_void_p, c_void_p],
     "mi_nms_mask": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mi_candidate_layout": [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
     "mi_nms_candidates": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p],
@@ -31,6 +33,8 @@ SIGNATURES = {
     "mi_bad_plan_build": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "mi_sparse_bad": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mi_sparse_bad_u8": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
+                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mi_bad_dense": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p],
     "mi_bad_dense_oriented": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
                               c_void_p],
@@ -87,6 +91,7 @@ SIGNATURES["mi_match_pairs"] = [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
 # include/mi355x_match_debug.h: test / tooling hooks, not part of the product ABI (nothing in this package calls them)
 DEBUG_SIGNATURES = {"mi_debug_set": [c_int, c_int]}
+SIGNATURES["mi_match_pairs_u8"] = SIGNATURES["mi_match_pairs"]
 _RESTYPE = {"mi_match_pairs_workspace_bytes": c_size_t, "mi_error_string": c_char_p, "mi_sinkhorn_workspace_bytes": c_size_t, "mi_bad_plan_bytes": c_size_t,
             "mi_sinkhorn_dots_workspace_bytes": c_size_t, "mi_mnn_duals_workspace_bytes": c_size_t}
 

@@ -29,6 +29,7 @@
 
 #include <math.h>
 
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -65,8 +66,10 @@ __device__ __forceinline__ int nearest_centre(float pos, float scale, int size) 
 // GROUPS = num_pairs / 64 at compile time (0: read it at run time).  With a constant trip count the pair
 // loop is straight-line code and the compiler hoists the pair-table loads of later groups above the box
 // gathers of earlier ones; with a run-time count every group paid an L1/L2 round trip where it was used.
-template <int GROUPS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void bad_fast_kernel(const float *__restrict__ image, int h, int w,
+// PIX = float (the reference's input) or uint8_t (the u8 ingest path: same window, a quarter of the bytes, no
+// integrality test -- every uint8 patch is integer-valued).
+template <int GROUPS, typename PIX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void bad_fast_kernel(const PIX *__restrict__ image, int h, int w,
                                                        const float *__restrict__ kpts, int k, int total,
                                                        int num_pairs, int normalize,
                                                        const BadPlan *__restrict__ plan,
@@ -81,7 +84,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const int flat = (int)xcd_contiguous_id(blockIdx.x, gridDim.x) * 4 + wave;
   if (flat >= total) return;
   const int img = flat / k;
-  const float *im = image + (size_t)img * h * w;
+  const PIX *im = image + (size_t)img * h * w;
+  constexpr uint32_t PB = (uint32_t)sizeof(PIX);
   const float ky = kpts[(size_t)flat * 2 + 0];
   const float kx = kpts[(size_t)flat * 2 + 1];
   const int groups = GROUPS ? GROUPS : num_pairs / 64;
@@ -119,17 +123,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const bool window_inside = ky >= 16.0f && ky <= (float)(h - 16) && kx >= 16.0f && kx <= (float)(w - 16);
   uint32_t off[16];
   if (window_inside) {                                         // wave-uniform
-    const uint32_t first = (uint32_t)((oy + 16 * half) * w + ox + c) * 4u;
+    const uint32_t first = (uint32_t)((oy + 16 * half) * w + ox + c) * PB;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) off[r] = first + (uint32_t)(r * w) * 4u;
+    for (int r = 0; r < 16; ++r) off[r] = first + (uint32_t)(r * w) * PB;
   } else {
     const int gx = clampi(ox + c, 0, w - 1);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) off[r] = (uint32_t)(clampi(oy + 16 * half + r, 0, h - 1) * w + gx) * 4u;
+    for (int r = 0; r < 16; ++r) off[r] = (uint32_t)(clampi(oy + 16 * half + r, 0, h - 1) * w + gx) * PB;
   }
-  float px[16];
+  PIX px[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) px[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(im) + off[r]);
+  for (int r = 0; r < 16; ++r) px[r] = *reinterpret_cast<const PIX *>(reinterpret_cast<const char *>(im) + off[r]);
   const uint4 *plan_offs = reinterpret_cast<const uint4 *>(plan + 1);
   const int *plan_tint = reinterpret_cast<const int *>(plan_offs + num_pairs);
   // the first pair-table words ride behind the window gather instead of waiting for the table build
@@ -147,11 +151,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int v = (int)px[r];
-    integral = integral && ((float)v == px[r]) && (v >= 0) && (v <= 255);
+    if constexpr (std::is_same<PIX, float>::value) integral = integral && ((float)v == px[r]) && (v >= 0) && (v <= 255);
     acc += v;
     col[r] = acc;
   }
-  if (!__all(integral)) {
+  if (std::is_same<PIX, float>::value && !__all(integral)) {
     if (lane == 0) status[flat] = 0;
     return;
   }
@@ -240,7 +244,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // `chunk` (<= 64) consecutive keypoints; it visits only those the fast kernel flagged (status == 0).
 // Small chunks keep the serial depth per wave low: about 6 % of the keypoints are flagged at 640x480
 // (those within 15 px of the border), i.e. about one per 16.
-__global__ __launch_bounds__(64) void sparse_bad_kernel(const float *__restrict__ image, int h, int w,
+template <typename PIX>
+__global__ __launch_bounds__(64) void sparse_bad_kernel(const PIX *__restrict__ image, int h, int w,
                                                         const float *__restrict__ kpts, int k, int total,
                                                         const uint32_t *__restrict__ geom,
                                                         const float *__restrict__ thr, int num_pairs,
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(64) void sparse_bad_kernel(const float *__restrict_
     todo &= todo - 1ull;
     const int flat = first + bit;
     const int img = flat / k;
-    const float *im = image + (size_t)img * h * w;
+    const PIX *im = image + (size_t)img * h * w;
     const float ky_raw = kpts[(size_t)flat * 2 + 0];
     const float kx_raw = kpts[(size_t)flat * 2 + 1];
     const bool valid = ky_raw >= 0.0f;                                   // bad.py:461
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(64) void sparse_bad_kernel(const float *__restrict_
     for (int i = lane; i < SP; i += 64) { sat[i] = 0.0; sat[i * SP] = 0.0; }
     if (lane < WIN) {
       const int gx = clampi(ox + lane, 0, w - 1);
-      float px[WIN];
+      PIX px[WIN];
 #pragma unroll
       for (int r = 0; r < WIN; ++r) px[r] = im[(size_t)clampi(oy + r, 0, h - 1) * w + gx];
       double acc = 0.0;
@@ -520,11 +525,11 @@ extern "C" int mi_bad_plan_build(const uint32_t *pair_geom, const float *pair_th
   return MI_OK;
 }
 
-extern "C" int mi_sparse_bad(const float *image, int n, int h, int w, const float *keypoints, int k,
-                             const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
-                             float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
-                             uint8_t *status, mi_stream_t stream) {
-  MI_ENTER();
+namespace {
+template <typename PIX>
+int sparse_bad_launch(const PIX *image, int n, int h, int w, const float *keypoints, int k, const uint32_t *pair_geom,
+                      const float *pair_thr, int num_pairs, int mode, float temperature, int normalize, float *desc,
+                      uint32_t *bits, const void *plan, uint8_t *status, mi_stream_t stream) {
   if (!image || !keypoints || !pair_geom || !pair_thr) return MI_E_NULL;
   if (!desc && !bits) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0 || k <= 0) return MI_E_SHAPE;
@@ -541,17 +546,38 @@ extern "C" int mi_sparse_bad(const float *image, int n, int h, int w, const floa
                     (long long)h * w < (1LL << 30);          // the fast kernel addresses a plane with 32-bit byte offsets
   if (fast) {
     const BadPlan *bp = reinterpret_cast<const BadPlan *>(plan);
-    auto fast_kernel = num_pairs == 512 ? bad_fast_kernel<8> : num_pairs == 256 ? bad_fast_kernel<4> : bad_fast_kernel<0>;
+    auto fast_kernel = num_pairs == 512 ? bad_fast_kernel<8, PIX> : num_pairs == 256 ? bad_fast_kernel<4, PIX> : bad_fast_kernel<0, PIX>;
     hipLaunchKernelGGL(fast_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, s, image, h, w, keypoints,
                        k, total, num_pairs, normalize, bp, pair_geom, desc, bits, status);
     constexpr int CHUNK = 16;
-    hipLaunchKernelGGL(sparse_bad_kernel, dim3((unsigned)ceil_div(total, CHUNK)), dim3(64), 0, s, image, h, w,
+    hipLaunchKernelGGL(sparse_bad_kernel<PIX>, dim3((unsigned)ceil_div(total, CHUNK)), dim3(64), 0, s, image, h, w,
                        keypoints, k, total, pair_geom, pair_thr, num_pairs, mode, temperature, normalize, scale_y,
                        scale_x, desc, bits, status, CHUNK);
   } else {
-    hipLaunchKernelGGL(sparse_bad_kernel, dim3((unsigned)total), dim3(64), 0, s, image, h, w, keypoints, k, total,
+    hipLaunchKernelGGL(sparse_bad_kernel<PIX>, dim3((unsigned)total), dim3(64), 0, s, image, h, w, keypoints, k, total,
                        pair_geom, pair_thr, num_pairs, mode, temperature, normalize, scale_y, scale_x, desc, bits,
                        nullptr, 1);
   }
   return mi_launch_status();
+}
+}  // namespace
+
+extern "C" int mi_sparse_bad(const float *image, int n, int h, int w, const float *keypoints, int k,
+                             const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
+                             float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
+                             uint8_t *status, mi_stream_t stream) {
+  MI_ENTER();
+  return sparse_bad_launch<float>(image, n, h, w, keypoints, k, pair_geom, pair_thr, num_pairs, mode, temperature,
+                                  normalize, desc, bits, plan, status, stream);
+}
+
+// u8 ingest: the same descriptors from uint8 pixels (a uint8 frame is what the camera delivers; the reference converts
+// it to float32 on the host first, sample/visual_odometry.py:65-92)
+extern "C" int mi_sparse_bad_u8(const uint8_t *image, int n, int h, int w, const float *keypoints, int k,
+                                const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
+                                float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
+                                uint8_t *status, mi_stream_t stream) {
+  MI_ENTER();
+  return sparse_bad_launch<uint8_t>(image, n, h, w, keypoints, k, pair_geom, pair_thr, num_pairs, mode, temperature,
+                                    normalize, desc, bits, plan, status, stream);
 }

@@ -14,6 +14,7 @@
 #pragma clang fp contract(off)
 
 #include <atomic>
+#include <type_traits>
 
 #include "../../include/mi355x_match_debug.h"
 
@@ -50,11 +51,35 @@ __device__ __forceinline__ float lambda_min(float a, float c, float b) {
   return fmaxf(half_trace - root, 0.0f);
 }
 
+// uint8 tiles (the u8 ingest path, mi_corner_response_u8): one dword = 4 pixels, LWD dwords per staged row
+constexpr int LWD = (TW + 2 * LPAD) / 4;
+
+// The 12 window columns x-4 .. x+7 of staged row `row` for thread column tx.  fp32 tile: three float4.  uint8
+// tile: three dwords, the eight columns the stencil uses (window indices 2..9) converted with
+// v_cvt_f32_ubyteN (exact; everything downstream is the fp32 arithmetic of the fp32 path, so both produce the
+// same bits); indices 0, 1, 10, 11 only exist so that the edge splats below stay uniform.
+__device__ __forceinline__ void load_window(const float4 *__restrict__ tile, int row, int tx, float *d) {
+  const float4 *src = &tile[row * LW4 + tx];
+  const float4 a = src[0], b = src[1], c = src[2];
+  d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
+  d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+  d[8] = c.x; d[9] = c.y; d[10] = c.z; d[11] = c.w;
+}
+__device__ __forceinline__ void load_window(const uint32_t *__restrict__ tile, int row, int tx, float *d) {
+  const uint32_t *src = &tile[row * LWD + tx];
+  const uint32_t a = src[0], b = src[1], c = src[2];
+  d[0] = 0.0f; d[1] = 0.0f;
+  d[2] = (float)((a >> 16) & 0xFFu); d[3] = (float)(a >> 24);
+  d[4] = (float)(b & 0xFFu); d[5] = (float)((b >> 8) & 0xFFu); d[6] = (float)((b >> 16) & 0xFFu); d[7] = (float)(b >> 24);
+  d[8] = (float)(c & 0xFFu); d[9] = (float)((c >> 8) & 0xFFu);
+  d[10] = 0.0f; d[11] = 0.0f;
+}
+
 // Per-thread stencil on a staged tile (shared by the tile and the streaming kernels).
-// `tile` is the row-major [LH][LW4] float4 image of the clamped image region whose first row is
-// y0 - HL and first column x0 - LPAD.
-template <int BS, int R>
-__device__ __forceinline__ void corner_compute(const float4 *__restrict__ tile, float *__restrict__ score,
+// `tile` is the row-major [LH][LW4] float4 (or [LH][LWD] dword, 4 uint8 pixels each) image of the clamped image
+// region whose first row is y0 - HL and first column x0 - LPAD.
+template <int BS, int R, typename TILE>
+__device__ __forceinline__ void corner_compute(const TILE *__restrict__ tile, float *__restrict__ score,
                                                int img, int h, int w, int x0, int y0, int t) {
   constexpr int HP = BS / 2;       // halo of the product maps
   constexpr int HL = HP + 1;       // halo of the image
@@ -85,12 +110,8 @@ __device__ __forceinline__ void corner_compute(const float4 *__restrict__ tile, 
   for (int ir = 0; ir < R + 2 * HL; ++ir) {
     // image row (ybase - HL + ir) lives in LDS row ty*R + ir
     {
-      const float4 *src = &tile[(ty * R + ir) * LW4 + tx];
-      const float4 a = src[0], b = src[1], c = src[2];
       float *d = win[ir % 3];
-      d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
-      d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
-      d[8] = c.x; d[9] = c.y; d[10] = c.z; d[11] = c.w;
+      load_window(tile, ty * R + ir, tx, d);
       // replicate padding of the IMAGE in x: chunks left/right of the image take the edge pixel
       // (the register-staged kernel already stored them that way; LDS-DMA cannot splat)
       if (tile_left) {
@@ -304,14 +325,18 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(const float *__restric
 // Row clamping is done by the DMA source address itself; chunks left/right of the image are
 // fetched from a clamped (valid) address and replaced by the edge pixel in registers
 // (corner_compute), so no LDS access ever has to wait for an in-flight DMA.
-template <int BS, int R>
-__global__ __launch_bounds__(256) void corner_stream_kernel(const float *__restrict__ image,
+// PIX = float: 16-byte pieces (global_load_lds_dwordx4), 8 B/px of HBM traffic per pixel (4 read + 4 written).
+// PIX = uint8_t (the u8 ingest path): the same chunk grid with 4-byte pieces (global_load_lds_dword, 4 pixels
+// each), 5 B/px; the tile is a quarter of the LDS, the stencil converts on the LDS read (load_window).
+template <int BS, int R, bool U8>
+__global__ __launch_bounds__(256) void corner_stream_kernel(const void *__restrict__ image_raw,
                                                             float *__restrict__ score, int h, int w,
                                                             int tiles_x, int tiles_y, int total_tiles) {
+  using CH = typename std::conditional<U8, uint32_t, float4>::type;   // 4 pixels
   constexpr int HP = BS / 2, HL = HP + 1, TH = 8 * R, LH = TH + 2 * HL;
   constexpr int NCH = (LH * LW4 + 255) / 256;   // DMA pieces per wave per tile
-  constexpr int BUF = NCH * 256;                // float4 slots per buffer (tail slots are scratch)
-  __shared__ float4 lds[2 * BUF];
+  constexpr int BUF = NCH * 256;                // chunk slots per buffer (tail slots are scratch)
+  __shared__ CH lds[2 * BUF];
 
   const int t = threadIdx.x;
   const int wave_base = t & ~63;
@@ -336,14 +361,19 @@ __global__ __launch_bounds__(256) void corner_stream_kernel(const float *__restr
     pcol[q] = 4 * (i % LW4) - LPAD;
   }
   auto issue = [&](int img, int x0, int y0, int buf) {
-    const float *im = image + (size_t)img * h * w;
+    // The source pointers have concrete types on purpose: with a template-dependent pointer type hipcc 7.2 checks
+    // the builtin's size immediate at instantiation time in the HOST pass, rejects 16 there without a diagnostic
+    // and drops the instance's host stub (undefined symbol at load time).
+    const size_t plane = (size_t)img * h * w;
+    const float *imf = static_cast<const float *>(image_raw) + plane;
+    const uint8_t *imb = static_cast<const uint8_t *>(image_raw) + plane;
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
       const int gy = clampi(y0 + prow[q], 0, h - 1);
       const int gx = clampi(x0 + pcol[q], 0, w - 4);
-      __builtin_amdgcn_global_load_lds(im + (gy * w + gx),
-                                       (__attribute__((address_space(3))) void *)&lds[buf * BUF + q * 256 + wave_base],
-                                       16, 0, 0);
+      auto *dst = (__attribute__((address_space(3))) void *)&lds[buf * BUF + q * 256 + wave_base];
+      if constexpr (U8) __builtin_amdgcn_global_load_lds(imb + (gy * w + gx), dst, 4, 0, 0);
+      else __builtin_amdgcn_global_load_lds(imf + (gy * w + gx), dst, 16, 0, 0);
     }
   };
 
@@ -369,7 +399,7 @@ __global__ __launch_bounds__(256) void corner_stream_kernel(const float *__restr
       issue(nimg, nx0, ny0, cur ^ 1);
     }
     prev_full = (x0 + TW <= w) && (y0 + TH <= h);  // workgroup-uniform
-    const float4 *tile = &lds[cur * BUF];
+    const CH *tile = &lds[cur * BUF];
     corner_compute<BS, R>(tile, score, img, h, w, x0, y0, t);
     img = nimg; x0 = nx0; y0 = ny0;
   }
@@ -377,7 +407,8 @@ __global__ __launch_bounds__(256) void corner_stream_kernel(const float *__restr
 
 // Generic path: any width, any odd block size.  One thread per pixel, straight from global
 // memory (L2 absorbs the re-reads).  Same arithmetic, same clamping rules.
-__global__ __launch_bounds__(256) void corner_generic_kernel(const float *__restrict__ image,
+template <typename PIX>
+__global__ __launch_bounds__(256) void corner_generic_kernel(const PIX *__restrict__ image,
                                                              float *__restrict__ score, int n, int h,
                                                              int w, int bs) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -385,20 +416,20 @@ __global__ __launch_bounds__(256) void corner_generic_kernel(const float *__rest
   if (idx >= total) return;
   const int x = (int)(idx % w);
   const int y = (int)((idx / w) % h);
-  const float *im = image + (idx / ((size_t)h * w)) * (size_t)h * w;
+  const PIX *im = image + (idx / ((size_t)h * w)) * (size_t)h * w;
   const int hp = bs / 2;
   float a = 0.f, c = 0.f, b = 0.f;
   for (int dy = -hp; dy <= hp; ++dy) {
     const int py = clampi(y + dy, 0, h - 1);
-    const float *r0 = im + (size_t)clampi(py - 1, 0, h - 1) * w;
-    const float *r1 = im + (size_t)py * w;
-    const float *r2 = im + (size_t)clampi(py + 1, 0, h - 1) * w;
+    const PIX *r0 = im + (size_t)clampi(py - 1, 0, h - 1) * w;
+    const PIX *r1 = im + (size_t)py * w;
+    const PIX *r2 = im + (size_t)clampi(py + 1, 0, h - 1) * w;
     for (int dx = -hp; dx <= hp; ++dx) {
       const int px = clampi(x + dx, 0, w - 1);
       const int xl = clampi(px - 1, 0, w - 1), xr = clampi(px + 1, 0, w - 1);
-      const float sl = (r0[xl] + r2[xl]) + 2.0f * r1[xl];
-      const float sr = (r0[xr] + r2[xr]) + 2.0f * r1[xr];
-      const float dl = r2[xl] - r0[xl], dc = r2[px] - r0[px], dr = r2[xr] - r0[xr];
+      const float sl = ((float)r0[xl] + (float)r2[xl]) + 2.0f * (float)r1[xl];
+      const float sr = ((float)r0[xr] + (float)r2[xr]) + 2.0f * (float)r1[xr];
+      const float dl = (float)r2[xl] - (float)r0[xl], dc = (float)r2[px] - (float)r0[px], dr = (float)r2[xr] - (float)r0[xr];
       const float gx = sr - sl;
       const float gy = (dl + dr) + 2.0f * dc;
       a += gx * gx;
@@ -420,19 +451,22 @@ int launch_tile(const float *image, int n, int h, int w, float *score, hipStream
 }
 
 // Persistent grid: 2 workgroups per CU (2 x 80 KiB of LDS) on the 256 CUs of an MI355X.
-template <int BS, int R>
-int launch_stream(const float *image, int n, int h, int w, float *score, hipStream_t s) {
+template <int BS, int R, typename PIX>
+int launch_stream(const PIX *image, int n, int h, int w, float *score, hipStream_t s) {
   const int tiles_x = ceil_div(w, TW), tiles_y = ceil_div(h, 8 * R);
   const long long total = (long long)n * tiles_x * tiles_y;
   if (total > 0x7fffffffLL) return MI_E_SHAPE;
   // persistent grid: as many workgroups per CU as two LDS buffers allow, on 256 CUs
   constexpr int LH = 8 * R + 2 * (BS / 2 + 1);
-  constexpr int LDS_BYTES = 2 * ((LH * LW4 + 255) / 256) * 256 * 16;
-  constexpr int PER_CU = (160 * 1024) / LDS_BYTES;
-  const int resident = 256 * (PER_CU > 8 ? 8 : PER_CU);
+  constexpr int PIECE = std::is_same<PIX, float>::value ? 16 : 4;
+  constexpr int LDS_BYTES = 2 * ((LH * LW4 + 255) / 256) * 256 * PIECE;
+  constexpr int PER_CU_LDS = (160 * 1024) / LDS_BYTES;
+  // fp32: LDS allows 4 workgroups per CU.  uint8: LDS would allow 16, registers (the same stencil) about 5.
+  constexpr int PER_CU = std::is_same<PIX, float>::value ? (PER_CU_LDS > 8 ? 8 : PER_CU_LDS) : 5;
+  const int resident = 256 * PER_CU;
   const int grid = total < resident ? (int)total : resident;
-  hipLaunchKernelGGL((corner_stream_kernel<BS, R>), dim3(grid), dim3(256), 0, s, image, score, h, w, tiles_x,
-                     tiles_y, (int)total);
+  hipLaunchKernelGGL((corner_stream_kernel<BS, R, std::is_same<PIX, uint8_t>::value>), dim3(grid), dim3(256), 0, s,
+                     static_cast<const void *>(image), score, h, w, tiles_x, tiles_y, (int)total);
   return mi_launch_status();
 }
 
@@ -463,9 +497,9 @@ extern "C" int mi_corner_response(const float *image, int n, int h, int w, int b
   if (aligned && h >= 4 && w >= 8) {
     const int rows = g_corner_rows.load(std::memory_order_relaxed);
     if (block_size == 3 && g_corner_impl.load(std::memory_order_relaxed) == 0) {
-      if (rows == 4) return launch_stream<3, 4>(image, n, h, w, score, s);
-      if (rows == 5) return launch_stream<3, 5>(image, n, h, w, score, s);
-      return launch_stream<3, 8>(image, n, h, w, score, s);
+      if (rows == 4) return launch_stream<3, 4, float>(image, n, h, w, score, s);
+      if (rows == 5) return launch_stream<3, 5, float>(image, n, h, w, score, s);
+      return launch_stream<3, 8, float>(image, n, h, w, score, s);
     }
     if (block_size == 3) return launch_tile<3, 8>(image, n, h, w, score, s);
     if (block_size == 5) return launch_tile<5, 8>(image, n, h, w, score, s);
@@ -474,7 +508,32 @@ extern "C" int mi_corner_response(const float *image, int n, int h, int w, int b
   const size_t total = (size_t)n * h * w;
   const size_t blocks = (total + 255) / 256;
   if (blocks > 0x7fffffffULL) return MI_E_SHAPE;
-  hipLaunchKernelGGL(corner_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, s, image, score, n, h,
+  hipLaunchKernelGGL(corner_generic_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, image, score, n, h,
                      w, block_size);
+  return mi_launch_status();
+}
+
+// u8 ingest (the camera-frame path of sample/visual_odometry.py:65-92 without the host-side
+// uint8 -> float32 conversion): the same score map from uint8 pixels, 1 + 4 instead of 4 + 4 bytes per pixel.
+extern "C" int mi_corner_response_u8(const uint8_t *image, int n, int h, int w, int block_size, float *score,
+                                     mi_stream_t stream) {
+  MI_ENTER();
+  if (!image || !score) return MI_E_NULL;
+  if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
+  if (block_size <= 0 || (block_size & 1) == 0) return MI_E_PARAM;
+  hipStream_t s = (hipStream_t)stream;
+  // 4-pixel DMA pieces: rows must start on a dword (w % 4 == 0, base 4-byte aligned); score rows are written as float4
+  const bool aligned = (w % 4 == 0) && ((uintptr_t)image % 4 == 0) && ((uintptr_t)score % 16 == 0);
+  if (aligned && h >= 4 && w >= 8 && block_size == 3) {
+    const int rows = g_corner_rows.load(std::memory_order_relaxed);
+    if (rows == 8) return launch_stream<3, 8, uint8_t>(image, n, h, w, score, s);
+    if (rows == 5) return launch_stream<3, 5, uint8_t>(image, n, h, w, score, s);
+    return launch_stream<3, 4, uint8_t>(image, n, h, w, score, s);
+  }
+  const size_t total = (size_t)n * h * w;
+  const size_t blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffffULL) return MI_E_SHAPE;
+  hipLaunchKernelGGL(corner_generic_kernel<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, s, image, score, n, h, w,
+                     block_size);
   return mi_launch_status();
 }

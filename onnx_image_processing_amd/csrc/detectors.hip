@@ -167,3 +167,30 @@ extern "C" int mi_dog_responses(const float *image, int n, int h, int w, const f
                      num_scales, kernel_size, out, score, tiles_x, tiles_y);
   return mi_launch_status();
 }
+
+// ---- u8 ingest for the entry points without a uint8 form: uint8 -> float32, the conversion the reference's
+// hosts do on the CPU before calling the model (sample/visual_odometry.py:65-92, sample/image_matching.py:42-46)
+namespace {
+__global__ __launch_bounds__(256) void convert_u8_f32_kernel(const uint8_t *__restrict__ src, float *__restrict__ dst,
+                                                             size_t count) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 4 <= count && ((uintptr_t)src % 4) == 0) {
+    const uint32_t v = *reinterpret_cast<const uint32_t *>(src + i);
+    dst[i] = (float)(v & 0xFFu); dst[i + 1] = (float)((v >> 8) & 0xFFu);
+    dst[i + 2] = (float)((v >> 16) & 0xFFu); dst[i + 3] = (float)(v >> 24);
+  } else {
+    for (size_t j = i; j < count && j < i + 4; ++j) dst[j] = (float)src[j];
+  }
+}
+}  // namespace
+
+extern "C" int mi_convert_u8_f32(const uint8_t *src, long long count, float *dst, mi_stream_t stream) {
+  MI_ENTER();
+  if (!src || !dst) return MI_E_NULL;
+  if (count <= 0) return MI_E_SHAPE;
+  const size_t blocks = ((size_t)count + 1023) / 1024;
+  if (blocks > 0x7fffffffULL) return MI_E_SHAPE;
+  hipLaunchKernelGGL(convert_u8_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     (size_t)count);
+  return mi_launch_status();
+}

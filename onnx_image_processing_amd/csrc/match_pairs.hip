@@ -88,11 +88,25 @@ extern "C" size_t mi_match_pairs_workspace_bytes(int batch, int h, int w, const 
   return L.total;
 }
 
-extern "C" int mi_match_pairs(const float *image1, const float *image2, int batch, int h, int w,
+namespace {
+int corner_of(const float *im, int n, int h, int w, int bs, float *score, mi_stream_t s) { return mi_corner_response(im, n, h, w, bs, score, s); }
+int corner_of(const uint8_t *im, int n, int h, int w, int bs, float *score, mi_stream_t s) { return mi_corner_response_u8(im, n, h, w, bs, score, s); }
+int bad_bits_of(const float *im, int n, int h, int w, const float *kp, int k, const mi_match_params *p, uint32_t *bits,
+                uint8_t *status, mi_stream_t s) {
+  return mi_sparse_bad(im, n, h, w, kp, k, p->pair_geom, p->pair_thr, p->num_pairs, MI_BAD_HARD, 0.0f,
+                       p->normalize_descriptors, nullptr, bits, p->bad_plan, p->bad_plan ? status : nullptr, s);
+}
+int bad_bits_of(const uint8_t *im, int n, int h, int w, const float *kp, int k, const mi_match_params *p, uint32_t *bits,
+                uint8_t *status, mi_stream_t s) {
+  return mi_sparse_bad_u8(im, n, h, w, kp, k, p->pair_geom, p->pair_thr, p->num_pairs, MI_BAD_HARD, 0.0f,
+                          p->normalize_descriptors, nullptr, bits, p->bad_plan, p->bad_plan ? status : nullptr, s);
+}
+
+template <typename PIX>
+int match_pairs_impl(const PIX *image1, const PIX *image2, int batch, int h, int w,
                               const mi_match_params *params, float *keypoints1, float *keypoints2,
                               float *matched1, float *matched2, float *match_scores, uint8_t *match_valid,
                               int32_t *match_ij, void *workspace, size_t workspace_bytes, mi_stream_t stream) {
-  MI_ENTER();
   if (!image1 || !image2 || !keypoints1 || !keypoints2 || !matched1 || !matched2 || !match_scores || !match_valid ||
       !workspace)
     return MI_E_NULL;
@@ -106,12 +120,12 @@ extern "C" int mi_match_pairs(const float *image1, const float *image2, int batc
   if ((e = lay_out(workspace, batch, h, w, k, pbits, &L)) != MI_OK) return e;
   if (workspace_bytes < L.total) return MI_E_CAPACITY;
 
-  const float *images[2] = {image1, image2};
+  const PIX *images[2] = {image1, image2};
   float *kpts[2] = {keypoints1, keypoints2};
   uint32_t *bits[2] = {L.bits1, L.bits2};
   for (int side = 0; side < 2; ++side) {
     // detector/shi_tomasi.py:66-112, utils/keypoint_utils.py:12-117 (mask never materialised)
-    if ((e = mi_corner_response(images[side], batch, h, w, params->block_size, L.score, stream)) != MI_OK) return e;
+    if ((e = corner_of(images[side], batch, h, w, params->block_size, L.score, stream)) != MI_OK) return e;
     if ((e = mi_nms_candidates(L.score, batch, h, w, params->nms_radius, params->score_threshold, params->border_margin,
                                L.cand, L.count, stream)) != MI_OK)
       return e;
@@ -119,10 +133,7 @@ extern "C" int mi_match_pairs(const float *image1, const float *image2, int batc
         MI_OK)
       return e;
     // descriptor/bad.py:436-576, hard bits, packed
-    if ((e = mi_sparse_bad(images[side], batch, h, w, kpts[side], k, params->pair_geom, params->pair_thr, pbits,
-                           MI_BAD_HARD, 0.0f, params->normalize_descriptors, nullptr, bits[side], params->bad_plan,
-                           params->bad_plan ? L.status : nullptr, stream)) != MI_OK)
-      return e;
+    if ((e = bad_bits_of(images[side], batch, h, w, kpts[side], k, params, bits[side], L.status, stream)) != MI_OK) return e;
   }
   // matching/sinkhorn.py:79-208 in the packed (uint16 dot product) form; P is never written
   if ((e = mi_cost_dots_bits(L.bits1, L.bits2, batch, k, k, pbits, params->normalize_descriptors, L.dots, L.pitch,
@@ -137,4 +148,25 @@ extern "C" int mi_match_pairs(const float *image1, const float *image2, int batc
   return mi_mnn_from_duals_dots(L.dots, L.row_info, L.col_info, batch, k, k, L.pitch, params->epsilon, L.u, L.v,
                                 keypoints1, keypoints2, params->max_matches, params->match_threshold, L.mnn_ws,
                                 L.mnn_bytes, matched1, matched2, match_scores, match_valid, match_ij, stream);
+}
+}  // namespace
+
+extern "C" int mi_match_pairs(const float *image1, const float *image2, int batch, int h, int w,
+                              const mi_match_params *params, float *keypoints1, float *keypoints2,
+                              float *matched1, float *matched2, float *match_scores, uint8_t *match_valid,
+                              int32_t *match_ij, void *workspace, size_t workspace_bytes, mi_stream_t stream) {
+  MI_ENTER();
+  return match_pairs_impl<float>(image1, image2, batch, h, w, params, keypoints1, keypoints2, matched1, matched2,
+                                 match_scores, match_valid, match_ij, workspace, workspace_bytes, stream);
+}
+
+// u8 ingest: the same call on uint8 frames (same workspace size; results identical to the float32 call on the
+// converted frames)
+extern "C" int mi_match_pairs_u8(const uint8_t *image1, const uint8_t *image2, int batch, int h, int w,
+                                 const mi_match_params *params, float *keypoints1, float *keypoints2,
+                                 float *matched1, float *matched2, float *match_scores, uint8_t *match_valid,
+                                 int32_t *match_ij, void *workspace, size_t workspace_bytes, mi_stream_t stream) {
+  MI_ENTER();
+  return match_pairs_impl<uint8_t>(image1, image2, batch, h, w, params, keypoints1, keypoints2, matched1, matched2,
+                                   match_scores, match_valid, match_ij, workspace, workspace_bytes, stream);
 }

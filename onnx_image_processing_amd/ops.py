@@ -13,18 +13,39 @@ from . import _native as N
 F32 = torch.float32
 
 
-def _images(image: torch.Tensor, what: str) -> torch.Tensor:
+U8 = torch.uint8
+
+
+def convert_u8(image: torch.Tensor) -> torch.Tensor:
+    """uint8 device tensor -> float32 of the same shape (`mi_convert_u8_f32`): what the reference's hosts do on the CPU
+    before calling the model (sample/visual_odometry.py:65-92)."""
+    src = image.contiguous()
+    out = torch.empty(src.shape, dtype=F32, device=src.device)
+    if src.numel():
+        N.call("mi_convert_u8_f32", N.dev(src, U8, "image"), src.numel(), out.data_ptr(), N.stream_ptr())
+    return out
+
+
+def _images(image: torch.Tensor, what: str, keep_u8: bool = False) -> torch.Tensor:
+    """(N,1,H,W) image batch as a contiguous float32 tensor.  uint8 frames (the u8 ingest path): kept as they are for
+    the entry points that have a uint8 form (keep_u8), converted on the device for the others."""
     if image.dim() != 4 or image.shape[1] != 1:
         raise RuntimeError(f"{what} must have shape (N, 1, H, W), got {tuple(image.shape)}")
+    if image.dtype == U8:
+        return image.contiguous() if keep_u8 else convert_u8(image)
     return image.float().contiguous()
 
 
 def corner_response(image: torch.Tensor, block_size: int) -> torch.Tensor:
-    img = _images(image, "image")
+    img = _images(image, "image", keep_u8=True)
     n, _, h, w = img.shape
-    out = torch.empty_like(img)
-    N.call("mi_corner_response", N.dev(img, F32, "image"), n, h, w, int(block_size), N.dev(out, F32, "score"),
-           N.stream_ptr())
+    out = torch.empty(img.shape, dtype=F32, device=img.device)
+    if img.dtype == U8:
+        N.call("mi_corner_response_u8", N.dev(img, U8, "image"), n, h, w, int(block_size), N.dev(out, F32, "score"),
+               N.stream_ptr())
+    else:
+        N.call("mi_corner_response", N.dev(img, F32, "image"), n, h, w, int(block_size), N.dev(out, F32, "score"),
+               N.stream_ptr())
     return out
 
 
@@ -103,7 +124,7 @@ def bad_plan(pair_geom: torch.Tensor, pair_thr: torch.Tensor) -> torch.Tensor:
 def sparse_bad(image: torch.Tensor, keypoints: torch.Tensor, pair_geom: torch.Tensor, pair_thr: torch.Tensor,
                mode: int, temperature: float, normalize: bool, want_desc: bool = True, want_bits: bool = False,
                plan: torch.Tensor | None = None):
-    img = _images(image, "image")
+    img = _images(image, "image", keep_u8=True)
     n, _, h, w = img.shape
     if keypoints.dim() != 3 or keypoints.shape[0] != n or keypoints.shape[2] != 2:
         raise RuntimeError(f"keypoints must have shape ({n}, K, 2), got {tuple(keypoints.shape)}")
@@ -112,7 +133,9 @@ def sparse_bad(image: torch.Tensor, keypoints: torch.Tensor, pair_geom: torch.Te
     p = pair_geom.numel()
     desc = torch.empty((n, k, p), dtype=F32, device=img.device) if want_desc else None
     bits = torch.empty((n, k, p // 32), dtype=torch.int32, device=img.device) if want_bits else None
-    N.call("mi_sparse_bad", N.dev(img, F32, "image"), n, h, w, N.dev(kp, F32, "keypoints"), k,
+    u8 = img.dtype == U8
+    N.call("mi_sparse_bad_u8" if u8 else "mi_sparse_bad", N.dev(img, U8 if u8 else F32, "image"), n, h, w,
+           N.dev(kp, F32, "keypoints"), k,
            N.dev(pair_geom, torch.int32, "pair_geom"), N.dev(pair_thr, F32, "pair_thr"), p, int(mode),
            float(temperature), int(bool(normalize)), desc.data_ptr() if want_desc else None,
            bits.data_ptr() if want_bits else None, plan.data_ptr() if plan is not None else None,
@@ -510,7 +533,8 @@ def match_pairs(image1: torch.Tensor, image2: torch.Tensor, *, block_size: int, 
     """The whole path in ONE C-ABI call (`mi_match_pairs`): what MatchExtractionWrapper(ShiTomasiSparseBADSinkhornMatcher)
     computes for hard-binarised descriptors and the L2 cost, bit-identical to the module path.
     -> (keypoints1, keypoints2, matched1, matched2, scores, valid[, match_ij])."""
-    a, b2 = _images(image1, "image1"), _images(image2, "image2")
+    u8 = image1.dtype == U8 and image2.dtype == U8           # both uint8: the u8 ingest form; otherwise float32
+    a, b2 = _images(image1, "image1", keep_u8=u8), _images(image2, "image2", keep_u8=u8)
     if a.shape != b2.shape:
         raise RuntimeError(f"image shapes differ: {tuple(a.shape)} vs {tuple(b2.shape)}")
     n, _, h, w = a.shape
@@ -532,7 +556,8 @@ def match_pairs(image1: torch.Tensor, image2: torch.Tensor, *, block_size: int, 
     sc = torch.empty((n, mx), dtype=F32, device=dev)
     valid = torch.empty((n, mx), dtype=torch.bool, device=dev)
     ij = torch.empty((n, mx, 2), dtype=torch.int32, device=dev) if want_ij else None
-    N.call("mi_match_pairs", N.dev(a, F32, "image1"), N.dev(b2, F32, "image2"), n, h, w, ctypes.byref(prm), kp1.data_ptr(),
+    N.call("mi_match_pairs_u8" if u8 else "mi_match_pairs", N.dev(a, U8 if u8 else F32, "image1"),
+           N.dev(b2, U8 if u8 else F32, "image2"), n, h, w, ctypes.byref(prm), kp1.data_ptr(),
            kp2.data_ptr(), mk1.data_ptr(), mk2.data_ptr(), sc.data_ptr(), valid.data_ptr(),
            ij.data_ptr() if ij is not None else None, work.data_ptr(), wbytes, N.stream_ptr())
     out = (kp1, kp2, mk1, mk2, sc, valid)

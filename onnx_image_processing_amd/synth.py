@@ -83,3 +83,20 @@ def synth_batch(
         a[i, 0] = p
         b[i, 0] = q
     return a, b
+
+
+def synth_batch_u8(
+    first_seed: int,
+    num_pairs: int,
+    height: int = 480,
+    width: int = 640,
+    shift: tuple[int, int] = (3, 5),
+    noise: int = 0,
+) -> tuple[np.ndarray, np.ndarray]:
+    """uint8 (B,1,H,W) x2: the same frames as synth_batch before the float32 conversion (what a camera delivers;
+    the u8 ingest path takes them as they are)."""
+    a = np.empty((num_pairs, 1, height, width), np.uint8)
+    b = np.empty((num_pairs, 1, height, width), np.uint8)
+    for i in range(num_pairs):
+        a[i, 0], b[i, 0] = synth_pair(first_seed + i, height, width, shift, noise)
+    return a, b

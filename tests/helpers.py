@@ -83,4 +83,9 @@ ALLOW = _Allow({
     # oracle vs recorded reference output (tests/test_oracle_golden.py): measured 0 everywhere
     "angle_hard_desc1": 0, "angle_hard_desc2": 0, "akaze_hard_u8": 0, "bilinear_int": 0, "bilinear_frac": 0,
     "bilinear_ori": 0, "dense_oriented_hard": 0,
+    # HIP path vs oracle / vs recorded reference output (tests/test_gpu_parity.py), measured on MI355X in round 2
+    # (gpurun_out/r2_test1.log): 0 everywhere
+    "gpu_oriented_vs_oracle": 0, "gpu_angle_detector_vs_reference": 0, "gpu_dense_oriented_vs_reference": 0,
+    "gpu_bilinear_int_vs_oracle": 0, "gpu_bilinear_int_vs_reference": 0, "gpu_bilinear_frac_vs_oracle": 0,
+    "gpu_bilinear_frac_vs_reference": 0, "gpu_bilinear_ori_vs_oracle": 0, "gpu_bilinear_ori_vs_reference": 0,
 })
