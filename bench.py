@@ -4,18 +4,27 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs-per-gpu B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the whole path (Shi-Tomasi -> NMS/top-k -> sparse BAD -> cost ->
-Sinkhorn -> mutual-NN match extraction; the reference's MatchExtractionWrapper form) over a batch of B synthetic pairs per GPU that is
-already resident in HBM, followed (N > 1) by the RCCL gather of the match records to rank 0.
-Configuration = BASELINE.json configs[1] hyper-parameters (the export-CLI values, SURVEY.md
-§2.2) with K=512; pairs are independent, so ranks hold different pairs (weak scaling).
-Prints ONE JSON line on rank 0.
+One "step" = one pass of the whole path (Shi-Tomasi -> NMS/top-k -> sparse BAD -> cost -> Sinkhorn -> mutual-NN match
+extraction; the reference's MatchExtractionWrapper form) over a batch of B synthetic pairs per GPU that is already
+resident in HBM as float32 (the reference's input type), followed (N > 1) by the RCCL gather of the match records to
+rank 0.  Configuration = BASELINE.json configs[1] hyper-parameters (the export-CLI values) with
+K=512; pairs are independent, so ranks hold different pairs (weak scaling).  Prints ONE JSON line on rank 0.
+
+Beside `value` the line carries (N = 1 only, all measured after the timed region, none of them part of `value`):
+  roofline      K1 corner response (the stencil north_star sets the 60 % target on), float32 input, 8 B/px
+  u8_ingest     the same workload on uint8 frames resident in HBM (5 B/px K1), with its own roofline object
+  streamed      uint8 frames in pinned host memory, H2D on a copy stream double-buffered against compute
+  latency       one pair per call and eight pairs per call (the reference harness's pattern,
+                sample/image_matching.py:313-328): eager and hipGraph replay, submit -> results on the device
+  cpu_baseline  the reference CPU path (oracle/torch_cpu.py, pinned to the reference's recorded outputs) on this
+                box's host cores with the reference harness's 5 + 10 protocol, plus the live match-set parity
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -32,60 +41,133 @@ CFG = dict(block_size=3, num_pairs=NUM_PAIRS, binarize=True, soft_binarize=False
            normalize_descriptors=True, sampling_mode="nearest")
 MNN = dict(max_matches=100, threshold=0.1)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA peak (MI355X_MICROARCH.md; the 2:1-sparsity headline is not used)
+
+
+# ----------------------------------------------------------------------------------------------- timing plumbing
+class StepClock:
+    """Per-step timestamps on the launch stream: HIP events on a GPU, perf_counter on the CPU (the gloo dry run of the
+    N > 1 control flow in tests/test_distributed_gloo.py)."""
+
+    def __init__(self, steps: int, cuda: bool):
+        self.cuda = cuda
+        self.marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if cuda else []
+        self.stamps: list[float] = []
+
+    def mark(self, i: int) -> None:
+        if self.cuda:
+            self.marks[i].record()
+        else:
+            self.stamps.append(time.perf_counter())
+
+    def per_step_ms(self) -> list[float]:
+        if self.cuda:
+            return [a.elapsed_time(b) for a, b in zip(self.marks, self.marks[1:])]
+        return [(b - a) * 1e3 for a, b in zip(self.stamps, self.stamps[1:])]
+
+
+def run_timed(step, steps: int, warmup: int, world: int, device, sync) -> tuple[float, list[float], object]:
+    """The contract's timed region: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by a barrier + device
+    synchronisation on both sides; returns (elapsed ms, MAX over ranks; per-step ms of this rank; last step's output).
+    `step()` returns what rank 0 needs (the gathered records); `sync()` is torch.cuda.synchronize on a GPU."""
+    from onnx_image_processing_amd import distributed as D
+    out = None
+    for _ in range(warmup):
+        out = step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    clock = StepClock(steps, torch.device(device).type == "cuda")
+    t0 = time.perf_counter()
+    clock.mark(0)
+    for i in range(steps):
+        out = step()
+        clock.mark(i + 1)
+    sync()
+    if world > 1:
+        dist.barrier()
+    elapsed_ms = (time.perf_counter() - t0) * 1e3
+    return D.barrier_max_ms(elapsed_ms, device), clock.per_step_ms(), out
+
+
+def step_stats(per_step_ms: list[float]) -> dict:
+    return {"min": min(per_step_ms), "median": statistics.median(per_step_ms), "max": max(per_step_ms),
+            "mean": statistics.fmean(per_step_ms)}
 
 
 def pmc_traffic(kernel_prefix: str, pairs_per_gpu: int):
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
-    (profiles/*_bench_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
-    script at the recorded pairs per GPU, reads doubled per the gfx950 note).  None when no profile of this batch
-    size exists."""
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*_bench_pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this script at the recorded pairs per GPU, reads
+    doubled per the gfx950 note).  None when no profile of this batch size exists."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_pmc_traffic.json")))
-    if not files:
-        return None, None
-    try:
-        prof = json.load(open(files[-1]))
-        if int(prof.get("pairs_per_gpu", 256)) != pairs_per_gpu:
-            return None, None
-        kernels = prof["kernels"]
-        for name, row in kernels.items():
-            if name.startswith(kernel_prefix):
-                return row["total_MB"] * 1e6, os.path.relpath(files[-1], ROOT)
-    except Exception:
-        pass
+    for path in reversed(files):
+        try:
+            prof = json.load(open(path))
+            if int(prof.get("pairs_per_gpu", 256)) != pairs_per_gpu:
+                continue
+            for name, row in prof["kernels"].items():
+                if name.startswith(kernel_prefix):
+                    return row["total_MB"] * 1e6, os.path.relpath(path, ROOT)
+        except Exception:
+            continue
     return None, None
 
 
-def cpu_baseline(pairs: int, gpu_records=None) -> dict:
-    """The oracle (numpy port of the reference algorithm) on this host's cores, same workload.  gpu_records: the
-    (pairs, max_matches, 6) match records the GPU path produced for the same pairs (rank 0's first `pairs` pairs);
-    when given, the oracle's outputs are compared with them after the clock stops ("parity")."""
-    from oracle import numpy_oracle as O
+def k1_roofline(ms_per_launch: float, bytes_per_px: float, images: int, kernel: str, prefix: str, pairs: int) -> dict:
+    nbytes = bytes_per_px * images * H * W
+    achieved = nbytes / (ms_per_launch * 1e-3) / 1e9
+    traffic, src = pmc_traffic(prefix, pairs)
+    return {"kernel": kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "bytes_per_launch": nbytes,
+            "bytes_per_pixel": bytes_per_px, "ms_per_launch": ms_per_launch}
+
+
+# ----------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(parity_pairs: int, gpu_records=None) -> dict:
+    """The reference CPU path on this host's cores: oracle/torch_cpu.py -- the same ATen CPU
+    kernels in the reference's order, pinned to the reference's recorded outputs by tests/test_oracle_golden.py -- with
+    the reference harness's protocol (5 warm-up + 10 timed calls, mean; sample/image_matching.py:313-328) for one pair
+    per call, for a batch of 8 pairs per call, and for one pair with one thread.  `value` is the best of the
+    multi-thread figures.  gpu_records: the (pairs, max_matches, 6) match records the GPU path produced for the same
+    pairs; the numpy oracle's match sets for the first `parity_pairs` of them are compared after the clocks stop."""
     from onnx_image_processing_amd.synth import synth_batch
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+    from oracle import numpy_oracle as O
+    from oracle.torch_cpu import TorchCpuPath, time_protocol
     t = np.load(os.path.join(ROOT, "onnx_image_processing_amd", "data", "bad_tables.npz"))
-    kw = {k: v for k, v in CFG.items() if k not in ("num_pairs", "sampling_mode")}
-    a, b = synth_batch(1000, pairs, H, W)
-    O.match_pair(a[:1], b[:1], t["box_512"], t["thr_512"], K, **kw)          # warm-up
-    results = []
-    t0 = time.perf_counter()
-    for i in range(pairs):
-        k1, k2, p = O.match_pair(a[i:i + 1], b[i:i + 1], t["box_512"], t["thr_512"], K, **kw)
-        results.append(O.mnn_extract(p, k1, k2, **MNN))
-    dt = time.perf_counter() - t0
-    out = {"value": pairs / dt, "unit": "image-pairs/sec", "cores": int(threads), "kind": "port",
-           "sample": f"{pairs} pairs 640x480 K=512 (seeds 1000..{999 + pairs}), oracle/numpy_oracle.py, one pair "
-                     f"at a time; BLAS matmul uses {threads} threads, the rest is single-threaded numpy"}
-    if gpu_records is not None:
-        # match-set parity of the very pairs just timed: same matched coordinates, same validity, scores within 1e-4
-        # A pair with more than max_matches mutual matches keeps the max_matches best: two scores closer than the 1e-4
-        # bound that straddle that cut may legitimately swap ("cut ties"); anything else is a real difference.
+    kw = {k: v for k, v in CFG.items() if k not in ("num_pairs", "sampling_mode", "distance_type")}
+    path = TorchCpuPath(t["box_512"], t["thr_512"], K, **kw)
+    a, b = synth_batch(1000, max(8, parity_pairs), H, W)
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    threads = torch.get_num_threads()
+    one = time_protocol(lambda: path.match(ta[:1], tb[:1], **MNN))
+    batched = time_protocol(lambda: path.match(ta[:8], tb[:8], **MNN), warmup=2, timed=5)
+    torch.set_num_threads(1)
+    single = time_protocol(lambda: path.match(ta[:1], tb[:1], **MNN), warmup=1, timed=3)
+    torch.set_num_threads(threads)
+    try:
+        model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    best = max(1.0 / one, 8.0 / batched)
+    out = {"value": best, "unit": "image-pairs/sec", "cores": int(threads), "kind": "port",
+           "sample": f"oracle/torch_cpu.py (torch-CPU restatement of the reference path, pinned to the reference's recorded "
+                     f"outputs), 640x480 K=512 pairs seeds 1000.., protocol of sample/image_matching.py:313-328: one pair per "
+                     f"call 5+10 runs, 8 pairs per call 2+5 runs, one pair on 1 thread 1+3 runs",
+           "one_pair_per_call": {"ms_per_call": one * 1e3, "pairs_per_sec": 1.0 / one, "threads": int(threads)},
+           "eight_pairs_per_call": {"ms_per_call": batched * 1e3, "pairs_per_sec": 8.0 / batched, "threads": int(threads)},
+           "one_thread": {"ms_per_call": single * 1e3, "pairs_per_sec": 1.0 / single, "threads": 1},
+           "host": {"cpu": model, "logical_cpus": os.cpu_count(), "torch": torch.__version__}}
+    if gpu_records is not None and parity_pairs > 0:
+        # match-set parity of the GPU's own output for these very pairs: same matched coordinates, same validity, scores
+        # within 1e-4.  A pair with more than max_matches mutual matches keeps the max_matches best: two scores closer than
+        # the 1e-4 bound that straddle that cut may legitimately swap ("cut ties"); anything else is a real difference.
+        okw = {k: v for k, v in CFG.items() if k not in ("num_pairs", "sampling_mode")}
         same, cut, other, worst, nmatch = 0, 0, 0, 0.0, 0
-        for i, (mk1, mk2, sc, valid, _) in enumerate(results):
+        for i in range(parity_pairs):
+            k1, k2, p = O.match_pair(a[i:i + 1], b[i:i + 1], t["box_512"], t["thr_512"], K, **okw)
+            mk1, mk2, sc, valid, _ = O.mnn_extract(p, k1, k2, **MNN)
             g = gpu_records[i]
             gv = g[:, 5] > 0.5
             want = {(*mk1[0, j], *mk2[0, j]): float(sc[0, j]) for j in np.nonzero(valid[0])[0]}
@@ -102,15 +184,114 @@ def cpu_baseline(pairs: int, gpu_records=None) -> dict:
                 cut += 1
             else:
                 other += 1
-        out["parity"] = {"pairs_checked": pairs, "pairs_with_identical_match_set": same,
+        out["parity"] = {"checker": "oracle/numpy_oracle.py", "pairs_checked": parity_pairs,
+                         "pairs_with_identical_match_set": same,
                          "pairs_differing_only_by_ties_at_the_max_matches_cut": cut, "pairs_differing_otherwise": other,
                          "matches_checked": nmatch, "max_abs_score_diff": worst, "bound": 1e-4}
     return out
 
 
+# ----------------------------------------------------------------------------------------------- N = 1 extras
+def measure_latency(model, img1, img2, iters: int = 200) -> dict:
+    """One call = submit -> results complete on the device (synchronise after every call), the reference harness's
+    pattern.  Eager = the module path (about 20 C-ABI calls); graph = the same forward replayed as one hipGraph."""
+    from onnx_image_processing_amd.graph import GraphedModule
+    out = {}
+    for b in (1, 8):
+        a1, b1 = img1[:b].contiguous(), img2[:b].contiguous()
+        for _ in range(10):
+            model(a1, b1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            model(a1, b1)
+            torch.cuda.synchronize()
+        eager = (time.perf_counter() - t0) / iters * 1e3
+        graphed = GraphedModule(model, a1, b1)
+        for _ in range(10):
+            graphed.graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            graphed.graph.replay()
+            torch.cuda.synchronize()
+        graph = (time.perf_counter() - t0) / iters * 1e3
+        out[f"pairs_per_call_{b}"] = {"eager_ms": eager, "graph_ms": graph, "eager_pairs_per_sec": b / (eager * 1e-3),
+                                      "graph_pairs_per_sec": b / (graph * 1e-3)}
+    out["what"] = ("MatchExtractionWrapper(ShiTomasiSparseBADSinkhornMatcher) forward, float32 frames resident in HBM, "
+                   f"host synchronised after every call, mean of {iters} calls")
+    return out
+
+
+def measure_u8_and_streamed(model, a8: np.ndarray, b8: np.ndarray, steps: int) -> tuple[dict, dict]:
+    """(u8_ingest, streamed): the default workload on uint8 frames -- resident in HBM, and streamed from pinned host
+    buffers (two slots; the copy of step i+1 runs on a copy stream while step i computes)."""
+    from onnx_image_processing_amd import _native, distributed as D
+    dev = torch.device("cuda", torch.cuda.current_device())
+    B = a8.shape[0]
+    host = torch.from_numpy(np.stack([a8, b8])).pin_memory()                   # (2, B, 1, H, W) uint8
+    slots = [torch.empty_like(host, device=dev) for _ in range(2)]
+    slots[0].copy_(host)
+    slots[1].copy_(host)
+    torch.cuda.synchronize()
+
+    def step(s):
+        return D.pack_records(*model(slots[s][0], slots[s][1]))
+
+    for _ in range(3):
+        step(0)
+    torch.cuda.synchronize()
+    _native.enable_timing(True, only={"mi_corner_response_u8"})
+    t0 = time.perf_counter()
+    for i in range(steps):
+        rec = step(i & 1)
+    torch.cuda.synchronize()
+    resident_ms = (time.perf_counter() - t0) * 1e3 / steps
+    k1 = _native.timings_ms()["mi_corner_response_u8"]
+    _native.enable_timing(False)
+    u8 = {"value": B / (resident_ms * 1e-3), "unit": "image-pairs/sec", "ms_per_step": resident_ms, "steps": steps,
+          "what": "the default workload on uint8 frames resident in HBM (mi_corner_response_u8 / mi_sparse_bad_u8)",
+          "mean_valid_matches_per_pair": float(rec[..., 5].sum().item()) / B,
+          "roofline": k1_roofline(float(np.mean(k1)), 5.0, B, "corner_stream_kernel<3,4,uint8> (mi_corner_response_u8)",
+                                  "corner_stream_kernel<3, 4, true>", B)}
+
+    main = torch.cuda.current_stream()
+    copier = torch.cuda.Stream()
+    copied = [torch.cuda.Event() for _ in range(2)]
+    done = [torch.cuda.Event() for _ in range(2)]
+
+    def streamed_loop(n):
+        for i in range(n):
+            s = i & 1
+            with torch.cuda.stream(copier):
+                if i >= 2:
+                    copier.wait_event(done[s])                                  # the step that last used this slot is finished
+                slots[s].copy_(host, non_blocking=True)
+                copied[s].record(copier)
+            main.wait_event(copied[s])
+            rec = step(s)
+            done[s].record(main)
+        return rec
+
+    streamed_loop(4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rec = streamed_loop(steps)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    nbytes = host.numel()
+    streamed = {"value": B / (ms * 1e-3), "unit": "image-pairs/sec", "ms_per_step": ms, "steps": steps,
+                "h2d_bytes_per_step": nbytes, "pcie_GBps_achieved": nbytes / (ms * 1e-3) / 1e9,
+                "what": "uint8 frames in pinned host memory, H2D inside the timed region on a copy stream, double-buffered "
+                        "against compute (two device slots); 0.61 MB per pair instead of 2.46 MB for float32 frames",
+                "mean_valid_matches_per_pair": float(rec[..., 5].sum().item()) / B}
+    return u8, streamed
+
+
+# ----------------------------------------------------------------------------------------------- configs[2] / [3]
 def side_workload(args, rank, world, dev) -> None:
-    """BASELINE configs[2]/[3] through the same modules: an informational JSON line (value and per-call
-    times only), not the bench contract's line."""
+    """BASELINE configs[2]/[3] through the same modules: value, per-call times and the roofline of the dominant
+    bandwidth-type kernel; no cpu_baseline (the metric's configuration is the default line)."""
     from onnx_image_processing_amd import _native, distributed as D
     from onnx_image_processing_amd.pytorch_model.feature_detection import (AKAZESparseBADSinkhornMatcher,
                                                                            MatchExtractionWrapper,
@@ -121,15 +302,18 @@ def side_workload(args, rank, world, dev) -> None:
         h, w, k = 1080, 1920, 1024
         base = ShiTomasiSparseBADSinkhornMatcher(max_keypoints=k, **CFG)
         what = "Shi-Tomasi sparse pipeline, 1920x1080, K=1024 (BASELINE configs[2])"
+        roof = ("mi_corner_response", "corner_stream_kernel<3,4> (mi_corner_response)", 8.0, 1)
     else:
         h, w, k = H, W, K
-        # export_akaze_sparse_bad_sinkhorn.py defaults (SURVEY.md §2.2): 256 pairs, no binarisation, NMS radius 3
+        # export_akaze_sparse_bad_sinkhorn.py defaults (SURVEY.md section 2.2): 256 pairs, no binarisation, NMS radius 3
         cfg = dict(num_pairs=256, binarize=False, sinkhorn_iterations=20, epsilon=0.05, unused_score=1.0,
                    distance_type="l2", nms_radius=3, score_threshold=0.0, normalize_descriptors=True,
                    sampling_mode="nearest")
         base = AKAZESparseBADSinkhornMatcher(max_keypoints=k, **cfg)
         what = ("AKAZE(3 scales x 3 steps) + oriented sparse BAD(256, raw) + Sinkhorn(20, eps 0.05), 640x480, K=512 "
                 "(BASELINE configs[3], AKAZE export-CLI values)")
+        # one scale per launch: reads the previous scale's image, writes the diffused image and the scale's score map
+        roof = ("mi_akaze_scale", "akaze_scale_kernel (mi_akaze_scale: 3 diffusion steps + Hessian + NMS per launch)", 12.0, 1)
     begin, _ = D.shard_range(B * world, rank, world)
     a, b = synth_batch(1000 + begin, B, h, w)
     img1, img2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
@@ -140,31 +324,33 @@ def side_workload(args, rank, world, dev) -> None:
     def step():
         return D.gather_records(D.pack_records(*model(img1, img2)), dst=0)
 
-    for _ in range(args.warmup):
-        out = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    _native.enable_timing(True, only={roof[0]})
+    elapsed_ms, per_step, out = run_timed(step, args.steps, args.warmup, world, dev, torch.cuda.synchronize)
+    timed = _native.timings_ms().get(roof[0], [])
+    timed = timed[-len(timed) * args.steps // (args.steps + args.warmup):] if timed else timed     # drop the warm-up calls
     _native.enable_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed_ms = D.barrier_max_ms((time.perf_counter() - t0) * 1e3, dev)
+    for _ in range(3):
+        step()
     per_call = _native.timings_ms()
     _native.enable_timing(False)
     if rank == 0:
         ms = elapsed_ms / args.steps
-        print(json.dumps({
+        line = {
             "metric": f"image-pairs/sec ({w}x{h}, K={k})", "value": B * world / (ms * 1e-3), "unit": "image-pairs/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": what, "pairs_per_gpu_per_step": B,
                        "mean_valid_matches_per_pair": float(out[..., 5].sum().item()) / (B * world)},
-            "kernels": {kk: {"ms_per_step": float(np.sum(v)) / args.steps, "calls_per_step": len(v) / args.steps}
-                        for kk, v in per_call.items()}}), flush=True)
+            "step_ms": step_stats(per_step),
+            "kernels": {kk: {"ms_per_step": float(np.sum(v)) / 3, "calls_per_step": len(v) / 3} for kk, v in per_call.items()}}
+        if timed:
+            nbytes = roof[2] * B * h * w * roof[3]
+            t_ms = float(np.mean(timed))
+            line["roofline"] = {"kernel": roof[1], "bound": "hbm", "achieved": nbytes / (t_ms * 1e-3) / 1e9,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "traffic": None, "bytes_per_launch": nbytes, "bytes_per_pixel": roof[2],
+                                "ms_per_launch": t_ms}
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -173,26 +359,27 @@ def side_workload(args, rank, world, dev) -> None:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=500,
+                    help="timed steps (default 500: a timed region of about 1.1 s, so that a 2 %% change is not noise)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pairs-per-gpu", type=int, default=448,
                     help="pairs resident per GPU and processed per step (448: the Sinkhorn row kernel's workgroups of "
                          "each half-batch fill whole rounds of the 256 CUs, and top-k runs two workgroups per CU)")
-    ap.add_argument("--cpu-pairs", type=int, default=192, help="oracle sample size for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=64, help="pairs of the live match-set parity check (0 = skip cpu_baseline)")
+    ap.add_argument("--no-extras", action="store_true", help="skip u8_ingest / streamed / latency (N = 1 extras)")
     ap.add_argument("--single-call", action="store_true",
                     help="run the step as ONE C-ABI call (mi_match_pairs); informational: no per-stage timers, so the "
                          "line carries no roofline object")
     ap.add_argument("--two-step", action="store_true",
                     help="materialise P and run the extractor on it (default: matches straight from the duals)")
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
-                    help="c2 (default, the metric's configuration); c3 = 1080x1920 K=1024; c4 = AKAZE front end "
-                         "(informational lines: no roofline/cpu_baseline)")
+                    help="c2 (default, the metric's configuration); c3 = 1080x1920 K=1024; c4 = AKAZE front end")
     args = ap.parse_args()
 
     from onnx_image_processing_amd import _native, distributed as D
     from onnx_image_processing_amd.pytorch_model.feature_detection import (MatchExtractionWrapper,
                                                                            ShiTomasiSparseBADSinkhornMatcher)
-    from onnx_image_processing_amd.synth import synth_batch
+    from onnx_image_processing_amd.synth import synth_batch_u8
 
     rank, world, local = D.init()
     if world != args.gpus:
@@ -210,11 +397,13 @@ def main() -> None:
 
     B = args.pairs_per_gpu
     if args.workload != "c2":
+        if args.steps == 500:
+            args.steps = 50
         return side_workload(args, rank, world, dev)
     begin, _ = D.shard_range(B * world, rank, world)            # this rank's pairs in the global order
-    a, b = synth_batch(1000 + begin, B, H, W)
-    img1, img2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)   # resident in HBM before timing
-    del a, b
+    a8, b8 = synth_batch_u8(1000 + begin, B, H, W)
+    # float32 [0,255] (B,1,H,W): the reference's input form, resident in HBM before timing
+    img1, img2 = torch.from_numpy(a8).to(dev).float(), torch.from_numpy(b8).to(dev).float()
     # the reference's deployment form of "matcher + match extraction" (match_extraction_wrapper.py:82-113)
     model = MatchExtractionWrapper(ShiTomasiSparseBADSinkhornMatcher(max_keypoints=K, **CFG),
                                    max_matches=MNN["max_matches"], match_threshold=MNN["threshold"]).to(dev)
@@ -224,57 +413,26 @@ def main() -> None:
         rec = D.pack_records(*(model.forward_single_call(img1, img2) if args.single_call else model(img1, img2)))
         return D.gather_records(rec, dst=0)
 
-    for _ in range(args.warmup):
-        out = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # HIP events around the roofline kernel's calls only (two per step) inside the timed region; the per-stage
-    # table below comes from extra steps after it, so its 24 events per step do not sit in the measurement
+    # HIP events around the roofline kernel's calls only (two per step) inside the timed region; the per-stage table
+    # below comes from extra steps after it, so its 24 events per step do not sit in the measurement
     _native.enable_timing(True, only=None if args.single_call else {"mi_corner_response"})
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed_ms = (time.perf_counter() - t0) * 1e3
+    elapsed_ms, per_step, out = run_timed(step, args.steps, args.warmup, world, dev, torch.cuda.synchronize)
     per_call = _native.timings_ms()
     _native.enable_timing(False)
-    elapsed_ms = D.barrier_max_ms(elapsed_ms, dev)
     stage_steps = 3
+    stages = {}
     if not args.single_call:                                     # per-stage times (informational), outside the timed region
         _native.enable_timing(True)
         for _ in range(stage_steps):
             out = step()
         stages = _native.timings_ms()
         _native.enable_timing(False)
-    else:
-        stages = {}
 
     if rank == 0:
         ms_per_step = elapsed_ms / args.steps
         pairs_per_step = B * world
         kernels = {k: {"ms_per_step": float(np.sum(v)) / stage_steps, "calls_per_step": len(v) / stage_steps}
                    for k, v in stages.items()}
-        # K1 corner response: 8 algorithmic bytes per pixel (4 read + 4 written); one launch covers
-        # one image of every pair of this rank, two launches per step
-        k1_bytes = 8.0 * B * H * W
-        if args.single_call:                       # informational line: the step is one C-ABI call, no per-stage events
-            print(json.dumps({"metric": "image-pairs/sec (640x480, K=512)", "value": pairs_per_step / (ms_per_step * 1e-3),
-                              "unit": "image-pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-                              "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                              "config": {"workload": "as the default line, issued as one mi_match_pairs call per step",
-                                         "pairs_per_gpu_per_step": B}, "kernels": kernels}), flush=True)
-            if world > 1:
-                dist.barrier()
-                dist.destroy_process_group()
-            return
-        k1_ms = float(np.mean(per_call["mi_corner_response"]))
-        achieved = k1_bytes / (k1_ms * 1e-3) / 1e9
-        nvalid = float(out[..., 5].sum().item()) / pairs_per_step
-        traffic, traffic_src = pmc_traffic("corner_stream_kernel", B)
         line = {
             "metric": "image-pairs/sec (640x480, K=512)",
             "value": pairs_per_step / (ms_per_step * 1e-3),
@@ -289,28 +447,48 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "Shi-Tomasi(3) + NMS(r=5)/top-k + sparse BAD(512, hard) + Sinkhorn(20, eps 0.05) "
-                                   "+ MNN(100, 0.1), 640x480 gray pairs, K=512 (BASELINE configs[1])",
+                                   "+ MNN(100, 0.1), 640x480 gray pairs, K=512 (BASELINE configs[1])"
+                                   + (", issued as one mi_match_pairs call per step" if args.single_call else ""),
                        "pairs_per_gpu_per_step": B, "global_pairs_per_step": pairs_per_step,
                        "height": H, "width": W, "max_keypoints": K, "parallelism": f"pair-sharded x{world}",
-                       "mean_valid_matches_per_pair": nvalid},
-            "roofline": {"kernel": "corner_stream_kernel<3,4> (mi_corner_response)", "bound": "hbm",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": k1_bytes,
-                         "ms_per_launch": k1_ms},
+                       "input": "float32 frames resident in HBM",
+                       "mean_valid_matches_per_pair": float(out[..., 5].sum().item()) / pairs_per_step},
+            "step_ms": step_stats(per_step),
             "kernels": kernels,
-            # informational: the other bandwidth-type stages by their algorithmic bytes
-            "roofline_other": {
-                "mi_nms_candidates": {"bytes_per_call": 4.0 * B * H * W, "unit": "GB/s",
-                                      "achieved": 4.0 * B * H * W / (float(np.mean(stages["mi_nms_candidates"])) * 1e-3) / 1e9},
-                "mi_sinkhorn_dots (per iteration, 2 B/element)": {
-                    "bytes_per_call": 2.0 * B * K * K * CFG["sinkhorn_iterations"], "unit": "GB/s",
-                    "achieved": 2.0 * B * K * K * CFG["sinkhorn_iterations"]
-                    / (float(np.mean(stages["mi_sinkhorn_dots"])) * 1e-3) / 1e9} if "mi_sinkhorn_dots" in stages else None,
-            },
         }
-        if world == 1 and args.cpu_pairs > 0:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_pairs, out[:args.cpu_pairs].cpu().numpy()
-                                                if args.cpu_pairs <= B else None)
+        if not args.single_call:
+            # K1 corner response: 8 algorithmic bytes per pixel (4 read + 4 written); one launch covers one image of
+            # every pair of this rank, two launches per step
+            k1 = per_call["mi_corner_response"][2 * args.warmup:]
+            line["roofline"] = k1_roofline(float(np.mean(k1)), 8.0, B, "corner_stream_kernel<3,4,float> (mi_corner_response)",
+                                           "corner_stream_kernel<3, 4, false>", B)
+            # informational: the other stages by their algorithmic bytes / operations
+            other = {}
+            if "mi_nms_candidates" in stages:
+                t = float(np.mean(stages["mi_nms_candidates"]))
+                other["mi_nms_candidates"] = {"bytes_per_call": 4.0 * B * H * W, "unit": "GB/s",
+                                              "achieved": 4.0 * B * H * W / (t * 1e-3) / 1e9}
+            if "mi_sinkhorn_dots" in stages:
+                t = float(np.mean(stages["mi_sinkhorn_dots"]))
+                nb = 2.0 * B * K * K * CFG["sinkhorn_iterations"]
+                other["mi_sinkhorn_dots (20 iterations, 2 B/element/iteration)"] = {
+                    "bytes_per_call": nb, "unit": "GB/s", "achieved": nb / (t * 1e-3) / 1e9}
+            if "mi_cost_dots_bits" in stages:
+                t = float(np.mean(stages["mi_cost_dots_bits"]))
+                ops_ = 2.0 * B * K * K * NUM_PAIRS
+                other["mi_cost_dots_bits (int8 MFMA)"] = {
+                    "ops_per_call": ops_, "unit": "Top/s", "achieved": ops_ / (t * 1e-3) / 1e12,
+                    "peak": I8_MFMA_PEAK_TOPS, "frac": ops_ / (t * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
+                    "bytes_written_per_call": 2.0 * B * K * K,
+                    "note": "co-limited by its uint16 store stream; MFMA busy counters in profiles/ (DESIGN.md K5)"}
+            line["roofline_other"] = other
+        if world == 1 and not args.single_call:
+            records = out[:args.cpu_pairs].cpu().numpy() if 0 < args.cpu_pairs <= B else None
+            if not args.no_extras:
+                line["u8_ingest"], line["streamed"] = measure_u8_and_streamed(model, a8, b8, min(args.steps, 100))
+                line["latency"] = measure_latency(model, img1, img2)
+            if args.cpu_pairs > 0:
+                line["cpu_baseline"] = cpu_baseline(min(args.cpu_pairs, B), records)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -472,3 +472,38 @@ def test_akaze_c4_480x640_k512_vs_reference():
     np.testing.assert_allclose(aux["desc1"][:, :64], g["desc1_first64"], rtol=0, atol=1e-5)
     ok, worst = p_close(p, g["P"])
     assert ok, worst
+
+
+# ---------------------------------------------------------------- torch-CPU timing twin (bench.py's cpu_baseline)
+@pytest.mark.parametrize("name", ["c2_pair_480x640_k512", "ragged_120x160_k96"])
+def test_torch_cpu_restatement_matches_the_reference_output(name):
+    """oracle/torch_cpu.py (what bench.py times as "the reference CPU path") reproduces the recorded reference run:
+    keypoints and BAD bits exactly (same ATen kernels, same order), P to 1e-6, same match set."""
+    import torch
+    from oracle.torch_cpu import TorchCpuPath
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    a, b = synth_batch(int(g["seed"]), 1, int(g["h"]), int(g["w"]), noise=int(g["noise"]))
+    if int(g["blank"][0]) >= 0:
+        y0, y1, x0, x1 = [int(v) for v in g["blank"]]
+        b[:, :, y0:y1, x0:x1] = 77.0
+    box, thr = bad_tables(cfg["num_pairs"])
+    kw = {k: v for k, v in cfg.items() if k not in ("num_pairs", "sampling_mode", "distance_type")}
+    path = TorchCpuPath(box, thr, int(g["k"]), **kw)
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    k1, k2, p = path.forward(ta, tb)
+    # torch.topk's tie order is not defined: compare after the same canonicalisation as everywhere else
+    w = int(g["w"])
+    mine = [tie_canonical_perm(k.numpy()[0], path.keypoints(path.scores(im))[1].numpy()[0], w) for k, im in ((k1, ta), (k2, tb))]
+    ref = [tie_canonical_perm(g["kpts" + t][0], g["kscores" + t][0], w) for t in "12"]
+    assert np.array_equal(k1.numpy()[0][mine[0]], g["kpts1"][0][ref[0]]) and np.array_equal(k2.numpy()[0][mine[1]], g["kpts2"][0][ref[1]])
+    for t, im, kp, pm, pr in (("1", ta, k1, mine[0], ref[0]), ("2", tb, k2, mine[1], ref[1])):
+        bits = path.describe(im, kp).numpy()[0] != 0
+        assert np.array_equal(bits[pm], unpack_bits(g["bits" + t][0][pr], cfg["num_pairs"]))
+    pc = permute_p(p.numpy()[0], mine[0], mine[1])
+    pref = permute_p(g["P"][0], ref[0], ref[1]) if "P" in g.files else None
+    if pref is not None:
+        assert np.abs(pc - pref).max() <= 1e-6 * max(1.0, float(np.abs(pref).max()))
+    mk1, mk2, sc, valid = path.mutual_matches(p, k1, k2, **cfg_of(g, "mnn_cfg"))
+    want = {(tuple(x), tuple(y)) for x, y, v in zip(g["mk1"][0], g["mk2"][0], g["mvalid"][0]) if v}
+    assert {(tuple(x), tuple(y)) for x, y, v in zip(mk1[0].numpy(), mk2[0].numpy(), valid[0].numpy()) if v} == want
