@@ -21,6 +21,7 @@
 extern std::atomic<int> mi_g_sinkhorn_log_partials;   // defined in sinkhorn.hip
 extern std::atomic<int> mi_g_sinkhorn_split;          // defined in sinkhorn_dots.hip
 extern std::atomic<int> mi_g_topk_select;             // defined in topk.hip
+extern std::atomic<int> mi_g_sinkhorn_persist;        // defined in sinkhorn_dots.hip
 
 namespace {
 
@@ -482,6 +483,7 @@ extern "C" int mi_debug_set(int key, int value) {
   if (key == 4) { mi_g_sinkhorn_log_partials = value; return MI_OK; }
   if (key == 6) { mi_g_sinkhorn_split = value; return MI_OK; }
   if (key == 9) { mi_g_topk_select = value; return MI_OK; }
+  if (key == 7) { mi_g_sinkhorn_persist = value; return MI_OK; }
   if (key == 2 && (value == 4 || value == 5 || value == 8)) { g_corner_rows = value; return MI_OK; }
   return MI_E_PARAM;
 }

@@ -17,6 +17,9 @@
 
 #include <atomic>
 
+// test hook (mi_debug_set key 7): 1 = batches of <= SKP_MAX_BATCH pairs (n, m <= 512) run the single-launch form
+// (default), 0 = always the multi-launch form.  Same duals bit for bit.
+std::atomic<int> mi_g_sinkhorn_persist{1};
 // test hook (mi_debug_set key 6, include/mi355x_match_debug.h): number of batch parts run on separate
 // streams (1 = one stream).  Whole bench step: 1.88 / 1.82 / 1.92 ms with 1 / 2 / 3 parts of 256 pairs.
 std::atomic<int> mi_g_sinkhorn_split{2};
@@ -371,6 +374,244 @@ __global__ __launch_bounds__(256) void sk_exp_dots_kernel(const uint16_t *__rest
   }
 }
 
+// ---- single-launch form for a few pairs (the one-pair-per-call latency path) ---------------------------------
+// With one pair per call the 41 dependent launches above are all latency: each kernel boundary costs more than
+// the work between two of them (MI355X_MICROARCH.md, "boundary" row).  Here ONE launch runs every iteration: the
+// nb <= 16 band workgroups of a pair keep their 32 rows of dot products in registers for the whole solve, and the
+// bands' column sums cross workgroups as 8-byte {iteration tag, value} granules written write-through (sc1) and
+// polled with sc1 loads -- the data is the flag, no fence, no separate barrier (cdna_hip_programming.md section 6,
+// Guideline 16, form R2).  Every workgroup gathers all bands' granules of a column and recomputes the column
+// update v_j (and the dustbin row, a 513-term reduction) for itself: one hand-off per iteration.  Two granule
+// buffers alternate by iteration parity: a workgroup can publish iteration k+2 only after consuming every band's
+// iteration k+1, which every band publishes only after consuming iteration k -- so nobody still reads what is
+// overwritten.  The arithmetic (operation order included) is that of sk_band_dots_kernel / sk_vcombine_dots_kernel,
+// so the duals equal the multi-launch form's bit for bit (asserted in tests/test_gpu_parity.py).
+// Requirements: n, m <= 512 and all batch * nb workgroups resident at once (batch <= SKP_MAX_BATCH: 128 workgroups
+// of 512 threads on 256 CUs); granule tags are zeroed by a memset node ahead of the launch; every spin is bounded
+// (SKP_SPIN_LIMIT polls, then the `fail` word is set and the workgroup leaves: garbage, never a hang).
+constexpr int SKP_MAX_BATCH = 8;
+constexpr int SKP_COLS = 520;                    // granules per band row: columns 0..m (<= 513), padded
+constexpr unsigned SKP_SPIN_LIMIT = 1u << 19;
+
+template <bool FAST>
+__global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restrict__ dots, int n, int m, int pitch,
+                                                         const float2 *__restrict__ row_info,
+                                                         const float2 *__restrict__ col_info, ZParams zp, int iterations,
+                                                         float *__restrict__ u, float *__restrict__ v,
+                                                         unsigned long long *gran, unsigned *fail, float log_m,
+                                                         float log_n) {
+  constexpr int RW = 4, NW = 8, BAND = NW * RW, NT = 64 * NW, NC = 512;
+  __shared__ float red[NW][NC + 1];
+  __shared__ float s_v[NC + 1];                  // v_j, j <= m
+  __shared__ float s_w[NC];                      // nie * |b_j|^2 + v_j (-inf past m): the row pass's per-column term
+  __shared__ float s_part[NW][2];
+  __shared__ int s_fail;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y, band = blockIdx.x, nb = gridDim.x, batch = gridDim.y;
+  const int row0 = band * BAND + wave * RW;
+  const float dust = zp.dust;
+  if (threadIdx.x == 0) s_fail = 0;
+
+  // ---- loaded once: this lane's 8 columns' (scale, squared norm), the wave's 4 rows of dot products
+  float tq[8], cy[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int j = lane * 8 + q;
+    const float2 c = col_info[(size_t)b * m + min(j, m - 1)];
+    tq[q] = (j < m) ? c.x : 0.0f;
+    cy[q] = (j < m) ? c.y * zp.neg_inv_eps : -INFINITY;
+  }
+  uint4 raw[RW];
+  float gi[RW], ci[RW];
+  bool live[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int i = min(row0 + r, n - 1);
+    live[r] = row0 + r < n;
+    raw[r] = *reinterpret_cast<const uint4 *>(dots + ((size_t)b * n + i) * pitch + min(lane * 8, pitch - 8));
+    const float2 ri = row_info[(size_t)b * n + i];
+    const float g0 = -2.0f * zp.neg_inv_eps * ri.x;
+    gi[r] = FAST ? g0 * SKD_L2E : g0;
+    ci[r] = ri.y * zp.neg_inv_eps;
+  }
+  // v = 0 (sinkhorn.py:134)
+  for (int j = threadIdx.x; j <= m; j += NT) s_v[j] = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s_w[lane * 8 + q] = cy[q];      // every wave writes the same values
+  __syncthreads();
+
+  float un = 0.0f, wmax = 0.0f;
+  // State derived from the current v, by every workgroup for itself: wmax = max_j (nie |b_j|^2 + v_j) (bounded-shift
+  // row pass) and u_n = log m - LSE_j(dust + v_j), the dustbin row's dual -- the dustbin band of sk_band_dots_kernel,
+  // operation for operation.
+  auto derive_state = [&]() {
+    const int t = threadIdx.x;
+    const float vd = s_v[m];
+    float mx = dust + vd;
+    for (int j = t; j < m; j += NT) mx = fmaxf(mx, dust + s_v[j]);
+    float wm = (t < m) ? s_w[t] : -INFINITY;
+    mx = wave_max_dpp(mx);
+    wm = wave_max_dpp(wm);
+    if (lane == 0) { s_part[wave][0] = mx; s_part[wave][1] = wm; }
+    __syncthreads();
+    mx = s_part[0][0];
+    wm = s_part[0][1];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) { mx = fmaxf(mx, s_part[w][0]); wm = fmaxf(wm, s_part[w][1]); }
+    __syncthreads();
+    float sum = 0.0f;
+    for (int j = t; j < m; j += NT) sum += expf((dust + s_v[j]) - mx);
+    sum = wave_sum_dpp(sum);
+    if (lane == 0) s_part[wave][0] = sum;
+    __syncthreads();
+    sum = s_part[0][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) sum += s_part[w][0];
+    sum += expf((dust + vd) - mx);
+    un = log_m - (logf(sum) + mx);
+    wmax = wm;
+    __syncthreads();
+  };
+  derive_state();
+
+  for (int it = 0; it < iterations; ++it) {
+    const float vd = s_v[m];
+    const float xd0 = dust + vd;
+    float wq[8];
+    {
+      const float4 w0 = *reinterpret_cast<const float4 *>(&s_w[lane * 8]), w1 = *reinterpret_cast<const float4 *>(&s_w[lane * 8 + 4]);
+      wq[0] = w0.x; wq[1] = w0.y; wq[2] = w0.z; wq[3] = w0.w; wq[4] = w1.x; wq[5] = w1.y; wq[6] = w1.z; wq[7] = w1.w;
+    }
+    float nm_pair = 0.0f;
+    if constexpr (FAST) {
+      const float S = fmaxf(wmax + zp.g_bound, xd0 + zp.d_bound);
+      nm_pair = -(S * SKD_L2E);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) wq[q] = __builtin_fmaf(wq[q], SKD_L2E, nm_pair);
+    }
+    // ---- row half (sk_band_dots_kernel's arithmetic)
+    float x[RW][8], mx[RW], xd[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      xd[r] = xd0 - ci[r];
+      const uint32_t w4[4] = {raw[r].x, raw[r].y, raw[r].z, raw[r].w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float dot = (float)((q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu));
+        x[r][q] = __builtin_fmaf(dot * tq[q], gi[r], wq[q]);
+      }
+      if constexpr (!FAST)
+        mx[r] = fmaxf(xd[r], fmaxf(fmaxf(fmaxf(x[r][0], x[r][1]), fmaxf(x[r][2], x[r][3])),
+                                   fmaxf(fmaxf(x[r][4], x[r][5]), fmaxf(x[r][6], x[r][7]))));
+    }
+    float nm[RW], sr[RW], ed[RW];
+    if constexpr (FAST) {
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        nm[r] = nm_pair;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[r][q] = __builtin_amdgcn_exp2f(x[r][q]);
+        sr[r] = 0.0f;
+        sr[r] += ((x[r][0] + x[r][1]) + (x[r][2] + x[r][3])) + ((x[r][4] + x[r][5]) + (x[r][6] + x[r][7]));
+        ed[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(xd[r], SKD_L2E, nm[r]));
+      }
+    } else {
+      wave_max4(mx);
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        nm[r] = -(mx[r] * SKD_L2E);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[r][q] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[r][q], SKD_L2E, nm[r]));
+        sr[r] = 0.0f;
+        sr[r] += ((x[r][0] + x[r][1]) + (x[r][2] + x[r][3])) + ((x[r][4] + x[r][5]) + (x[r][6] + x[r][7]));
+        ed[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(xd[r], SKD_L2E, nm[r]));
+      }
+    }
+    wave_sum4(sr);
+    float colsum[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) colsum[q] = 0.0f;
+    float dustcol = 0.0f;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const float st = sr[r] + ed[r];
+      if (it == iterations - 1 && lane == 0 && live[r])                                  // sinkhorn.py:139
+        u[(size_t)b * (n + 1) + row0 + r] = (nm[r] - __builtin_amdgcn_logf(st)) * SKD_LN2 - ci[r];
+      const float wgt = live[r] ? __builtin_amdgcn_rcpf(st) : 0.0f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) colsum[q] = __builtin_fmaf(x[r][q], wgt, colsum[q]);
+      dustcol = __builtin_fmaf(ed[r], wgt, dustcol);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[wave][lane * 8 + q] = colsum[q];
+    if (lane == 0) red[wave][NC] = dustcol;
+    __syncthreads();
+    // ---- publish this band's column sums: one 8-byte {tag, value} granule per column, write-through
+    const unsigned tag = (unsigned)it + 1u;
+    unsigned long long *gbuf = gran + ((size_t)(it & 1) * batch + b) * (size_t)nb * SKP_COLS;
+    for (int c = threadIdx.x; c <= NC; c += NT) {
+      const int j = (c == NC) ? m : c;
+      if (c < NC && j >= m) continue;
+      float t = red[0][c];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) t += red[w][c];
+      __hip_atomic_store(gbuf + (size_t)band * SKP_COLS + j, ((unsigned long long)tag << 32) | __float_as_uint(t),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- column half, by every workgroup for all columns (sk_vcombine_dots_kernel's arithmetic): gather the bands'
+    // granules of column j (all loads of a sweep in flight together), in band order
+    for (int j = threadIdx.x; j <= m; j += NT) {
+      const unsigned long long *gcol = gbuf + j;
+      float part[16];
+      bool ok = false;
+      for (unsigned spins = 0; !ok; ++spins) {
+        unsigned long long g[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          g[k] = (k < nb) ? __hip_atomic_load(gcol + (size_t)k * SKP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                          : ((unsigned long long)tag << 32);
+        ok = true;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          ok = ok && (unsigned)(g[k] >> 32) == tag;
+          part[k] = __uint_as_float((unsigned)g[k]);
+        }
+        if (!ok) {
+          if (spins > SKP_SPIN_LIMIT) {                       // a band never arrived: give up, flag it, leave
+            s_fail = 1;
+            __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      float ssum = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (k < nb) ssum += part[k];
+      const float vold = s_v[j];
+      const float bj = (dust + un) + vold;                     // the dustbin row's log-probability
+      const float a = ssum > 0.0f ? __builtin_amdgcn_logf(ssum) * SKD_LN2 : -INFINITY;
+      const float hi = fmaxf(a, bj), lo = fminf(a, bj);
+      const float lse = hi + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f((lo - hi) * SKD_L2E)) * SKD_LN2;
+      part[0] = (vold + ((j == m) ? log_n : 0.0f)) - lse;      // v_j (sinkhorn.py:142)
+      // every thread reads s_v[j] before any thread rewrites it: j is private to this thread
+      s_v[j] = part[0];
+      if (j < m) s_w[j] = col_info[(size_t)b * m + j].y * zp.neg_inv_eps + part[0];
+    }
+    __syncthreads();
+    if (s_fail) return;                                        // uniform: every thread sees the flag after the barrier
+    if (it == iterations - 1) {
+      if (band == 0) {
+        for (int j = threadIdx.x; j <= m; j += NT) v[(size_t)b * (m + 1) + j] = s_v[j];
+        if (threadIdx.x == 0) u[(size_t)b * (n + 1) + n] = un;
+      }
+      return;
+    }
+    derive_state();
+  }
+}
+
 // Helper streams for the split schedule below.  Fork/join by events, so the caller's stream semantics are
 // unchanged: everything is ordered after earlier work on `s` and before later work on it.  The streams and
 // events belong to ONE caller (device, stream) -- stream_registry.h says why -- and are created on the first
@@ -475,12 +716,23 @@ size_t dots_partials_bytes(int batch, int n, int m, int band) {
 }
 int dots_cpitch(int m) { return m <= 512 ? 512 : 1024; }
 
+// single-launch form: two granule buffers of nb band rows per pair, then the fail word (16 bytes reserved)
+bool persist_shape(int batch, int n, int m) { return batch <= SKP_MAX_BATCH && n <= 512 && m <= 512; }
+size_t persist_granule_bytes(int batch, int n) {
+  return 2 * (size_t)batch * (size_t)ceil_div(n, 32) * SKP_COLS * sizeof(unsigned long long);
+}
+size_t dots_base_bytes(int batch, int n, int m) {
+  const size_t b = dots_partials_bytes(batch, n, m, dots_rows_per_band(m)) +
+                   (2 * (size_t)batch * dots_cpitch(m) + (size_t)batch * SKD_AUX) * sizeof(float);
+  return (b + 15) & ~(size_t)15;
+}
+
 }  // namespace
 
 extern "C" size_t mi_sinkhorn_dots_workspace_bytes(int batch, int n, int m) {
   const int band = dots_rows_per_band(m);
   if (batch <= 0 || n <= 0 || m <= 0 || band == 0) return 0;
-  return dots_partials_bytes(batch, n, m, band) + (2 * (size_t)batch * dots_cpitch(m) + (size_t)batch * SKD_AUX) * sizeof(float);
+  return dots_base_bytes(batch, n, m) + (persist_shape(batch, n, m) ? persist_granule_bytes(batch, n) + 16 : 0);
 }
 
 // see include/mi355x_match.h: a caller that destroys a stream it passed to mi_sinkhorn_dots / mi_match_pairs
@@ -520,6 +772,27 @@ extern "C" int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, con
   zp.g_bound = (float)(2.0 / epsilon * sqnorm_bound);
   zp.d_bound = (float)(sqnorm_bound / epsilon);
   const bool fast = sqnorm_bound > 0.0 && (double)zp.g_bound * 1.4426950408889634 < (double)SKD_FAST_LIMIT;
+  if (persist_shape(batch, n, m) && mi_g_sinkhorn_persist.load(std::memory_order_relaxed) != 0) {
+    // single-launch form: zero the granule tags and the fail word (one memset node), then one kernel
+    char *gbase = reinterpret_cast<char *>(workspace) + dots_base_bytes(batch, n, m);
+    const size_t gbytes = persist_granule_bytes(batch, n);
+    hipError_t me = hipMemsetAsync(gbase, 0, gbytes + 16, s);
+    if (me != hipSuccess) return (int)me;
+    unsigned long long *gran = reinterpret_cast<unsigned long long *>(gbase);
+    unsigned *failw = reinterpret_cast<unsigned *>(gbase + gbytes);
+    const dim3 grid(ceil_div(n, 32), batch);
+    if (fast)
+      hipLaunchKernelGGL(sk_persist_kernel<true>, grid, dim3(512), 0, s, dots, n, m, pitch, ri, ci, zp, iterations, u, v,
+                         gran, failw, log_m, log_n);
+    else
+      hipLaunchKernelGGL(sk_persist_kernel<false>, grid, dim3(512), 0, s, dots, n, m, pitch, ri, ci, zp, iterations, u, v,
+                         gran, failw, log_m, log_n);
+    MI_CHECK_LAUNCH();
+    if (p)
+      hipLaunchKernelGGL(sk_exp_dots_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, dots, n, m, pitch, ri, ci,
+                         zp, u, v, p);
+    return mi_launch_status();
+  }
 #define SKD_LAUNCH(E8, RW, FAST) launch_dots<E8, RW, 8, FAST>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, wp, tp, aux, log_m, log_n, s)
   int e;
   if (m <= 512) e = fast ? SKD_LAUNCH(1, 4, true) : SKD_LAUNCH(1, 4, false);

@@ -299,6 +299,39 @@ def test_sinkhorn_dots_bounded_shift_vs_row_maximum(mods, eps, unused):
     assert float(((p_fast - p_slow).abs() / p_slow.abs().clamp(min=1.0)).max()) < 2e-5      # relative on the dustbin entries
 
 
+@pytest.mark.parametrize("batch,n,m,normalized,iters", [(1, 512, 512, True, 20), (8, 512, 512, True, 20), (3, 300, 470, True, 7),
+                                                         (2, 512, 33, True, 1), (1, 31, 512, False, 20), (5, 512, 511, False, 3),
+                                                         (1, 1, 1, True, 4)])
+def test_sinkhorn_single_launch_equals_multi_launch(mods, batch, n, m, normalized, iters):
+    """mi_sinkhorn_dots for <= 8 pairs runs ONE persistent launch (bands exchange column sums as tagged granules);
+    its duals and P must equal the 41-launch form's bit for bit, for both row-pass variants (bounded shift for unit
+    descriptors, per-row maxima for raw bit vectors), ragged shapes and repeated calls on one workspace."""
+    from onnx_image_processing_amd import _native as N, ops
+    rng = np.random.default_rng(batch * 1000 + n + m)
+    words = 16
+    b1 = rng.integers(0, 2 ** 32, size=(batch, n, words), dtype=np.uint64).astype(np.uint32)
+    b2 = rng.integers(0, 2 ** 32, size=(batch, m, words), dtype=np.uint64).astype(np.uint32)
+    k = min(n, m) // 2
+    b2[:, :k] = b1[:, :k]                                        # true matches
+    t1, t2 = gpu(b1.view(np.int32)), gpu(b2.view(np.int32))
+    eps, unused = (0.05, 1.0) if normalized else (24.0, 300.0)
+    lib = N.load()
+    try:
+        assert lib.mi_debug_set(7, 0) == 0
+        want = [t.clone() for t in ops.sinkhorn_bits(t1, t2, normalized, eps, unused, iters, return_duals=True)]
+        assert lib.mi_debug_set(7, 1) == 0
+        for _ in range(3):                                       # the same shapes again: allocator reuse, stale granules
+            got = ops.sinkhorn_bits(t1, t2, normalized, eps, unused, iters, return_duals=True)
+            for x, y in zip(got, want):
+                assert torch.equal(x, y)
+    finally:
+        lib.mi_debug_set(7, 1)
+    ref = O.sinkhorn_match(*[unpack_bits(b, 512).astype(np.float64) / (np.sqrt(unpack_bits(b, 512).sum(-1, keepdims=True)) if normalized else 1.0)
+                             for b in (b1, b2)], iters, eps, unused, "l2", dtype=np.float64)
+    ok, worst = p_close(got[0].cpu().numpy(), ref)
+    assert ok, worst
+
+
 @pytest.mark.parametrize("n,m", [(512, 512), (97, 301), (5, 3), (700, 1000), (64, 1500)])
 def test_sinkhorn_fused_equals_two_pass(mods, n, m):
     """The band-fused iteration (Z read once) and the two-pass form agree to fp32 rounding, and both
