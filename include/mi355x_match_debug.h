@@ -16,6 +16,7 @@ extern "C" {
  * staged tile kernel.  key 2: rows per thread of the streaming corner kernel (4, 5 or 8).
  * key 6: number of batch parts mi_sinkhorn_dots runs on separate streams (1..4, default 2).
  * key 7: mi_sinkhorn_dots for <= 8 pairs (n, m <= 512), 1 = single-launch form (default), 0 = multi-launch form.
+ * key 8: 1 = the single-launch Sinkhorn kernel records phase time stamps behind its workspace's fail word (tools/).
  * key 9: top-k, 1 = radix-select the k-th key and sort only the k winners when k << candidates
  * (default), 0 = always sort every candidate.
  * key 4: Sinkhorn band kernel, 0 = probability form, lean instruction stream (default), 2 = first

@@ -69,8 +69,8 @@ __device__ __forceinline__ int nearest_centre(float pos, float scale, int size) 
 // PIX = float (the reference's input) or uint8_t (the u8 ingest path: same window, a quarter of the bytes, no
 // integrality test -- every uint8 patch is integer-valued).
 template <int GROUPS, typename PIX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void bad_fast_kernel(const PIX *__restrict__ image, int h, int w,
-                                                       const float *__restrict__ kpts, int k, int total,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void bad_fast_kernel(MiSets images, int h, int w,
+                                                       MiSets kpt_sets, int k, int total,
                                                        int num_pairs, int normalize,
                                                        const BadPlan *__restrict__ plan,
                                                        const uint32_t *__restrict__ geom,
@@ -84,10 +84,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const int flat = (int)xcd_contiguous_id(blockIdx.x, gridDim.x) * 4 + wave;
   if (flat >= total) return;
   const int img = flat / k;
-  const PIX *im = image + (size_t)img * h * w;
+  const PIX *im = mi_set_item<PIX>(images, img, (size_t)h * w);
   constexpr uint32_t PB = (uint32_t)sizeof(PIX);
-  const float ky = kpts[(size_t)flat * 2 + 0];
-  const float kx = kpts[(size_t)flat * 2 + 1];
+  const float *kp = mi_set_item<float>(kpt_sets, img, (size_t)k * 2) + (size_t)(flat - img * k) * 2;
+  const float ky = kp[0];
+  const float kx = kp[1];
   const int groups = GROUPS ? GROUPS : num_pairs / 64;
   const int words = 2 * groups;
   constexpr int GMAX = GROUPS ? GROUPS : 16;
@@ -245,8 +246,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // Small chunks keep the serial depth per wave low: about 6 % of the keypoints are flagged at 640x480
 // (those within 15 px of the border), i.e. about one per 16.
 template <typename PIX>
-__global__ __launch_bounds__(64) void sparse_bad_kernel(const PIX *__restrict__ image, int h, int w,
-                                                        const float *__restrict__ kpts, int k, int total,
+__global__ __launch_bounds__(64) void sparse_bad_kernel(MiSets images, int h, int w,
+                                                        MiSets kpt_sets, int k, int total,
                                                         const uint32_t *__restrict__ geom,
                                                         const float *__restrict__ thr, int num_pairs,
                                                         int mode, float temperature, int normalize,
@@ -282,9 +283,10 @@ __global__ __launch_bounds__(64) void sparse_bad_kernel(const PIX *__restrict__ 
     todo &= todo - 1ull;
     const int flat = first + bit;
     const int img = flat / k;
-    const PIX *im = image + (size_t)img * h * w;
-    const float ky_raw = kpts[(size_t)flat * 2 + 0];
-    const float kx_raw = kpts[(size_t)flat * 2 + 1];
+    const PIX *im = mi_set_item<PIX>(images, img, (size_t)h * w);
+    const float *kp = mi_set_item<float>(kpt_sets, img, (size_t)k * 2) + (size_t)(flat - img * k) * 2;
+    const float ky_raw = kp[0];
+    const float kx_raw = kp[1];
     const bool valid = ky_raw >= 0.0f;                                   // bad.py:461
     const float ky = fminf(fmaxf(ky_raw, 0.0f), (float)(h - 1));         // bad.py:464-465
     const float kx = fminf(fmaxf(kx_raw, 0.0f), (float)(w - 1));
@@ -527,10 +529,11 @@ extern "C" int mi_bad_plan_build(const uint32_t *pair_geom, const float *pair_th
 
 namespace {
 template <typename PIX>
-int sparse_bad_launch(const PIX *image, int n, int h, int w, const float *keypoints, int k, const uint32_t *pair_geom,
+int sparse_bad_launch(MiSets image, int n, int h, int w, MiSets keypoints, int k, const uint32_t *pair_geom,
                       const float *pair_thr, int num_pairs, int mode, float temperature, int normalize, float *desc,
                       uint32_t *bits, const void *plan, uint8_t *status, mi_stream_t stream) {
-  if (!image || !keypoints || !pair_geom || !pair_thr) return MI_E_NULL;
+  if (!image.a || !keypoints.a || !pair_geom || !pair_thr) return MI_E_NULL;
+  if ((image.per_set < n && !image.b) || (keypoints.per_set < n && !keypoints.b)) return MI_E_NULL;
   if (!desc && !bits) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0 || k <= 0) return MI_E_SHAPE;
   if (num_pairs <= 0 || num_pairs % 64 != 0 || num_pairs > 1024) return MI_E_PARAM;
@@ -562,12 +565,22 @@ int sparse_bad_launch(const PIX *image, int n, int h, int w, const float *keypoi
 }
 }  // namespace
 
+int mi_sparse_bad_sets(MiSets images, int pix_u8, int n, int h, int w, MiSets keypoints, int k, const uint32_t *pair_geom,
+                       const float *pair_thr, int num_pairs, int mode, float temperature, int normalize, float *desc,
+                       uint32_t *bits, const void *plan, uint8_t *status, mi_stream_t stream) {
+  if (pix_u8)
+    return sparse_bad_launch<uint8_t>(images, n, h, w, keypoints, k, pair_geom, pair_thr, num_pairs, mode, temperature,
+                                      normalize, desc, bits, plan, status, stream);
+  return sparse_bad_launch<float>(images, n, h, w, keypoints, k, pair_geom, pair_thr, num_pairs, mode, temperature,
+                                  normalize, desc, bits, plan, status, stream);
+}
+
 extern "C" int mi_sparse_bad(const float *image, int n, int h, int w, const float *keypoints, int k,
                              const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
                              float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
                              uint8_t *status, mi_stream_t stream) {
   MI_ENTER();
-  return sparse_bad_launch<float>(image, n, h, w, keypoints, k, pair_geom, pair_thr, num_pairs, mode, temperature,
+  return sparse_bad_launch<float>(mi_one_set(image, n), n, h, w, mi_one_set(keypoints, n), k, pair_geom, pair_thr, num_pairs, mode, temperature,
                                   normalize, desc, bits, plan, status, stream);
 }
 
@@ -578,6 +591,6 @@ extern "C" int mi_sparse_bad_u8(const uint8_t *image, int n, int h, int w, const
                                 float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
                                 uint8_t *status, mi_stream_t stream) {
   MI_ENTER();
-  return sparse_bad_launch<uint8_t>(image, n, h, w, keypoints, k, pair_geom, pair_thr, num_pairs, mode, temperature,
+  return sparse_bad_launch<uint8_t>(mi_one_set(image, n), n, h, w, mi_one_set(keypoints, n), k, pair_geom, pair_thr, num_pairs, mode, temperature,
                                     normalize, desc, bits, plan, status, stream);
 }

@@ -23,6 +23,21 @@ static inline int mi_launch_status() {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Two equally shaped batches behind ONE launch (image1 / image2 of mi_match_pairs, and the keypoint arrays that belong
+// to them): item i of n = 2 * per_set lives in `a` for i < per_set and in `b` otherwise.  A single batch is
+// {ptr, nullptr, n}.  Which batch an item came from never changes what is computed for it.
+struct MiSets {
+  const void *a;
+  const void *b;
+  int per_set;
+};
+static inline MiSets mi_one_set(const void *p, int n) { return MiSets{p, nullptr, n}; }
+template <typename T>
+__device__ __forceinline__ const T *mi_set_item(const MiSets &s, int i, size_t item_elems) {
+  const bool second = i >= s.per_set;
+  return static_cast<const T *>(second ? s.b : s.a) + (size_t)(second ? i - s.per_set : i) * item_elems;
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share
@@ -144,3 +159,14 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// ---- internal launchers shared between translation units (not part of the C ABI): the entry points of
+// include/mi355x_match.h with `MiSets` in place of a single batch pointer.  mi_match_pairs uses them to put both images
+// of every pair behind one launch per stage when the batch is small (the one-pair-per-call latency path).
+int mi_corner_response_sets(MiSets images, int pix_u8, int n, int h, int w, int block_size, float *score,
+                            mi_stream_t stream);
+int mi_topk_keypoints_sets(const uint64_t *cand, const uint32_t *count, int segments, int segment_capacity, int n, int w,
+                           int k, MiSets keypoints, float *kscores, mi_stream_t stream);
+int mi_sparse_bad_sets(MiSets images, int pix_u8, int n, int h, int w, MiSets keypoints, int k, const uint32_t *pair_geom,
+                       const float *pair_thr, int num_pairs, int mode, float temperature, int normalize, float *desc,
+                       uint32_t *bits, const void *plan, uint8_t *status, mi_stream_t stream);

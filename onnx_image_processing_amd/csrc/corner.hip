@@ -22,6 +22,7 @@ extern std::atomic<int> mi_g_sinkhorn_log_partials;   // defined in sinkhorn.hip
 extern std::atomic<int> mi_g_sinkhorn_split;          // defined in sinkhorn_dots.hip
 extern std::atomic<int> mi_g_topk_select;             // defined in topk.hip
 extern std::atomic<int> mi_g_sinkhorn_persist;        // defined in sinkhorn_dots.hip
+extern std::atomic<int> mi_g_sinkhorn_stamps;
 
 namespace {
 
@@ -262,7 +263,7 @@ __device__ __forceinline__ void corner_compute(const TILE *__restrict__ tile, fl
 }
 
 template <int BS, int R>
-__global__ __launch_bounds__(256) void corner_tile_kernel(const float *__restrict__ image,
+__global__ __launch_bounds__(256) void corner_tile_kernel(MiSets images,
                                                           float *__restrict__ score, int h, int w,
                                                           int tiles_x, int tiles_y) {
   constexpr int HP = BS / 2;       // halo of the product maps
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(const float *__restric
   const int ty_tile = bid % tiles_y;
   const int img = bid / tiles_y;
   const int x0 = tx_tile * TW, y0 = ty_tile * TH;
-  const float *im = image + (size_t)img * h * w;
+  const float *im = mi_set_item<float>(images, img, (size_t)h * w);
 
   // ---- stage the clamped tile: every float4 chunk is wholly inside or wholly outside (w % 4 == 0)
   // All of a thread's 16-byte loads are issued before the first LDS store, so ~10 loads per lane
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(const float *__restric
 // PIX = uint8_t (the u8 ingest path): the same chunk grid with 4-byte pieces (global_load_lds_dword, 4 pixels
 // each), 5 B/px; the tile is a quarter of the LDS, the stencil converts on the LDS read (load_window).
 template <int BS, int R, bool U8>
-__global__ __launch_bounds__(256) void corner_stream_kernel(const void *__restrict__ image_raw,
+__global__ __launch_bounds__(256) void corner_stream_kernel(MiSets images,
                                                             float *__restrict__ score, int h, int w,
                                                             int tiles_x, int tiles_y, int total_tiles) {
   using CH = typename std::conditional<U8, uint32_t, float4>::type;   // 4 pixels
@@ -365,9 +366,8 @@ __global__ __launch_bounds__(256) void corner_stream_kernel(const void *__restri
     // The source pointers have concrete types on purpose: with a template-dependent pointer type hipcc 7.2 checks
     // the builtin's size immediate at instantiation time in the HOST pass, rejects 16 there without a diagnostic
     // and drops the instance's host stub (undefined symbol at load time).
-    const size_t plane = (size_t)img * h * w;
-    const float *imf = static_cast<const float *>(image_raw) + plane;
-    const uint8_t *imb = static_cast<const uint8_t *>(image_raw) + plane;
+    const float *imf = mi_set_item<float>(images, img, (size_t)h * w);
+    const uint8_t *imb = mi_set_item<uint8_t>(images, img, (size_t)h * w);
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
       const int gy = clampi(y0 + prow[q], 0, h - 1);
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void corner_stream_kernel(const void *__restri
 // Generic path: any width, any odd block size.  One thread per pixel, straight from global
 // memory (L2 absorbs the re-reads).  Same arithmetic, same clamping rules.
 template <typename PIX>
-__global__ __launch_bounds__(256) void corner_generic_kernel(const PIX *__restrict__ image,
+__global__ __launch_bounds__(256) void corner_generic_kernel(MiSets images,
                                                              float *__restrict__ score, int n, int h,
                                                              int w, int bs) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void corner_generic_kernel(const PIX *__restri
   if (idx >= total) return;
   const int x = (int)(idx % w);
   const int y = (int)((idx / w) % h);
-  const PIX *im = image + (idx / ((size_t)h * w)) * (size_t)h * w;
+  const PIX *im = mi_set_item<PIX>(images, (int)(idx / ((size_t)h * w)), (size_t)h * w);
   const int hp = bs / 2;
   float a = 0.f, c = 0.f, b = 0.f;
   for (int dy = -hp; dy <= hp; ++dy) {
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void corner_generic_kernel(const PIX *__restri
 }
 
 template <int BS, int R>
-int launch_tile(const float *image, int n, int h, int w, float *score, hipStream_t s) {
+int launch_tile(MiSets image, int n, int h, int w, float *score, hipStream_t s) {
   const int tiles_x = ceil_div(w, TW), tiles_y = ceil_div(h, 8 * R);
   const long long blocks = (long long)n * tiles_x * tiles_y;
   if (blocks > 0x7fffffffLL) return MI_E_SHAPE;
@@ -453,7 +453,7 @@ int launch_tile(const float *image, int n, int h, int w, float *score, hipStream
 
 // Persistent grid: 2 workgroups per CU (2 x 80 KiB of LDS) on the 256 CUs of an MI355X.
 template <int BS, int R, typename PIX>
-int launch_stream(const PIX *image, int n, int h, int w, float *score, hipStream_t s) {
+int launch_stream(MiSets image, int n, int h, int w, float *score, hipStream_t s) {
   const int tiles_x = ceil_div(w, TW), tiles_y = ceil_div(h, 8 * R);
   const long long total = (long long)n * tiles_x * tiles_y;
   if (total > 0x7fffffffLL) return MI_E_SHAPE;
@@ -467,7 +467,7 @@ int launch_stream(const PIX *image, int n, int h, int w, float *score, hipStream
   const int resident = 256 * PER_CU;
   const int grid = total < resident ? (int)total : resident;
   hipLaunchKernelGGL((corner_stream_kernel<BS, R, std::is_same<PIX, uint8_t>::value>), dim3(grid), dim3(256), 0, s,
-                     static_cast<const void *>(image), score, h, w, tiles_x, tiles_y, (int)total);
+                     image, score, h, w, tiles_x, tiles_y, (int)total);
   return mi_launch_status();
 }
 
@@ -484,35 +484,56 @@ extern "C" int mi_debug_set(int key, int value) {
   if (key == 6) { mi_g_sinkhorn_split = value; return MI_OK; }
   if (key == 9) { mi_g_topk_select = value; return MI_OK; }
   if (key == 7) { mi_g_sinkhorn_persist = value; return MI_OK; }
+  if (key == 8) { mi_g_sinkhorn_stamps = value; return MI_OK; }
   if (key == 2 && (value == 4 || value == 5 || value == 8)) { g_corner_rows = value; return MI_OK; }
   return MI_E_PARAM;
+}
+
+// The shared launcher: `images` names one batch or two (MiSets), n = the total number of images.
+int mi_corner_response_sets(MiSets images, int pix_u8, int n, int h, int w, int block_size, float *score,
+                            mi_stream_t stream) {
+  if (!images.a || (images.per_set < n && !images.b) || !score) return MI_E_NULL;
+  if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
+  if (block_size <= 0 || (block_size & 1) == 0) return MI_E_PARAM;
+  hipStream_t s = (hipStream_t)stream;
+  const uintptr_t bases = (uintptr_t)images.a | (uintptr_t)images.b;
+  const int rows = g_corner_rows.load(std::memory_order_relaxed);
+  const size_t total = (size_t)n * h * w;
+  const size_t blocks = (total + 255) / 256;
+  if (pix_u8) {
+    // 4-pixel DMA pieces: rows must start on a dword (w % 4 == 0, bases 4-byte aligned); score rows are written as float4
+    const bool aligned = (w % 4 == 0) && (bases % 4 == 0) && ((uintptr_t)score % 16 == 0);
+    if (aligned && h >= 4 && w >= 8 && block_size == 3) {
+      if (rows == 8) return launch_stream<3, 8, uint8_t>(images, n, h, w, score, s);
+      if (rows == 5) return launch_stream<3, 5, uint8_t>(images, n, h, w, score, s);
+      return launch_stream<3, 4, uint8_t>(images, n, h, w, score, s);
+    }
+    if (blocks > 0x7fffffffULL) return MI_E_SHAPE;
+    hipLaunchKernelGGL(corner_generic_kernel<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, s, images, score, n, h, w,
+                       block_size);
+    return mi_launch_status();
+  }
+  const bool aligned = (w % 4 == 0) && ((bases | (uintptr_t)score) % 16 == 0);
+  if (aligned && h >= 4 && w >= 8) {
+    if (block_size == 3 && g_corner_impl.load(std::memory_order_relaxed) == 0) {
+      if (rows == 4) return launch_stream<3, 4, float>(images, n, h, w, score, s);
+      if (rows == 5) return launch_stream<3, 5, float>(images, n, h, w, score, s);
+      return launch_stream<3, 8, float>(images, n, h, w, score, s);
+    }
+    if (block_size == 3) return launch_tile<3, 8>(images, n, h, w, score, s);
+    if (block_size == 5) return launch_tile<5, 8>(images, n, h, w, score, s);
+    if (block_size == 7) return launch_tile<7, 8>(images, n, h, w, score, s);
+  }
+  if (blocks > 0x7fffffffULL) return MI_E_SHAPE;
+  hipLaunchKernelGGL(corner_generic_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, images, score, n, h, w,
+                     block_size);
+  return mi_launch_status();
 }
 
 extern "C" int mi_corner_response(const float *image, int n, int h, int w, int block_size, float *score,
                                   mi_stream_t stream) {
   MI_ENTER();
-  if (!image || !score) return MI_E_NULL;
-  if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
-  if (block_size <= 0 || (block_size & 1) == 0) return MI_E_PARAM;
-  hipStream_t s = (hipStream_t)stream;
-  const bool aligned = (w % 4 == 0) && (((uintptr_t)image | (uintptr_t)score) % 16 == 0);
-  if (aligned && h >= 4 && w >= 8) {
-    const int rows = g_corner_rows.load(std::memory_order_relaxed);
-    if (block_size == 3 && g_corner_impl.load(std::memory_order_relaxed) == 0) {
-      if (rows == 4) return launch_stream<3, 4, float>(image, n, h, w, score, s);
-      if (rows == 5) return launch_stream<3, 5, float>(image, n, h, w, score, s);
-      return launch_stream<3, 8, float>(image, n, h, w, score, s);
-    }
-    if (block_size == 3) return launch_tile<3, 8>(image, n, h, w, score, s);
-    if (block_size == 5) return launch_tile<5, 8>(image, n, h, w, score, s);
-    if (block_size == 7) return launch_tile<7, 8>(image, n, h, w, score, s);
-  }
-  const size_t total = (size_t)n * h * w;
-  const size_t blocks = (total + 255) / 256;
-  if (blocks > 0x7fffffffULL) return MI_E_SHAPE;
-  hipLaunchKernelGGL(corner_generic_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, image, score, n, h,
-                     w, block_size);
-  return mi_launch_status();
+  return mi_corner_response_sets(mi_one_set(image, n), 0, n, h, w, block_size, score, stream);
 }
 
 // u8 ingest (the camera-frame path of sample/visual_odometry.py:65-92 without the host-side
@@ -520,22 +541,5 @@ extern "C" int mi_corner_response(const float *image, int n, int h, int w, int b
 extern "C" int mi_corner_response_u8(const uint8_t *image, int n, int h, int w, int block_size, float *score,
                                      mi_stream_t stream) {
   MI_ENTER();
-  if (!image || !score) return MI_E_NULL;
-  if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
-  if (block_size <= 0 || (block_size & 1) == 0) return MI_E_PARAM;
-  hipStream_t s = (hipStream_t)stream;
-  // 4-pixel DMA pieces: rows must start on a dword (w % 4 == 0, base 4-byte aligned); score rows are written as float4
-  const bool aligned = (w % 4 == 0) && ((uintptr_t)image % 4 == 0) && ((uintptr_t)score % 16 == 0);
-  if (aligned && h >= 4 && w >= 8 && block_size == 3) {
-    const int rows = g_corner_rows.load(std::memory_order_relaxed);
-    if (rows == 8) return launch_stream<3, 8, uint8_t>(image, n, h, w, score, s);
-    if (rows == 5) return launch_stream<3, 5, uint8_t>(image, n, h, w, score, s);
-    return launch_stream<3, 4, uint8_t>(image, n, h, w, score, s);
-  }
-  const size_t total = (size_t)n * h * w;
-  const size_t blocks = (total + 255) / 256;
-  if (blocks > 0x7fffffffULL) return MI_E_SHAPE;
-  hipLaunchKernelGGL(corner_generic_kernel<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, s, image, score, n, h, w,
-                     block_size);
-  return mi_launch_status();
+  return mi_corner_response_sets(mi_one_set(image, n), 1, n, h, w, block_size, score, stream);
 }

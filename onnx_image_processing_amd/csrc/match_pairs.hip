@@ -12,6 +12,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace {
 
 struct Carver {
@@ -27,13 +29,19 @@ struct Carver {
   }
 };
 
+// Batches up to this many pairs put image1 and image2 behind ONE launch per stage (twice the score / candidate
+// workspace, half the dependent launches): the one-pair-per-call latency path.  Larger batches keep one launch per
+// image side (every launch already fills the chip; the workspace stays at one side's size).
+constexpr int MP_MERGED_MAX_BATCH = 32;
+
 struct Layout {
-  float *score;                 // (batch, h, w), reused for both images
+  int sides;                    // 2 when both images share the detection workspace (merged launches), else 1
+  float *score;                 // (sides * batch, h, w); with sides == 1 reused for both images
   uint64_t *cand;               // (batch, segments, capacity)
   uint32_t *count;              // (batch, segments)
   float *kscores;               // (batch, K), scratch (keypoint scores are not an output of the wrapper)
   uint32_t *bits1, *bits2;      // (batch, K, P/32)
-  uint8_t *status;              // (batch, K)
+  uint8_t *status;              // (sides * batch, K)
   uint16_t *dots;               // (batch, K, pitch)
   float *row_info, *col_info;   // (batch, K, 2)
   float *u, *v;                 // (batch, K+1)
@@ -48,18 +56,21 @@ struct Layout {
 int lay_out(void *ws, int batch, int h, int w, int k, int num_pairs, Layout *L) {
   int e = mi_candidate_layout(h, w, &L->segments, &L->capacity);
   if (e) return e;
+  L->sides = batch <= MP_MERGED_MAX_BATCH ? 2 : 1;
+  const size_t nb = (size_t)L->sides * batch;
   L->pitch = (k + 7) / 8 * 8;
   L->sk_bytes = mi_sinkhorn_dots_workspace_bytes(batch, k, k);
   L->mnn_bytes = mi_mnn_duals_workspace_bytes(batch, k, k);
   if (L->sk_bytes == 0 || L->mnn_bytes == 0) return MI_E_PARAM;       // K > 1024: not the packed form
   Carver c(ws);
-  L->score = c.take<float>((size_t)batch * h * w);
-  L->cand = c.take<uint64_t>((size_t)batch * L->segments * L->capacity);
-  L->count = c.take<uint32_t>((size_t)batch * L->segments);
-  L->kscores = c.take<float>((size_t)batch * k);
-  L->bits1 = c.take<uint32_t>((size_t)batch * k * (num_pairs / 32));
-  L->bits2 = c.take<uint32_t>((size_t)batch * k * (num_pairs / 32));
-  L->status = c.take<uint8_t>((size_t)batch * k);
+  L->score = c.take<float>(nb * h * w);
+  L->cand = c.take<uint64_t>(nb * L->segments * L->capacity);
+  L->count = c.take<uint32_t>(nb * L->segments);
+  L->kscores = c.take<float>(nb * k);
+  // bits1 and bits2 are one array (2 * batch, K, P/32): the merged descriptor launch writes both halves
+  L->bits1 = c.take<uint32_t>(2 * (size_t)batch * k * (num_pairs / 32));
+  L->bits2 = L->bits1 + (size_t)batch * k * (num_pairs / 32);
+  L->status = c.take<uint8_t>(nb * k);
   L->dots = c.take<uint16_t>((size_t)batch * k * L->pitch);
   L->row_info = c.take<float>((size_t)batch * k * 2);
   L->col_info = c.take<float>((size_t)batch * k * 2);
@@ -120,20 +131,36 @@ int match_pairs_impl(const PIX *image1, const PIX *image2, int batch, int h, int
   if ((e = lay_out(workspace, batch, h, w, k, pbits, &L)) != MI_OK) return e;
   if (workspace_bytes < L.total) return MI_E_CAPACITY;
 
-  const PIX *images[2] = {image1, image2};
-  float *kpts[2] = {keypoints1, keypoints2};
-  uint32_t *bits[2] = {L.bits1, L.bits2};
-  for (int side = 0; side < 2; ++side) {
-    // detector/shi_tomasi.py:66-112, utils/keypoint_utils.py:12-117 (mask never materialised)
-    if ((e = corner_of(images[side], batch, h, w, params->block_size, L.score, stream)) != MI_OK) return e;
-    if ((e = mi_nms_candidates(L.score, batch, h, w, params->nms_radius, params->score_threshold, params->border_margin,
-                               L.cand, L.count, stream)) != MI_OK)
+  constexpr int U8 = std::is_same<PIX, uint8_t>::value ? 1 : 0;
+  if (L.sides == 2) {
+    // both images of every pair behind one launch per stage (items 0..batch-1 = image1, batch..2*batch-1 = image2)
+    const MiSets imgs{image1, image2, batch}, kps{keypoints1, keypoints2, batch};
+    const int n2 = 2 * batch;
+    if ((e = mi_corner_response_sets(imgs, U8, n2, h, w, params->block_size, L.score, stream)) != MI_OK) return e;
+    if ((e = mi_nms_candidates(L.score, n2, h, w, params->nms_radius, params->score_threshold, params->border_margin, L.cand,
+                               L.count, stream)) != MI_OK)
       return e;
-    if ((e = mi_topk_keypoints(L.cand, L.count, L.segments, L.capacity, batch, w, k, kpts[side], L.kscores, stream)) !=
-        MI_OK)
+    if ((e = mi_topk_keypoints_sets(L.cand, L.count, L.segments, L.capacity, n2, w, k, kps, L.kscores, stream)) != MI_OK) return e;
+    if ((e = mi_sparse_bad_sets(imgs, U8, n2, h, w, kps, k, params->pair_geom, params->pair_thr, pbits, MI_BAD_HARD, 0.0f,
+                                params->normalize_descriptors, nullptr, L.bits1, params->bad_plan,
+                                params->bad_plan ? L.status : nullptr, stream)) != MI_OK)
       return e;
-    // descriptor/bad.py:436-576, hard bits, packed
-    if ((e = bad_bits_of(images[side], batch, h, w, kpts[side], k, params, bits[side], L.status, stream)) != MI_OK) return e;
+  } else {
+    const PIX *images[2] = {image1, image2};
+    float *kpts[2] = {keypoints1, keypoints2};
+    uint32_t *bits[2] = {L.bits1, L.bits2};
+    for (int side = 0; side < 2; ++side) {
+      // detector/shi_tomasi.py:66-112, utils/keypoint_utils.py:12-117 (mask never materialised)
+      if ((e = corner_of(images[side], batch, h, w, params->block_size, L.score, stream)) != MI_OK) return e;
+      if ((e = mi_nms_candidates(L.score, batch, h, w, params->nms_radius, params->score_threshold, params->border_margin,
+                                 L.cand, L.count, stream)) != MI_OK)
+        return e;
+      if ((e = mi_topk_keypoints(L.cand, L.count, L.segments, L.capacity, batch, w, k, kpts[side], L.kscores, stream)) !=
+          MI_OK)
+        return e;
+      // descriptor/bad.py:436-576, hard bits, packed
+      if ((e = bad_bits_of(images[side], batch, h, w, kpts[side], k, params, bits[side], L.status, stream)) != MI_OK) return e;
+    }
   }
   // matching/sinkhorn.py:79-208 in the packed (uint16 dot product) form; P is never written
   if ((e = mi_cost_dots_bits(L.bits1, L.bits2, batch, k, k, pbits, params->normalize_descriptors, L.dots, L.pitch,

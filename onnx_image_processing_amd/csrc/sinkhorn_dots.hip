@@ -20,12 +20,14 @@
 // test hook (mi_debug_set key 7): 1 = batches of <= SKP_MAX_BATCH pairs (n, m <= 512) run the single-launch form
 // (default), 0 = always the multi-launch form.  Same duals bit for bit.
 std::atomic<int> mi_g_sinkhorn_persist{1};
+std::atomic<int> mi_g_sinkhorn_stamps{0};      // key 8: 1 = the single-launch kernel records phase time stamps
 // test hook (mi_debug_set key 6, include/mi355x_match_debug.h): number of batch parts run on separate
 // streams (1 = one stream).  Whole bench step: 1.88 / 1.82 / 1.92 ms with 1 / 2 / 3 parts of 256 pairs.
 std::atomic<int> mi_g_sinkhorn_split{2};
 
 namespace {
 
+__device__ __forceinline__ int ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
 __device__ __forceinline__ float sk_exp(float d) { return __builtin_amdgcn_exp2f(d * 1.4426950408889634f); }
 
 constexpr float SKD_L2E = 1.4426950408889634f, SKD_LN2 = 0.6931471805599453f;
@@ -392,6 +394,7 @@ __global__ __launch_bounds__(256) void sk_exp_dots_kernel(const uint16_t *__rest
 constexpr int SKP_MAX_BATCH = 8;
 constexpr int SKP_COLS = 520;                    // granules per band row: columns 0..m (<= 513), padded
 constexpr unsigned SKP_SPIN_LIMIT = 1u << 19;
+constexpr size_t SKP_PROF_BYTES = 4096;          // phase time stamps of the development aid (key 8), after the fail word
 
 template <bool FAST>
 __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restrict__ dots, int n, int m, int pitch,
@@ -399,27 +402,34 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
                                                          const float2 *__restrict__ col_info, ZParams zp, int iterations,
                                                          float *__restrict__ u, float *__restrict__ v,
                                                          unsigned long long *gran, unsigned *fail, float log_m,
-                                                         float log_n) {
+                                                         float log_n, unsigned long long *prof, int batch) {
   constexpr int RW = 4, NW = 8, BAND = NW * RW, NT = 64 * NW, NC = 512;
+  // development aid (mi_debug_set key 8): band 0 of pair 0 stamps the phases of every iteration (100 MHz clock)
+#define SKP_STAMP(slot) do { if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[it * 8 + (slot)] = wall_clock64(); } while (0)
   __shared__ float red[NW][NC + 1];
-  __shared__ float s_v[NC + 1];                  // v_j, j <= m
   __shared__ float s_w[NC];                      // nie * |b_j|^2 + v_j (-inf past m): the row pass's per-column term
-  __shared__ float s_part[NW][2];
+  __shared__ float s_part[2][NW][2];             // two sets: a barrier separates a set's writes from its reads only once
+  __shared__ float s_vd;                         // v_m, the dustbin column's dual
   __shared__ int s_fail;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.y, band = blockIdx.x, nb = gridDim.x, batch = gridDim.y;
+  // Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md, workgroup dispatch): linear block L sits
+  // on XCD L % 8.  The bands of one pair take the blocks L = xcd + 8 * slot of ONE XCD, so that their granules meet
+  // in that XCD's L2 (placement is a speed matter only: stores are write-through and loads bypass L1 either way).
+  const int nb = ceil_div_dev(n, BAND);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int b = xcd + 8 * (slot / nb), band = slot % nb;
+  if (b >= batch) return;
   const int row0 = band * BAND + wave * RW;
   const float dust = zp.dust;
-  if (threadIdx.x == 0) s_fail = 0;
+  const int t = threadIdx.x;
+  if (t == 0) s_fail = 0;
 
-  // ---- loaded once: this lane's 8 columns' (scale, squared norm), the wave's 4 rows of dot products
-  float tq[8], cy[8];
+  // ---- loaded once: this lane's 8 columns' scales, the wave's 4 rows of dot products, the rows' constants
+  float tq[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int j = lane * 8 + q;
-    const float2 c = col_info[(size_t)b * m + min(j, m - 1)];
-    tq[q] = (j < m) ? c.x : 0.0f;
-    cy[q] = (j < m) ? c.y * zp.neg_inv_eps : -INFINITY;
+    tq[q] = (j < m) ? col_info[(size_t)b * m + min(j, m - 1)].x : 0.0f;
   }
   uint4 raw[RW];
   float gi[RW], ci[RW];
@@ -434,48 +444,49 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
     gi[r] = FAST ? g0 * SKD_L2E : g0;
     ci[r] = ri.y * zp.neg_inv_eps;
   }
-  // v = 0 (sinkhorn.py:134)
-  for (int j = threadIdx.x; j <= m; j += NT) s_v[j] = 0.0f;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) s_w[lane * 8 + q] = cy[q];      // every wave writes the same values
-  __syncthreads();
+  // ---- the column half's state lives in registers: thread t owns column t (its v_j and nie * |b_j|^2); the dustbin
+  // column m is owned by thread m, or by thread 0 as a second column when m == NT
+  const bool own0 = t <= m;                                  // column t exists (t == m: the dustbin column)
+  const bool core0 = t < m;
+  const bool own1 = (t == 0) && (m == NT);                   // column m = 512
+  const float cy0 = core0 ? col_info[(size_t)b * m + t].y * zp.neg_inv_eps : -INFINITY;
+  float v0 = 0.0f, v1 = 0.0f;                                // v = 0 (sinkhorn.py:134)
+  s_w[t] = cy0;                                              // NT == NC: every column of the row pass's array
+  if (t == 0) s_vd = 0.0f;
 
-  float un = 0.0f, wmax = 0.0f;
+  float un = 0.0f, wmax = 0.0f, vd = 0.0f;
   // State derived from the current v, by every workgroup for itself: wmax = max_j (nie |b_j|^2 + v_j) (bounded-shift
   // row pass) and u_n = log m - LSE_j(dust + v_j), the dustbin row's dual -- the dustbin band of sk_band_dots_kernel,
-  // operation for operation.
+  // operation for operation.  Two barriers; it also publishes s_w / s_vd written just before it.
+  int set = 0;
   auto derive_state = [&]() {
-    const int t = threadIdx.x;
-    const float vd = s_v[m];
-    float mx = dust + vd;
-    for (int j = t; j < m; j += NT) mx = fmaxf(mx, dust + s_v[j]);
-    float wm = (t < m) ? s_w[t] : -INFINITY;
+    float mx = core0 ? dust + v0 : -INFINITY;
+    float wm = core0 ? cy0 + v0 : -INFINITY;
     mx = wave_max_dpp(mx);
     wm = wave_max_dpp(wm);
-    if (lane == 0) { s_part[wave][0] = mx; s_part[wave][1] = wm; }
+    if (lane == 0) { s_part[set][wave][0] = mx; s_part[set][wave][1] = wm; }
     __syncthreads();
-    mx = s_part[0][0];
-    wm = s_part[0][1];
+    vd = s_vd;
+    mx = fmaxf(dust + vd, s_part[set][0][0]);
+    wm = s_part[set][0][1];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) { mx = fmaxf(mx, s_part[w][0]); wm = fmaxf(wm, s_part[w][1]); }
-    __syncthreads();
-    float sum = 0.0f;
-    for (int j = t; j < m; j += NT) sum += expf((dust + s_v[j]) - mx);
+    for (int w = 1; w < NW; ++w) { mx = fmaxf(mx, s_part[set][w][0]); wm = fmaxf(wm, s_part[set][w][1]); }
+    float sum = core0 ? expf((dust + v0) - mx) : 0.0f;
     sum = wave_sum_dpp(sum);
-    if (lane == 0) s_part[wave][0] = sum;
+    set ^= 1;
+    if (lane == 0) s_part[set][wave][0] = sum;
     __syncthreads();
-    sum = s_part[0][0];
+    sum = s_part[set][0][0];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) sum += s_part[w][0];
+    for (int w = 1; w < NW; ++w) sum += s_part[set][w][0];
     sum += expf((dust + vd) - mx);
     un = log_m - (logf(sum) + mx);
     wmax = wm;
-    __syncthreads();
   };
   derive_state();
 
   for (int it = 0; it < iterations; ++it) {
-    const float vd = s_v[m];
+    SKP_STAMP(0);
     const float xd0 = dust + vd;
     float wq[8];
     {
@@ -546,35 +557,53 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
     for (int q = 0; q < 8; ++q) red[wave][lane * 8 + q] = colsum[q];
     if (lane == 0) red[wave][NC] = dustcol;
     __syncthreads();
+    SKP_STAMP(1);
     // ---- publish this band's column sums: one 8-byte {tag, value} granule per column, write-through
     const unsigned tag = (unsigned)it + 1u;
     unsigned long long *gbuf = gran + ((size_t)(it & 1) * batch + b) * (size_t)nb * SKP_COLS;
-    for (int c = threadIdx.x; c <= NC; c += NT) {
-      const int j = (c == NC) ? m : c;
-      if (c < NC && j >= m) continue;
-      float t = red[0][c];
+    auto publish = [&](int c, int j) {                        // c: index into red, j: the column it belongs to
+      float s8 = red[0][c];
 #pragma unroll
-      for (int w = 1; w < NW; ++w) t += red[w][c];
-      __hip_atomic_store(gbuf + (size_t)band * SKP_COLS + j, ((unsigned long long)tag << 32) | __float_as_uint(t),
+      for (int w = 1; w < NW; ++w) s8 += red[w][c];
+      __hip_atomic_store(gbuf + (size_t)band * SKP_COLS + j, ((unsigned long long)tag << 32) | __float_as_uint(s8),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    };
+    if (core0) publish(t, t);
+    if (t == 0) publish(NC, m);                               // the dustbin column's sum sits at red[.][NC]
+    SKP_STAMP(4);
     // ---- column half, by every workgroup for all columns (sk_vcombine_dots_kernel's arithmetic): gather the bands'
-    // granules of column j (all loads of a sweep in flight together), in band order
-    for (int j = threadIdx.x; j <= m; j += NT) {
-      const unsigned long long *gcol = gbuf + j;
-      float part[16];
+    // granules of a column (all loads of a sweep in flight together) and add them in band order
+    // thread t gathers column t; thread 0 also gathers column m when m == NT (own1), its loads in flight together
+    // with the first column's
+    float ssum0 = 0.0f, ssum1 = 0.0f;
+    if (own0) {
+      const unsigned long long *gcol = gbuf + t;
+      float part[16], part1[16];
       bool ok = false;
       for (unsigned spins = 0; !ok; ++spins) {
-        unsigned long long g[16];
+        unsigned long long g[16], g1[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k)
           g[k] = (k < nb) ? __hip_atomic_load(gcol + (size_t)k * SKP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                           : ((unsigned long long)tag << 32);
+        if (own1) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            g1[k] = (k < nb) ? __hip_atomic_load(gbuf + m + (size_t)k * SKP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                             : ((unsigned long long)tag << 32);
+        }
         ok = true;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
           ok = ok && (unsigned)(g[k] >> 32) == tag;
           part[k] = __uint_as_float((unsigned)g[k]);
+        }
+        if (own1) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            ok = ok && (unsigned)(g1[k] >> 32) == tag;
+            part1[k] = __uint_as_float((unsigned)g1[k]);
+          }
         }
         if (!ok) {
           if (spins > SKP_SPIN_LIMIT) {                       // a band never arrived: give up, flag it, leave
@@ -585,31 +614,47 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
           __builtin_amdgcn_s_sleep(1);
         }
       }
-      float ssum = 0.0f;
 #pragma unroll
       for (int k = 0; k < 16; ++k)
-        if (k < nb) ssum += part[k];
-      const float vold = s_v[j];
+        if (k < nb) ssum0 += part[k];                          // band order, as sk_vcombine_dots_kernel adds them
+      if (own1) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k < nb) ssum1 += part1[k];
+      }
+    }
+    auto column_update = [&](float ssum, float vold, bool dustbin_col) -> float {
       const float bj = (dust + un) + vold;                     // the dustbin row's log-probability
       const float a = ssum > 0.0f ? __builtin_amdgcn_logf(ssum) * SKD_LN2 : -INFINITY;
       const float hi = fmaxf(a, bj), lo = fminf(a, bj);
       const float lse = hi + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f((lo - hi) * SKD_L2E)) * SKD_LN2;
-      part[0] = (vold + ((j == m) ? log_n : 0.0f)) - lse;      // v_j (sinkhorn.py:142)
-      // every thread reads s_v[j] before any thread rewrites it: j is private to this thread
-      s_v[j] = part[0];
-      if (j < m) s_w[j] = col_info[(size_t)b * m + j].y * zp.neg_inv_eps + part[0];
+      return (vold + (dustbin_col ? log_n : 0.0f)) - lse;      // v_j (sinkhorn.py:142)
+    };
+    if (own0) {
+      if (t == 0) SKP_STAMP(5);
+      v0 = column_update(ssum0, v0, t == m);
+      if (core0) s_w[t] = cy0 + v0; else s_vd = v0;
     }
-    __syncthreads();
-    if (s_fail) return;                                        // uniform: every thread sees the flag after the barrier
+    if (own1) {
+      v1 = column_update(ssum1, v1, true);
+      s_vd = v1;
+    }
+    SKP_STAMP(2);
     if (it == iterations - 1) {
+      __syncthreads();
+      if (s_fail) return;
       if (band == 0) {
-        for (int j = threadIdx.x; j <= m; j += NT) v[(size_t)b * (m + 1) + j] = s_v[j];
-        if (threadIdx.x == 0) u[(size_t)b * (n + 1) + n] = un;
+        if (own0) v[(size_t)b * (m + 1) + t] = v0;
+        if (own1) v[(size_t)b * (m + 1) + m] = v1;
+        if (t == 0) u[(size_t)b * (n + 1) + n] = un;
       }
       return;
     }
-    derive_state();
+    derive_state();                                            // (its first barrier publishes s_w / s_vd / s_fail)
+    if (s_fail) return;                                        // uniform: every thread reads it after a barrier
+    SKP_STAMP(3);
   }
+#undef SKP_STAMP
 }
 
 // Helper streams for the split schedule below.  Fork/join by events, so the caller's stream semantics are
@@ -732,7 +777,7 @@ size_t dots_base_bytes(int batch, int n, int m) {
 extern "C" size_t mi_sinkhorn_dots_workspace_bytes(int batch, int n, int m) {
   const int band = dots_rows_per_band(m);
   if (batch <= 0 || n <= 0 || m <= 0 || band == 0) return 0;
-  return dots_base_bytes(batch, n, m) + (persist_shape(batch, n, m) ? persist_granule_bytes(batch, n) + 16 : 0);
+  return dots_base_bytes(batch, n, m) + (persist_shape(batch, n, m) ? persist_granule_bytes(batch, n) + 16 + SKP_PROF_BYTES : 0);
 }
 
 // see include/mi355x_match.h: a caller that destroys a stream it passed to mi_sinkhorn_dots / mi_match_pairs
@@ -780,13 +825,15 @@ extern "C" int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, con
     if (me != hipSuccess) return (int)me;
     unsigned long long *gran = reinterpret_cast<unsigned long long *>(gbase);
     unsigned *failw = reinterpret_cast<unsigned *>(gbase + gbytes);
-    const dim3 grid(ceil_div(n, 32), batch);
+    unsigned long long *prof = mi_g_sinkhorn_stamps.load(std::memory_order_relaxed) && iterations * 64 <= (int)SKP_PROF_BYTES
+                                   ? reinterpret_cast<unsigned long long *>(gbase + gbytes + 16) : nullptr;
+    const dim3 grid(8 * ceil_div(n, 32) * ceil_div(batch, 8));
     if (fast)
       hipLaunchKernelGGL(sk_persist_kernel<true>, grid, dim3(512), 0, s, dots, n, m, pitch, ri, ci, zp, iterations, u, v,
-                         gran, failw, log_m, log_n);
+                         gran, failw, log_m, log_n, prof, batch);
     else
       hipLaunchKernelGGL(sk_persist_kernel<false>, grid, dim3(512), 0, s, dots, n, m, pitch, ri, ci, zp, iterations, u, v,
-                         gran, failw, log_m, log_n);
+                         gran, failw, log_m, log_n, prof, batch);
     MI_CHECK_LAUNCH();
     if (p)
       hipLaunchKernelGGL(sk_exp_dots_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, dots, n, m, pitch, ri, ci,

@@ -121,8 +121,7 @@ __device__ __forceinline__ void bitonic_sort_desc_4096(uint64_t *keys, uint64_t 
 
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__restrict__ cand,
                                                           const uint32_t *__restrict__ count, int segments,
-                                                          uint32_t seg_cap, int w, int k,
-                                                          float *__restrict__ kpts,
+                                                          uint32_t seg_cap, int w, int k, MiSets kpt_sets,
                                                           float *__restrict__ kscores, int select_mode) {
   __shared__ uint64_t keys[TK_MAX];
   __shared__ uint64_t keys2[TK_MAX];      // second buffer of the register sort's cross-wave stages
@@ -255,9 +254,34 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
       while (kpad < k) kpad <<= 1;
       for (int i = nsel + t; i < kpad; i += TK_THREADS) keys2[i] = 0ull;
       __syncthreads();
-      bitonic_sort_desc(keys2, kpad, t);
-      for (int i = t; i < nsel; i += TK_THREADS) keys[i] = keys2[i];      // the epilogue reads `keys`
-      __syncthreads();
+      if (kpad <= TK_THREADS) {
+        // Rank sort of the <= 1024 winners: the keys are distinct, so a key's place in the descending order is the
+        // number of keys greater than it.  TK_THREADS / kpad threads share one key, each counting over its share of
+        // the list; every lane of a wave reads the same list entry (an LDS broadcast), so the inner loop is a load,
+        // a 64-bit compare and an add -- no barrier per stage as in the bitonic network (45 stages for 512 keys).
+        // Same result: the descending order of distinct keys is unique.
+        const int per_key = TK_THREADS / kpad;                 // 1, 2, 4, ... threads per key
+        const int idx = t & (kpad - 1), part = t / kpad;
+        const uint64_t mine = keys2[idx];
+        const int span = (nsel + per_key - 1) / per_key;
+        const int j0 = part * span, j1 = min(j0 + span, nsel);
+        uint32_t rank = 0;
+        for (int j = j0; j < j1; ++j) rank += keys2[j] > mine ? 1u : 0u;
+        uint32_t *ranks = reinterpret_cast<uint32_t *>(keys);  // kpad counters per part; `keys` is free here
+        ranks[part * kpad + idx] = rank;
+        __syncthreads();
+        uint32_t total = 0;
+        if (part == 0 && idx < nsel) {
+          for (int q = 0; q < per_key; ++q) total += ranks[q * kpad + idx];
+        }
+        __syncthreads();                                        // every counter is read before `keys` is rewritten
+        if (part == 0 && idx < nsel) keys[total] = mine;
+        __syncthreads();
+      } else {
+        bitonic_sort_desc(keys2, kpad, t);
+        for (int i = t; i < nsel; i += TK_THREADS) keys[i] = keys2[i];      // the epilogue reads `keys`
+        __syncthreads();
+      }
     } else {
     for (int i = (int)n + t; i < npad; i += TK_THREADS) keys[i] = 0ull;
     __syncthreads();
@@ -369,6 +393,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
     bitonic_sort_desc(keys, npad, t);
   }
 
+  float *kpts = const_cast<float *>(mi_set_item<float>(kpt_sets, img, (size_t)k * 2));
   for (int j = t; j < k; j += TK_THREADS) {
     float y = -1.0f, x = -1.0f, s = 0.0f;
     if (j < nsel) {
@@ -378,23 +403,28 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
       x = (float)(lin % (uint32_t)w);
       s = __uint_as_float((uint32_t)(key >> 32));
     }
-    kpts[((size_t)img * k + j) * 2 + 0] = y;
-    kpts[((size_t)img * k + j) * 2 + 1] = x;
+    kpts[(size_t)j * 2 + 0] = y;
+    kpts[(size_t)j * 2 + 1] = x;
     kscores[(size_t)img * k + j] = s;
   }
 }
 
 }  // namespace
 
-extern "C" int mi_topk_keypoints(const uint64_t *cand, const uint32_t *count, int segments,
-                                 int segment_capacity, int n, int w, int k, float *keypoints, float *kscores,
-                                 mi_stream_t stream) {
-  MI_ENTER();
-  if (!cand || !count || !keypoints || !kscores) return MI_E_NULL;
+int mi_topk_keypoints_sets(const uint64_t *cand, const uint32_t *count, int segments, int segment_capacity, int n, int w,
+                           int k, MiSets keypoints, float *kscores, mi_stream_t stream) {
+  if (!cand || !count || !keypoints.a || (keypoints.per_set < n && !keypoints.b) || !kscores) return MI_E_NULL;
   if (n <= 0 || w <= 0 || segments <= 0) return MI_E_SHAPE;
   if (k <= 0 || k > TK_MAX) return MI_E_PARAM;
   if (segment_capacity <= 0) return MI_E_CAPACITY;
   hipLaunchKernelGGL(topk_kernel, dim3(n), dim3(TK_THREADS), 0, (hipStream_t)stream, cand, count, segments,
                      (uint32_t)segment_capacity, w, k, keypoints, kscores, mi_g_topk_select.load(std::memory_order_relaxed));
   return mi_launch_status();
+}
+
+extern "C" int mi_topk_keypoints(const uint64_t *cand, const uint32_t *count, int segments,
+                                 int segment_capacity, int n, int w, int k, float *keypoints, float *kscores,
+                                 mi_stream_t stream) {
+  MI_ENTER();
+  return mi_topk_keypoints_sets(cand, count, segments, segment_capacity, n, w, k, mi_one_set(keypoints, n), kscores, stream);
 }

@@ -45,8 +45,30 @@ def main():
     graphed = GraphedModule(model, i1, i2)
     graph_ms, graph_out = timed(lambda: graphed(i1, i2))
     same = all(torch.equal(x, y) for x, y in zip(eager_out, graph_out))
-    print(f"pairs per call {args.pairs}: eager {eager_ms:.3f} ms, hipGraph replay {graph_ms:.3f} ms "
+    print(f"module path, pairs per call {args.pairs}: eager {eager_ms:.3f} ms, hipGraph replay {graph_ms:.3f} ms "
           f"({args.pairs / graph_ms * 1e3:.0f} pairs/s), outputs identical: {same}")
+
+    class OneCall(torch.nn.Module):                       # the same forward as ONE C-ABI call (mi_match_pairs)
+        def forward(self, x, y):
+            return model.forward_single_call(x, y)
+    one = OneCall()
+    e1, o1 = timed(lambda: one(i1, i2))
+    g1 = GraphedModule(one, i1, i2)
+    e2, o2 = timed(lambda: g1(i1, i2))
+
+    def synced(fn):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.iters):
+            fn()
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.iters * 1e3
+    s1, s2 = synced(lambda: one(i1, i2)), synced(g1.graph.replay)
+    same = all(torch.equal(x, y) for x, y in zip(o1, eager_out)) and all(torch.equal(x, y) for x, y in zip(o2, eager_out))
+    print(f"mi_match_pairs, pairs per call {args.pairs}: eager {e1:.3f} ms, hipGraph replay {e2:.3f} ms back to back; "
+          f"{s1:.3f} / {s2:.3f} ms with a host sync per call; outputs identical to the module path: {same}")
 
 
 if __name__ == "__main__":
