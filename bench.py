@@ -192,34 +192,43 @@ def cpu_baseline(parity_pairs: int, gpu_records=None) -> dict:
 
 
 # ----------------------------------------------------------------------------------------------- N = 1 extras
-def measure_latency(model, img1, img2, iters: int = 200) -> dict:
-    """One call = submit -> results complete on the device (synchronise after every call), the reference harness's
-    pattern.  Eager = the module path (about 20 C-ABI calls); graph = the same forward replayed as one hipGraph."""
+def measure_latency(model, img1, img2, a8, b8, iters: int = 200) -> dict:
+    """One call = submit -> results complete on the device (host synchronised after every call), the reference
+    harness's pattern (sample/image_matching.py:313-328).  Three forms of the same forward, outputs identical:
+      module       the nn.Module path (about 20 C-ABI calls, one launch per stage and image);
+      single_call  ONE C-ABI call, mi_match_pairs: both images per launch, top-k by merge-rank sort, the 20 Sinkhorn
+                   iterations as one persistent launch (bands exchange column sums as tagged granules);
+      single_call_u8  the same on uint8 frames (mi_match_pairs_u8).
+    Each eager and replayed as one hipGraph."""
     from onnx_image_processing_amd.graph import GraphedModule
+
+    def timed(fn):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+
+    def one_call(x, y):
+        return model.forward_single_call(x, y)
+
     out = {}
     for b in (1, 8):
-        a1, b1 = img1[:b].contiguous(), img2[:b].contiguous()
-        for _ in range(10):
-            model(a1, b1)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            model(a1, b1)
-            torch.cuda.synchronize()
-        eager = (time.perf_counter() - t0) / iters * 1e3
-        graphed = GraphedModule(model, a1, b1)
-        for _ in range(10):
-            graphed.graph.replay()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            graphed.graph.replay()
-            torch.cuda.synchronize()
-        graph = (time.perf_counter() - t0) / iters * 1e3
-        out[f"pairs_per_call_{b}"] = {"eager_ms": eager, "graph_ms": graph, "eager_pairs_per_sec": b / (eager * 1e-3),
-                                      "graph_pairs_per_sec": b / (graph * 1e-3)}
-    out["what"] = ("MatchExtractionWrapper(ShiTomasiSparseBADSinkhornMatcher) forward, float32 frames resident in HBM, "
-                   f"host synchronised after every call, mean of {iters} calls")
+        f1, f2 = img1[:b].contiguous(), img2[:b].contiguous()
+        u1, u2 = torch.from_numpy(a8[:b]).to(img1.device), torch.from_numpy(b8[:b]).to(img1.device)
+        row = {}
+        for name, fn, x, y in (("module", model, f1, f2), ("single_call", one_call, f1, f2), ("single_call_u8", one_call, u1, u2)):
+            eager = timed(lambda: fn(x, y))
+            graphed = GraphedModule(fn, x, y)
+            graph = timed(graphed.graph.replay)
+            row[name] = {"eager_ms": eager, "graph_ms": graph, "eager_pairs_per_sec": b / (eager * 1e-3),
+                         "graph_pairs_per_sec": b / (graph * 1e-3)}
+        out[f"pairs_per_call_{b}"] = row
+    out["what"] = ("MatchExtractionWrapper(ShiTomasiSparseBADSinkhornMatcher), frames resident in HBM, host synchronised "
+                   f"after every call, mean of {iters} calls; forms: see bench.py measure_latency")
     return out
 
 
@@ -486,7 +495,7 @@ def main() -> None:
             records = out[:args.cpu_pairs].cpu().numpy() if 0 < args.cpu_pairs <= B else None
             if not args.no_extras:
                 line["u8_ingest"], line["streamed"] = measure_u8_and_streamed(model, a8, b8, min(args.steps, 100))
-                line["latency"] = measure_latency(model, img1, img2)
+                line["latency"] = measure_latency(model, img1, img2, a8, b8)
             if args.cpu_pairs > 0:
                 line["cpu_baseline"] = cpu_baseline(min(args.cpu_pairs, B), records)
         print(json.dumps(line), flush=True)

@@ -22,6 +22,8 @@ extern "C" {
  * key 4: Sinkhorn band kernel, 0 = probability form, lean instruction stream (default), 2 = first
  * probability-form kernel, 1 = log-domain (max,sum) partials (results agree to fp32 rounding). */
 int mi_debug_set(int key, int value);
+/* top-k kernel phase time stamps (100 MHz clock) of workgroup 0 into `buffer` (8 x uint64, device memory); NULL = off */
+int mi_debug_topk_stamps(void *buffer);
 
 #ifdef __cplusplus
 }

@@ -170,3 +170,13 @@ int mi_topk_keypoints_sets(const uint64_t *cand, const uint32_t *count, int segm
 int mi_sparse_bad_sets(MiSets images, int pix_u8, int n, int h, int w, MiSets keypoints, int k, const uint32_t *pair_geom,
                        const float *pair_thr, int num_pairs, int mode, float temperature, int normalize, float *desc,
                        uint32_t *bits, const void *plan, uint8_t *status, mi_stream_t stream);
+int mi_cost_dots_bits_zeroing(const uint32_t *bits1, const uint32_t *bits2, int batch, int n, int m, int num_bits,
+                              int normalized, uint16_t *dots, int pitch, float *row_info, float *col_info,
+                              void *zero_ptr, size_t zero_bytes, mi_stream_t stream);
+// mi_sinkhorn_dots' single-launch form polls tagged granules that must start out zero: by default it clears them with
+// a memset node of its own; a caller that has them cleared by an earlier kernel of the same call (the region this
+// returns; 0 bytes when the multi-launch form will run) passes prezeroed = 1.
+size_t mi_sinkhorn_dots_handoff_region(void *workspace, int batch, int n, int m, void **region);
+int mi_sinkhorn_dots_impl(const uint16_t *dots, const float *row_info, const float *col_info, int batch, int n, int m,
+                          int pitch, double epsilon, double unused_score, double sqnorm_bound, int iterations, float *u,
+                          float *v, float *p, void *workspace, size_t workspace_bytes, int prezeroed, mi_stream_t stream);

@@ -43,8 +43,17 @@ __global__ __launch_bounds__(256) void cost_bits_kernel(const uint32_t *__restri
                                                         float *__restrict__ z, int pitch,
                                                         uint16_t *__restrict__ dots,
                                                         float2 *__restrict__ row_info,
-                                                        float2 *__restrict__ col_info) {
+                                                        float2 *__restrict__ col_info, uint4 *__restrict__ zero16,
+                                                        size_t zero_count) {
   extern __shared__ uint32_t lds_u[];
+  // side job for mi_match_pairs: clear the next stage's hand-off area (the single-launch Sinkhorn's granule tags),
+  // which saves that stage its own memset node on the one-pair-per-call path; zero_count 16-byte words, all
+  // workgroups share them
+  if (zero_count) {
+    const size_t nthreads = (size_t)gridDim.x * gridDim.y * gridDim.z * 256;
+    const size_t me = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    for (size_t i = me; i < zero_count; i += nthreads) zero16[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
   const int wp = words + 1;                          // +1 word: conflict-free column reads
   uint32_t *sa = lds_u;                              // [128][wp]
   uint32_t *sb = sa + CB_T * wp;                     // [128][wp]
@@ -396,19 +405,20 @@ extern "C" int mi_cost_logscores_bits(const uint32_t *bits1, const uint32_t *bit
   const int words = num_bits / 32;
   const size_t lds = (size_t)2 * CB_T * (words + 1) * 4 + 4 * CB_T * 4;
   dim3 grid(ceil_div(m, CB_T), ceil_div(n, CB_T), batch);
+  uint4 *const no_zero = nullptr;
   hipLaunchKernelGGL(cost_bits_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, bits1, bits2, n, m,
-                     words, normalized, (float)epsilon, z, pitch, nullptr, nullptr, nullptr);
+                     words, normalized, (float)epsilon, z, pitch, nullptr, nullptr, nullptr, no_zero, (size_t)0);
   return mi_launch_status();
 }
 
-extern "C" int mi_cost_dots_bits(const uint32_t *bits1, const uint32_t *bits2, int batch, int n, int m,
-                                 int num_bits, int normalized, uint16_t *dots, int pitch, float *row_info,
-                                 float *col_info, mi_stream_t stream) {
-  MI_ENTER();
+// shared launcher; zero16 / zero_bytes: see cost_bits_kernel's side job (16-byte aligned, a multiple of 16 bytes)
+int mi_cost_dots_bits_zeroing(const uint32_t *bits1, const uint32_t *bits2, int batch, int n, int m, int num_bits,
+                              int normalized, uint16_t *dots, int pitch, float *row_info, float *col_info,
+                              void *zero_ptr, size_t zero_bytes, mi_stream_t stream) {
   if (!bits1 || !bits2 || !dots || !row_info || !col_info) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
   if (pitch < m || pitch % 8 != 0 || ((uintptr_t)dots % 16) != 0 || ((uintptr_t)row_info % 8) != 0 ||
-      ((uintptr_t)col_info % 8) != 0)
+      ((uintptr_t)col_info % 8) != 0 || ((uintptr_t)zero_ptr % 16) != 0 || zero_bytes % 16 != 0)
     return MI_E_ALIGN;
   if (num_bits <= 0 || num_bits % 32 != 0 || num_bits > 4096) return MI_E_PARAM;   // dot <= 4096 fits uint16
   const int words = num_bits / 32;
@@ -418,8 +428,17 @@ extern "C" int mi_cost_dots_bits(const uint32_t *bits1, const uint32_t *bits2, i
   dim3 grid(ceil_div(m, CB_T), ceil_div(n, CB_T), batch);
   hipLaunchKernelGGL(cost_bits_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, bits1, bits2, n, m, words,
                      normalized, 1.0f, nullptr, pitch, dots, reinterpret_cast<float2 *>(row_info),
-                     reinterpret_cast<float2 *>(col_info));
+                     reinterpret_cast<float2 *>(col_info), reinterpret_cast<uint4 *>(zero_ptr),
+                     zero_ptr ? zero_bytes / 16 : (size_t)0);
   return mi_launch_status();
+}
+
+extern "C" int mi_cost_dots_bits(const uint32_t *bits1, const uint32_t *bits2, int batch, int n, int m,
+                                 int num_bits, int normalized, uint16_t *dots, int pitch, float *row_info,
+                                 float *col_info, mi_stream_t stream) {
+  MI_ENTER();
+  return mi_cost_dots_bits_zeroing(bits1, bits2, batch, n, m, num_bits, normalized, dots, pitch, row_info, col_info,
+                                   nullptr, 0, stream);
 }
 
 extern "C" int mi_cost_logscores_f32(const float *desc1, const float *desc2, int batch, int n, int m, int d,

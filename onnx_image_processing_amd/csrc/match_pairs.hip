@@ -163,13 +163,16 @@ int match_pairs_impl(const PIX *image1, const PIX *image2, int batch, int h, int
     }
   }
   // matching/sinkhorn.py:79-208 in the packed (uint16 dot product) form; P is never written
-  if ((e = mi_cost_dots_bits(L.bits1, L.bits2, batch, k, k, pbits, params->normalize_descriptors, L.dots, L.pitch,
-                             L.row_info, L.col_info, stream)) != MI_OK)
+  // (the cost kernel also clears the hand-off area of the single-launch Sinkhorn: one graph node less per call)
+  void *handoff = nullptr;
+  const size_t handoff_bytes = mi_sinkhorn_dots_handoff_region(L.sk_ws, batch, k, k, &handoff);
+  if ((e = mi_cost_dots_bits_zeroing(L.bits1, L.bits2, batch, k, k, pbits, params->normalize_descriptors, L.dots, L.pitch,
+                                     L.row_info, L.col_info, handoff, handoff_bytes, stream)) != MI_OK)
     return e;
   const double sqnorm_bound = params->normalize_descriptors ? 1.0 : (double)pbits;
-  if ((e = mi_sinkhorn_dots(L.dots, L.row_info, L.col_info, batch, k, k, L.pitch, params->epsilon, params->unused_score,
-                            sqnorm_bound, params->sinkhorn_iterations, L.u, L.v, nullptr, L.sk_ws, L.sk_bytes,
-                            stream)) != MI_OK)
+  if ((e = mi_sinkhorn_dots_impl(L.dots, L.row_info, L.col_info, batch, k, k, L.pitch, params->epsilon,
+                                 params->unused_score, sqnorm_bound, params->sinkhorn_iterations, L.u, L.v, nullptr, L.sk_ws,
+                                 L.sk_bytes, handoff_bytes > 0, stream)) != MI_OK)
     return e;
   // matching/match_extraction.py:46-184 straight from the duals
   return mi_mnn_from_duals_dots(L.dots, L.row_info, L.col_info, batch, k, k, L.pitch, params->epsilon, L.u, L.v,

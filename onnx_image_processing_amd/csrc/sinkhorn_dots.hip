@@ -396,19 +396,30 @@ constexpr int SKP_COLS = 520;                    // granules per band row: colum
 constexpr unsigned SKP_SPIN_LIMIT = 1u << 19;
 constexpr size_t SKP_PROF_BYTES = 4096;          // phase time stamps of the development aid (key 8), after the fail word
 
-template <bool FAST>
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations, NOT for its outstanding global
+// memory operations -- __syncthreads() would drain vmcnt first, i.e. stall every wave until the write-through granule
+// stores have been acknowledged and the granule loads in flight have returned (about 1 us each on this path).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <bool FAST, int RW>
 __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restrict__ dots, int n, int m, int pitch,
                                                          const float2 *__restrict__ row_info,
                                                          const float2 *__restrict__ col_info, ZParams zp, int iterations,
                                                          float *__restrict__ u, float *__restrict__ v,
                                                          unsigned long long *gran, unsigned *fail, float log_m,
                                                          float log_n, unsigned long long *prof, int batch) {
-  constexpr int RW = 4, NW = 8, BAND = NW * RW, NT = 64 * NW, NC = 512;
+  constexpr int NW = 8, BAND = NW * RW, NT = 64 * NW, NC = 512;
+  constexpr int MAXB = 512 / BAND;                 // bands of a pair: 16 (RW = 4) or 32 (RW = 2)
+  constexpr int RP = 4;                            // the four-at-a-time wave reductions run on RP rows (padding past RW)
   // development aid (mi_debug_set key 8): band 0 of pair 0 stamps the phases of every iteration (100 MHz clock)
 #define SKP_STAMP(slot) do { if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[it * 8 + (slot)] = wall_clock64(); } while (0)
   __shared__ float red[NW][NC + 1];
   __shared__ float s_w[NC];                      // nie * |b_j|^2 + v_j (-inf past m): the row pass's per-column term
-  __shared__ float s_part[2][NW][2];             // two sets: a barrier separates a set's writes from its reads only once
+  __shared__ float s_part[3][NW][2];             // maxima / sums of compute_un, maxima of reduce_wmax
   __shared__ float s_vd;                         // v_m, the dustbin column's dual
   __shared__ int s_fail;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -455,35 +466,42 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
   if (t == 0) s_vd = 0.0f;
 
   float un = 0.0f, wmax = 0.0f, vd = 0.0f;
-  // State derived from the current v, by every workgroup for itself: wmax = max_j (nie |b_j|^2 + v_j) (bounded-shift
-  // row pass) and u_n = log m - LSE_j(dust + v_j), the dustbin row's dual -- the dustbin band of sk_band_dots_kernel,
-  // operation for operation.  Two barriers; it also publishes s_w / s_vd written just before it.
-  int set = 0;
-  auto derive_state = [&]() {
-    float mx = core0 ? dust + v0 : -INFINITY;
+  // State derived from v, by every workgroup for itself, operation for operation what the dustbin band of
+  // sk_band_dots_kernel and the column kernel's aux maxima compute:
+  //   wmax = max_j (nie |b_j|^2 + v_j): needed by the NEXT row pass (bounded shift) -- one barrier, which also
+  //          publishes the s_w / s_vd / s_fail written just before it;
+  //   u_n  = log m - LSE_j(dust + v_j), the dustbin row's dual: needed only by the column update, so it is computed
+  //          after the granules of the row pass have been published, in the shadow of their flight (two barriers).
+  auto reduce_wmax = [&]() {
     float wm = core0 ? cy0 + v0 : -INFINITY;
-    mx = wave_max_dpp(mx);
     wm = wave_max_dpp(wm);
-    if (lane == 0) { s_part[set][wave][0] = mx; s_part[set][wave][1] = wm; }
-    __syncthreads();
+    if (lane == 0) s_part[2][wave][0] = wm;
+    lds_barrier();
     vd = s_vd;
-    mx = fmaxf(dust + vd, s_part[set][0][0]);
-    wm = s_part[set][0][1];
+    wm = s_part[2][0][0];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) { mx = fmaxf(mx, s_part[set][w][0]); wm = fmaxf(wm, s_part[set][w][1]); }
-    float sum = core0 ? expf((dust + v0) - mx) : 0.0f;
-    sum = wave_sum_dpp(sum);
-    set ^= 1;
-    if (lane == 0) s_part[set][wave][0] = sum;
-    __syncthreads();
-    sum = s_part[set][0][0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) sum += s_part[set][w][0];
-    sum += expf((dust + vd) - mx);
-    un = log_m - (logf(sum) + mx);
+    for (int w = 1; w < NW; ++w) wm = fmaxf(wm, s_part[2][w][0]);
     wmax = wm;
   };
-  derive_state();
+  auto compute_un = [&]() {
+    float mx = core0 ? dust + v0 : -INFINITY;
+    mx = wave_max_dpp(mx);
+    if (lane == 0) s_part[0][wave][0] = mx;
+    lds_barrier();
+    mx = fmaxf(dust + vd, s_part[0][0][0]);
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, s_part[0][w][0]);
+    float sum = core0 ? expf((dust + v0) - mx) : 0.0f;
+    sum = wave_sum_dpp(sum);
+    if (lane == 0) s_part[1][wave][0] = sum;
+    lds_barrier();
+    sum = s_part[1][0][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) sum += s_part[1][w][0];
+    sum += expf((dust + vd) - mx);
+    un = log_m - (logf(sum) + mx);
+  };
+  reduce_wmax();
 
   for (int it = 0; it < iterations; ++it) {
     SKP_STAMP(0);
@@ -501,7 +519,7 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
       for (int q = 0; q < 8; ++q) wq[q] = __builtin_fmaf(wq[q], SKD_L2E, nm_pair);
     }
     // ---- row half (sk_band_dots_kernel's arithmetic)
-    float x[RW][8], mx[RW], xd[RW];
+    float x[RW][8], mx[RP], xd[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
       xd[r] = xd0 - ci[r];
@@ -515,7 +533,9 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
         mx[r] = fmaxf(xd[r], fmaxf(fmaxf(fmaxf(x[r][0], x[r][1]), fmaxf(x[r][2], x[r][3])),
                                    fmaxf(fmaxf(x[r][4], x[r][5]), fmaxf(x[r][6], x[r][7]))));
     }
-    float nm[RW], sr[RW], ed[RW];
+    float nm[RW], sr[RP], ed[RW];
+#pragma unroll
+    for (int r = RW; r < RP; ++r) { sr[r] = 0.0f; mx[r] = -INFINITY; }
     if constexpr (FAST) {
 #pragma unroll
       for (int r = 0; r < RW; ++r) {
@@ -556,7 +576,7 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
 #pragma unroll
     for (int q = 0; q < 8; ++q) red[wave][lane * 8 + q] = colsum[q];
     if (lane == 0) red[wave][NC] = dustcol;
-    __syncthreads();
+    lds_barrier();
     SKP_STAMP(1);
     // ---- publish this band's column sums: one 8-byte {tag, value} granule per column, write-through
     const unsigned tag = (unsigned)it + 1u;
@@ -571,57 +591,52 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
     if (core0) publish(t, t);
     if (t == 0) publish(NC, m);                               // the dustbin column's sum sits at red[.][NC]
     SKP_STAMP(4);
-    // ---- column half, by every workgroup for all columns (sk_vcombine_dots_kernel's arithmetic): gather the bands'
-    // granules of a column (all loads of a sweep in flight together) and add them in band order
-    // thread t gathers column t; thread 0 also gathers column m when m == NT (own1), its loads in flight together
-    // with the first column's
+    // ---- column half, by every workgroup for all columns (sk_vcombine_dots_kernel's arithmetic).  Thread t gathers
+    // the bands' granules of column t (thread 0 also column m when m == NT), all loads of a sweep in flight
+    // together; late bands are polled again.
     float ssum0 = 0.0f, ssum1 = 0.0f;
-    if (own0) {
+    unsigned long long g[MAXB], g1[MAXB];
+    auto sweep = [&]() {
       const unsigned long long *gcol = gbuf + t;
-      float part[16], part1[16];
-      bool ok = false;
-      for (unsigned spins = 0; !ok; ++spins) {
-        unsigned long long g[16], g1[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-          g[k] = (k < nb) ? __hip_atomic_load(gcol + (size_t)k * SKP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                          : ((unsigned long long)tag << 32);
-        if (own1) {
-#pragma unroll
-          for (int k = 0; k < 16; ++k)
-            g1[k] = (k < nb) ? __hip_atomic_load(gbuf + m + (size_t)k * SKP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                             : ((unsigned long long)tag << 32);
-        }
-        ok = true;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          ok = ok && (unsigned)(g[k] >> 32) == tag;
-          part[k] = __uint_as_float((unsigned)g[k]);
-        }
-        if (own1) {
-#pragma unroll
-          for (int k = 0; k < 16; ++k) {
-            ok = ok && (unsigned)(g1[k] >> 32) == tag;
-            part1[k] = __uint_as_float((unsigned)g1[k]);
-          }
-        }
-        if (!ok) {
-          if (spins > SKP_SPIN_LIMIT) {                       // a band never arrived: give up, flag it, leave
-            s_fail = 1;
-            __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 16; ++k)
-        if (k < nb) ssum0 += part[k];                          // band order, as sk_vcombine_dots_kernel adds them
+      for (int k = 0; k < MAXB; ++k)
+        g[k] = (k < nb && own0) ? __hip_atomic_load(gcol + (size_t)k * SKP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : ((unsigned long long)tag << 32);
       if (own1) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k < nb) ssum1 += part1[k];
+        for (int k = 0; k < MAXB; ++k)
+          g1[k] = (k < nb) ? __hip_atomic_load(gbuf + m + (size_t)k * SKP_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                           : ((unsigned long long)tag << 32);
       }
+    };
+    // u_n first (LDS barriers only: about the time the write-through stores need to become visible), then the sweep:
+    // a sweep issued too early finds stale tags and costs a whole extra round trip
+    compute_un();
+    sweep();
+    for (unsigned spins = 0;; ++spins) {
+      bool ok = true;
+#pragma unroll
+      for (int k = 0; k < MAXB; ++k) ok = ok && (unsigned)(g[k] >> 32) == tag;
+      if (own1) {
+#pragma unroll
+        for (int k = 0; k < MAXB; ++k) ok = ok && (unsigned)(g1[k] >> 32) == tag;
+      }
+      if (ok) break;
+      if (spins > SKP_SPIN_LIMIT) {                           // a band never arrived: give up, flag it, leave
+        s_fail = 1;
+        __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+      sweep();
+    }
+#pragma unroll
+    for (int k = 0; k < MAXB; ++k)
+      if (k < nb) ssum0 += __uint_as_float((unsigned)g[k]);    // band order, as sk_vcombine_dots_kernel adds them
+    if (own1) {
+#pragma unroll
+      for (int k = 0; k < MAXB; ++k)
+        if (k < nb) ssum1 += __uint_as_float((unsigned)g1[k]);
     }
     auto column_update = [&](float ssum, float vold, bool dustbin_col) -> float {
       const float bj = (dust + un) + vold;                     // the dustbin row's log-probability
@@ -641,7 +656,7 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
     }
     SKP_STAMP(2);
     if (it == iterations - 1) {
-      __syncthreads();
+      lds_barrier();
       if (s_fail) return;
       if (band == 0) {
         if (own0) v[(size_t)b * (m + 1) + t] = v0;
@@ -650,7 +665,7 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
       }
       return;
     }
-    derive_state();                                            // (its first barrier publishes s_w / s_vd / s_fail)
+    reduce_wmax();                                             // (its barrier publishes s_w / s_vd / s_fail)
     if (s_fail) return;                                        // uniform: every thread reads it after a barrier
     SKP_STAMP(3);
   }
@@ -763,6 +778,10 @@ int dots_cpitch(int m) { return m <= 512 ? 512 : 1024; }
 
 // single-launch form: two granule buffers of nb band rows per pair, then the fail word (16 bytes reserved)
 bool persist_shape(int batch, int n, int m) { return batch <= SKP_MAX_BATCH && n <= 512 && m <= 512; }
+// Rows per wave of the single-launch kernel.  4 = the multi-launch kernel's banding, which its column sums must share
+// to come out bit-identical (a band's column sum is an fma chain over its rows: 16-row bands -- twice the workgroups,
+// half the row pass -- were measured 0.5 us per iteration faster but round differently).
+int persist_rows_per_wave(int) { return 4; }
 size_t persist_granule_bytes(int batch, int n) {
   return 2 * (size_t)batch * (size_t)ceil_div(n, 32) * SKP_COLS * sizeof(unsigned long long);
 }
@@ -789,11 +808,24 @@ extern "C" int mi_release_stream_resources(mi_stream_t stream) {
   return MI_OK;
 }
 
+size_t mi_sinkhorn_dots_handoff_region(void *workspace, int batch, int n, int m, void **region) {
+  if (!persist_shape(batch, n, m) || mi_g_sinkhorn_persist.load(std::memory_order_relaxed) == 0) return 0;
+  *region = reinterpret_cast<char *>(workspace) + dots_base_bytes(batch, n, m);
+  return persist_granule_bytes(batch, n) + 16;
+}
+
 extern "C" int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch,
                                 int n, int m, int pitch, double epsilon, double unused_score, double sqnorm_bound,
                                 int iterations, float *u, float *v, float *p, void *workspace, size_t workspace_bytes,
                                 mi_stream_t stream) {
   MI_ENTER();
+  return mi_sinkhorn_dots_impl(dots, row_info, col_info, batch, n, m, pitch, epsilon, unused_score, sqnorm_bound,
+                               iterations, u, v, p, workspace, workspace_bytes, 0, stream);
+}
+
+int mi_sinkhorn_dots_impl(const uint16_t *dots, const float *row_info, const float *col_info, int batch, int n, int m,
+                          int pitch, double epsilon, double unused_score, double sqnorm_bound, int iterations, float *u,
+                          float *v, float *p, void *workspace, size_t workspace_bytes, int prezeroed, mi_stream_t stream) {
   if (!dots || !row_info || !col_info || !u || !v || !workspace) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
   if (pitch < m || pitch % 8 != 0 || ((uintptr_t)dots % 16) != 0 || ((uintptr_t)workspace % 16) != 0) return MI_E_ALIGN;
@@ -821,19 +853,20 @@ extern "C" int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, con
     // single-launch form: zero the granule tags and the fail word (one memset node), then one kernel
     char *gbase = reinterpret_cast<char *>(workspace) + dots_base_bytes(batch, n, m);
     const size_t gbytes = persist_granule_bytes(batch, n);
-    hipError_t me = hipMemsetAsync(gbase, 0, gbytes + 16, s);
-    if (me != hipSuccess) return (int)me;
+    if (!prezeroed) {
+      hipError_t me = hipMemsetAsync(gbase, 0, gbytes + 16, s);
+      if (me != hipSuccess) return (int)me;
+    }
     unsigned long long *gran = reinterpret_cast<unsigned long long *>(gbase);
     unsigned *failw = reinterpret_cast<unsigned *>(gbase + gbytes);
     unsigned long long *prof = mi_g_sinkhorn_stamps.load(std::memory_order_relaxed) && iterations * 64 <= (int)SKP_PROF_BYTES
                                    ? reinterpret_cast<unsigned long long *>(gbase + gbytes + 16) : nullptr;
-    const dim3 grid(8 * ceil_div(n, 32) * ceil_div(batch, 8));
-    if (fast)
-      hipLaunchKernelGGL(sk_persist_kernel<true>, grid, dim3(512), 0, s, dots, n, m, pitch, ri, ci, zp, iterations, u, v,
-                         gran, failw, log_m, log_n, prof, batch);
-    else
-      hipLaunchKernelGGL(sk_persist_kernel<false>, grid, dim3(512), 0, s, dots, n, m, pitch, ri, ci, zp, iterations, u, v,
-                         gran, failw, log_m, log_n, prof, batch);
+    const int rw = persist_rows_per_wave(batch);
+    const dim3 grid(8 * ceil_div(n, 8 * rw) * ceil_div(batch, 8));
+#define SKP_LAUNCH(FAST, RW) hipLaunchKernelGGL((sk_persist_kernel<FAST, RW>), grid, dim3(512), 0, s, dots, n, m, pitch, ri, ci, zp, iterations, u, v, gran, failw, log_m, log_n, prof, batch)
+    if (fast) { if (rw == 2) SKP_LAUNCH(true, 2); else SKP_LAUNCH(true, 4); }
+    else { if (rw == 2) SKP_LAUNCH(false, 2); else SKP_LAUNCH(false, 4); }
+#undef SKP_LAUNCH
     MI_CHECK_LAUNCH();
     if (p)
       hipLaunchKernelGGL(sk_exp_dots_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, dots, n, m, pitch, ri, ci,

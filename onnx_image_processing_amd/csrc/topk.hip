@@ -122,7 +122,10 @@ __device__ __forceinline__ void bitonic_sort_desc_4096(uint64_t *keys, uint64_t 
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__restrict__ cand,
                                                           const uint32_t *__restrict__ count, int segments,
                                                           uint32_t seg_cap, int w, int k, MiSets kpt_sets,
-                                                          float *__restrict__ kscores, int select_mode) {
+                                                          float *__restrict__ kscores, int select_mode,
+                                                          unsigned long long *prof) {
+#define TK_STAMP(i) do { if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[i] = wall_clock64(); } while (0)
+  TK_STAMP(0);
   __shared__ uint64_t keys[TK_MAX];
   __shared__ uint64_t keys2[TK_MAX];      // second buffer of the register sort's cross-wave stages
   __shared__ uint32_t seg_cnt[TK_SEGS], seg_base[TK_SEGS];
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
 #pragma unroll
   for (int q = 0; q < TK_WAVES; ++q) n += wsum[q];
   int nsel;
+  TK_STAMP(1);
 
   if (n <= (uint32_t)TK_MAX && slots) {
     // gather: a wave takes four segments at a time, all their loads in flight before the first LDS store
@@ -182,6 +186,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
     int npad = 2;
     while (npad < (int)n) npad <<= 1;
     __syncthreads();
+    TK_STAMP(2);
     if (select_mode && n > (uint32_t)k && 4 * k <= TK_MAX) {
       // Far fewer keys are wanted than there are candidates (512 of ~3300 at 640x480): find the k-th largest key
       // by MSB radix select on register copies of the LDS keys (at most 8 passes of 8 bits, typically 4: the
@@ -242,6 +247,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
         if (s_done) break;                // workgroup-uniform
       }
       const uint64_t kth = s_prefix;      // keys are distinct: exactly k keys are >= kth
+      TK_STAMP(3);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (r[q] != 0ull && r[q] >= kth) {
@@ -254,28 +260,58 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
       while (kpad < k) kpad <<= 1;
       for (int i = nsel + t; i < kpad; i += TK_THREADS) keys2[i] = 0ull;
       __syncthreads();
-      if (kpad <= TK_THREADS) {
-        // Rank sort of the <= 1024 winners: the keys are distinct, so a key's place in the descending order is the
-        // number of keys greater than it.  TK_THREADS / kpad threads share one key, each counting over its share of
-        // the list; every lane of a wave reads the same list entry (an LDS broadcast), so the inner loop is a load,
-        // a 64-bit compare and an add -- no barrier per stage as in the bitonic network (45 stages for 512 keys).
+      TK_STAMP(4);
+      if (kpad >= 128 && kpad <= TK_THREADS) {
+        // Merge-rank sort of the <= 1024 winners, two barriers instead of the bitonic network's 45 stages:
+        //  1. every wave sorts one group of 64 keys in registers (21 shuffle stages, descending; padding zeros last);
+        //  2. a key's place in the final order = its place in its own group + for every other group the number of
+        //     that group's keys above it, found by a 6-step binary search in the sorted group (keys are distinct).
         // Same result: the descending order of distinct keys is unique.
-        const int per_key = TK_THREADS / kpad;                 // 1, 2, 4, ... threads per key
-        const int idx = t & (kpad - 1), part = t / kpad;
-        const uint64_t mine = keys2[idx];
-        const int span = (nsel + per_key - 1) / per_key;
-        const int j0 = part * span, j1 = min(j0 + span, nsel);
-        uint32_t rank = 0;
-        for (int j = j0; j < j1; ++j) rank += keys2[j] > mine ? 1u : 0u;
-        uint32_t *ranks = reinterpret_cast<uint32_t *>(keys);  // kpad counters per part; `keys` is free here
-        ranks[part * kpad + idx] = rank;
-        __syncthreads();
-        uint32_t total = 0;
-        if (part == 0 && idx < nsel) {
-          for (int q = 0; q < per_key; ++q) total += ranks[q * kpad + idx];
+        const int groups = kpad >> 6;
+        uint64_t mine = 0ull;
+        if (wave < groups) {
+          mine = keys2[wave * 64 + lane];
+#pragma unroll
+          for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+              const uint64_t other = __shfl_xor(mine, stride, 64);
+              const bool desc = (lane & size) == 0;                 // size == 64: every lane, i.e. descending
+              const bool lower = (lane & stride) == 0;
+              const uint64_t hi = mine > other ? mine : other, lo = mine > other ? other : mine;
+              mine = (lower == desc) ? hi : lo;
+            }
+          }
         }
-        __syncthreads();                                        // every counter is read before `keys` is rewritten
-        if (part == 0 && idx < nsel) keys[total] = mine;
+        __syncthreads();                                            // every wave has read its unsorted group
+        if (wave < groups) keys2[wave * 64 + lane] = mine;
+        __syncthreads();
+        if (wave < groups && mine != 0ull) {
+          uint32_t rank = (uint32_t)lane;
+          for (int h0 = 0; h0 < groups; h0 += 8) {                  // eight groups' searches interleaved
+            uint32_t lo[8], hi[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { lo[q] = 0u; hi[q] = 64u; }
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+              uint64_t probe[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const int h = h0 + q;
+                probe[q] = (h < groups && h != wave) ? keys2[h * 64 + ((lo[q] + hi[q]) >> 1)] : 0ull;
+              }
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const uint32_t mid = (lo[q] + hi[q]) >> 1;
+                if (probe[q] > mine) lo[q] = mid + 1u; else hi[q] = mid;
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              if (h0 + q < groups && h0 + q != wave) rank += lo[q];
+          }
+          keys[rank] = mine;
+        }
         __syncthreads();
       } else {
         bitonic_sort_desc(keys2, kpad, t);
@@ -393,6 +429,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
     bitonic_sort_desc(keys, npad, t);
   }
 
+  TK_STAMP(5);
   float *kpts = const_cast<float *>(mi_set_item<float>(kpt_sets, img, (size_t)k * 2));
   for (int j = t; j < k; j += TK_THREADS) {
     float y = -1.0f, x = -1.0f, s = 0.0f;
@@ -407,7 +444,13 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
     kpts[(size_t)j * 2 + 1] = x;
     kscores[(size_t)img * k + j] = s;
   }
+  TK_STAMP(6);
+#undef TK_STAMP
 }
+
+// development aid (mi_debug_set key 10 = address of a device buffer's low 32 bits is not expressible; instead the
+// stamps go to a buffer registered through mi_debug_topk_stamps)
+unsigned long long *g_topk_prof = nullptr;
 
 }  // namespace
 
@@ -418,8 +461,16 @@ int mi_topk_keypoints_sets(const uint64_t *cand, const uint32_t *count, int segm
   if (k <= 0 || k > TK_MAX) return MI_E_PARAM;
   if (segment_capacity <= 0) return MI_E_CAPACITY;
   hipLaunchKernelGGL(topk_kernel, dim3(n), dim3(TK_THREADS), 0, (hipStream_t)stream, cand, count, segments,
-                     (uint32_t)segment_capacity, w, k, keypoints, kscores, mi_g_topk_select.load(std::memory_order_relaxed));
+                     (uint32_t)segment_capacity, w, k, keypoints, kscores, mi_g_topk_select.load(std::memory_order_relaxed),
+                     g_topk_prof);
   return mi_launch_status();
+}
+
+// development aid (include/mi355x_match_debug.h): phase time stamps of workgroup 0 go to `buffer` (8 x u64, device
+// memory) on every later launch; NULL switches them off
+extern "C" int mi_debug_topk_stamps(void *buffer) {
+  g_topk_prof = reinterpret_cast<unsigned long long *>(buffer);
+  return MI_OK;
 }
 
 extern "C" int mi_topk_keypoints(const uint64_t *cand, const uint32_t *count, int segments,

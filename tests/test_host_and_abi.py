@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib_path):
 def test_binding_covers_the_header(lib_path):
     from onnx_image_processing_amd import _native
     assert sorted(_native.SIGNATURES) == header_functions()
-    assert sorted(_native.DEBUG_SIGNATURES) == header_functions(DEBUG_HEADER) == ["mi_debug_set"]
+    assert sorted(_native.DEBUG_SIGNATURES) == header_functions(DEBUG_HEADER) == ["mi_debug_set", "mi_debug_topk_stamps"]
     _native.load()
 
 
