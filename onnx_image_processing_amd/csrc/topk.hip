@@ -265,7 +265,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
         // Merge-rank sort of the <= 1024 winners, two barriers instead of the bitonic network's 45 stages:
         //  1. every wave sorts one group of 64 keys in registers (21 shuffle stages, descending; padding zeros last);
         //  2. a key's place in the final order = its place in its own group + for every other group the number of
-        //     that group's keys above it, found by a 6-step binary search in the sorted group (keys are distinct).
+        //     that group's keys above it, found by a 7-step binary search in the sorted group (keys are distinct).
         // Same result: the descending order of distinct keys is unique.
         const int groups = kpad >> 6;
         uint64_t mine = 0ull;
@@ -293,17 +293,17 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
 #pragma unroll
             for (int q = 0; q < 8; ++q) { lo[q] = 0u; hi[q] = 64u; }
 #pragma unroll
-            for (int step = 0; step < 6; ++step) {
+            for (int step = 0; step < 7; ++step) {                   // 65 possible answers (0..64)
               uint64_t probe[8];
 #pragma unroll
               for (int q = 0; q < 8; ++q) {
                 const int h = h0 + q;
-                probe[q] = (h < groups && h != wave) ? keys2[h * 64 + ((lo[q] + hi[q]) >> 1)] : 0ull;
+                probe[q] = (h < groups && h != wave && lo[q] < hi[q]) ? keys2[h * 64 + ((lo[q] + hi[q]) >> 1)] : 0ull;
               }
 #pragma unroll
               for (int q = 0; q < 8; ++q) {
                 const uint32_t mid = (lo[q] + hi[q]) >> 1;
-                if (probe[q] > mine) lo[q] = mid + 1u; else hi[q] = mid;
+                if (lo[q] < hi[q]) { if (probe[q] > mine) lo[q] = mid + 1u; else hi[q] = mid; }
               }
             }
 #pragma unroll
