@@ -283,6 +283,14 @@ int mi_mnn_from_duals_dots(const uint16_t *dots, const float *row_info, const fl
  *   sampling the combined map the way descriptor/bad.py:487-500 does. */
 int mi_akaze_diffuse(const float *l_in, int n, int h, int w, float kappa, float dt, float *l_out,
                      mi_stream_t stream);
+/* One scale of AKAZE.forward (akaze.py:430-440) in one launch: l_out = `iterations` diffusion steps of l_in,
+ * scores = mi_akaze_hessian_scores(l_out); identical maps, 12 instead of 8 * iterations + 8 bytes per pixel of HBM
+ * traffic (the steps run on an LDS-resident tile).  Fused for iterations 1..3 and nms_size 3 / 5 / 7
+ * (mi_akaze_scale_fused returns 1); other values run the per-step kernels and then need `tmp` (n*h*w floats) when
+ * iterations > 1.  l_out must not alias l_in. */
+int mi_akaze_scale_fused(int iterations, int nms_size);
+int mi_akaze_scale(const float *l_in, int n, int h, int w, int iterations, float kappa, float dt, float threshold,
+                   int nms_size, float *l_out, float *scores, float *tmp, mi_stream_t stream);
 int mi_akaze_hessian_scores(const float *l, int n, int h, int w, float threshold, int nms_size, float *scores,
                             mi_stream_t stream);
 int mi_akaze_combine(const float *scale_scores, const float *scale_orientations, int num_scales, int n, int h,

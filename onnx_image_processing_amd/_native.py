@@ -70,6 +70,9 @@ SIGNATURES = {
     "mi_fast_score": [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
     "mi_dog_responses": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mi_akaze_diffuse": [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p],
+    "mi_akaze_scale_fused": [c_int, c_int],
+    "mi_akaze_scale": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                       c_void_p],
     "mi_akaze_hessian_scores": [c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     "mi_akaze_combine": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mi_akaze_orientation_at_keypoints": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,

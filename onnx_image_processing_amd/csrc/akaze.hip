@@ -172,6 +172,20 @@ __global__ __launch_bounds__(256) void combine_kernel(const float *__restrict__ 
   oris[i] = acc;
 }
 
+// scores only (what the matchers need: the orientation is evaluated at the keypoints), four pixels per thread with
+// 16-byte loads: (S + 1) * 4 bytes per pixel, HBM-bound
+__global__ __launch_bounds__(256) void combine_scores4_kernel(const float4 *__restrict__ scores_s, int nscales,
+                                                              size_t plane4, float4 *__restrict__ scores) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= plane4) return;
+  float4 mx = scores_s[i];
+  for (int s = 1; s < nscales; ++s) {
+    const float4 v = scores_s[(size_t)s * plane4 + i];
+    mx.x = fmaxf(mx.x, v.x); mx.y = fmaxf(mx.y, v.y); mx.z = fmaxf(mx.z, v.z); mx.w = fmaxf(mx.w, v.w);
+  }
+  scores[i] = mx;
+}
+
 // the same selection, only at the keypoints: scores_s (S,n,h,w), theta_s (S,n,k) -> theta (n,k)
 __global__ __launch_bounds__(256) void combine_kp_kernel(const float *__restrict__ scores_s,
                                                          const float *__restrict__ theta_s, int nscales, int n,
@@ -200,6 +214,176 @@ __global__ __launch_bounds__(256) void combine_kp_kernel(const float *__restrict
     acc += theta_s[(size_t)s * n * k + flat] * m;
   }
   theta[flat] = acc;
+}
+
+// ---- one launch per scale: ITERS diffusion steps, the Hessian response and its NMS on one LDS-resident tile -----
+// The per-step form above moves 8 B/px through HBM per diffusion step and 8 more for the Hessian pass (32 B/px per
+// scale, 4 launches); here an output tile is staged once with a halo of 2*ITERS + 1 + NH pixels, the steps run
+// in place in LDS (each step's valid region shrinks by 2: gradients need one ring, the divergence of the flux
+// another), the diffused tile is written once and the Hessian determinant + window-equality NMS are evaluated on the
+// tile still in LDS: 12 B/px per scale (read L, write L, write scores), one launch.  The halo is recomputed per tile
+// (about 1.5x the arithmetic), every expression is the per-step kernels' (same operation order), so the maps equal
+// theirs bit for bit.
+constexpr int AS_H = 32;                 // output tile height; its width is 64 - 2 * halo (see the kernel)
+
+// Correctly rounded fp32 sqrt and division for the operand ranges of the diffusion step (normal, finite, far from
+// overflow: |g| <= ~255, kappa and 1 + q^2 >= 1e-4), i.e. the compiler's IEEE expansions without their denormal
+// scaling and special-case fix-ups: v_sqrt_f32 / v_rcp_f32 (1 ulp) + exact fma residuals.  Same results as
+// sqrtf() and operator/ on these ranges (asserted against the per-step kernels, which use those, bit for bit).
+__device__ __forceinline__ float ak_sqrt(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float lo = __uint_as_float(__float_as_uint(s) - 1u), hi = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rl = __builtin_fmaf(-lo, s, x), rh = __builtin_fmaf(-hi, s, x);
+  float r = (rl <= 0.0f) ? lo : s;
+  r = (rh > 0.0f) ? hi : r;
+  return r;
+}
+__device__ __forceinline__ float ak_div(float a, float b) {
+  float y = __builtin_amdgcn_rcpf(b);
+  const float e = __builtin_fmaf(-b, y, 1.0f);
+  y = __builtin_fmaf(e, y, y);                       // reciprocal to < 1 ulp
+  float q = a * y;
+  float r = __builtin_fmaf(-b, q, a);                // exact residual
+  q = __builtin_fmaf(r, y, q);
+  r = __builtin_fmaf(-b, q, a);                      // second correction: the compiler's own sequence
+  return __builtin_fmaf(r, y, q);                    // (v_div_fmas without the scaling)
+}
+
+template <int ITERS, int NH>
+__global__ __launch_bounds__(256) void akaze_scale_kernel(const float *__restrict__ lin, int h, int w, float kappa,
+                                                          float dt, float threshold, float *__restrict__ lout,
+                                                          float *__restrict__ scores, int tiles_x, int tiles_y) {
+  constexpr int HALO = 2 * ITERS + 1 + NH;
+  // the staged tile is exactly one wave wide (64 columns: every row operation uses all 64 lanes, one row per wave
+  // instruction, no index arithmetic), so the OUTPUT tile is 64 - 2 * HALO columns wide
+  constexpr int TW = 64 - 2 * HALO;
+  constexpr int LW = 64, LH = AS_H + 2 * HALO;
+  __shared__ float L[LH][LW];              // the image tile, zero outside the image (both convolutions zero-pad)
+  __shared__ float FX[LH][LW], FY[LH][LW]; // the flux (same coordinates); later the response and its row maxima
+  int bid = (int)blockIdx.x;
+  const int txi = bid % tiles_x;
+  bid /= tiles_x;
+  const int tyi = bid % tiles_y;
+  const int img = bid / tiles_y;
+  const int x0 = txi * TW - HALO, y0 = tyi * AS_H - HALO;            // global coordinates of L[0][0]
+  const float *src = lin + (size_t)img * h * w;
+  // thread = (column tx, row group ty): a wave handles one staged row per instruction, rows ty, ty + 4, ...
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  // the image rows / columns the tile covers, in tile coordinates: [ry0, ry1) x [cx0, cx1) lies inside the image
+  const int ry0 = max(0, -y0), ry1 = min(LH, h - y0), cx0 = max(0, -x0), cx1 = min(LW, w - x0);
+  for (int r = ty; r < LH; r += 4) {
+    const bool rin = r >= ry0 && r < ry1;
+    const float *row = src + (size_t)(y0 + r) * w + x0;
+    L[r][tx] = (rin && tx >= cx0 && tx < cx1) ? row[tx] : 0.0f;
+  }
+  __syncthreads();
+  // Row blocks: every phase hands each of the 4 waves a contiguous block of rows and walks down it with the rows
+  // above and below in registers (3 new LDS reads per flux value instead of 8, 5 + 1 per update instead of 12 + 1),
+  // the next row's loads issued before the current row's arithmetic.
+  const int c = tx;
+#pragma unroll
+  for (int s = 0; s < ITERS; ++s) {
+    // flux on rows / columns [2s+1, L? - 2s - 1): needs L one ring further out
+    {
+      const int f0 = 2 * s + 1, nrows = LH - 2 * f0, per = (nrows + 3) / 4;
+      const int rbeg = f0 + ty * per, rend = min(rbeg + per, LH - f0);
+      if (c >= f0 && c < LW - f0 && rbeg < rend) {
+        const bool cin = c >= cx0 && c < cx1;
+        float t0 = L[rbeg - 1][c - 1], t1 = L[rbeg - 1][c], t2 = L[rbeg - 1][c + 1];
+        float m0 = L[rbeg][c - 1], m2 = L[rbeg][c + 1];
+        float b0 = L[rbeg + 1][c - 1], b1 = L[rbeg + 1][c], b2 = L[rbeg + 1][c + 1];
+        for (int r = rbeg; r < rend; ++r) {
+          float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
+          if (r + 1 < rend) { n0 = L[r + 2][c - 1]; n1 = L[r + 2][c]; n2 = L[r + 2][c + 1]; }   // next row, early
+          float fx = 0.0f, fy = 0.0f;
+          if (cin && r >= ry0 && r < ry1) {                                // the flux is zero-padded outside the image
+            const float gxv = (((((t2 - t0) - 2.0f * m0) + 2.0f * m2) - b0) + b2) * 0.125f;          // akaze.py:50-63,82
+            const float gyv = ((((((-t0) - 2.0f * t1) - t2) + b0) + 2.0f * b1) + b2) * 0.125f;
+            const float mag = ak_sqrt(gxv * gxv + gyv * gyv + 1e-8f);                             // :116
+            const float q = ak_div(mag, kappa);
+            const float cond = ak_div(1.0f, 1.0f + q * q);                                        // :96
+            fx = cond * gxv;
+            fy = cond * gyv;
+          }
+          FX[r][c] = fx;
+          FY[r][c] = fy;
+          t0 = m0; t2 = m2;
+          t1 = L[r][c];                                 // (the centre of the row that becomes the top row)
+          m0 = b0; m2 = b2;
+          b0 = n0; b1 = n1; b2 = n2;
+        }
+      }
+    }
+    __syncthreads();
+    // L += dt * div(flux) on rows / columns [2s+2, L? - 2s - 2), in place (only pixels of the image evolve)
+    {
+      const int u0 = 2 * s + 2, nrows = LH - 2 * u0, per = (nrows + 3) / 4;
+      const int rbeg = max(u0 + ty * per, ry0), rend = min(min(u0 + (ty + 1) * per, LH - u0), ry1);
+      if (c >= max(u0, cx0) && c < min(LW - u0, cx1) && rbeg < rend) {
+        float xt0 = FX[rbeg - 1][c - 1], xt2 = FX[rbeg - 1][c + 1];
+        float yt0 = FY[rbeg - 1][c - 1], yt1 = FY[rbeg - 1][c], yt2 = FY[rbeg - 1][c + 1];
+        float xm0 = FX[rbeg][c - 1], xm2 = FX[rbeg][c + 1];
+        float ym0 = FY[rbeg][c - 1], ym1 = FY[rbeg][c], ym2 = FY[rbeg][c + 1];
+        for (int r = rbeg; r < rend; ++r) {
+          const float xb0 = FX[r + 1][c - 1], xb2 = FX[r + 1][c + 1];
+          const float yb0 = FY[r + 1][c - 1], yb1 = FY[r + 1][c], yb2 = FY[r + 1][c + 1];
+          const float lc = L[r][c];
+          const float dx = (((((xt2 - xt0) - 2.0f * xm0) + 2.0f * xm2) - xb0) + xb2) * 0.125f;       // :125-126
+          const float dy = ((((((-yt0) - 2.0f * yt1) - yt2) + yb0) + 2.0f * yb1) + yb2) * 0.125f;
+          L[r][c] = lc + dt * (dx + dy);                                                        // :129
+          xt0 = xm0; xt2 = xm2; yt0 = ym0; yt1 = ym1; yt2 = ym2;
+          xm0 = xb0; xm2 = xb2; ym0 = yb0; ym1 = yb1; ym2 = yb2;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // the diffused tile (AS_W = 64 columns: one column chunk) and the Hessian determinant on the tile + NH (into FX;
+  // -inf outside the image: the pool's padding)
+  for (int r = HALO + ty; r < min(HALO + AS_H, ry1); r += 4) {
+    const int c = tx;
+    if (c >= HALO && c < HALO + TW && c < cx1) lout[((size_t)img * h + (y0 + r)) * w + (x0 + c)] = L[r][c];
+  }
+  constexpr int R0 = 2 * ITERS + 1;
+#pragma unroll 2
+  for (int r = R0 + ty; r < LH - R0; r += 4) {
+    const bool rin = r >= ry0 && r < ry1;
+    {
+      const int c = tx;
+      if (c < R0 || c >= LW - R0) continue;
+      float resp = -INFINITY;
+      if (rin && c >= cx0 && c < cx1) {
+        const float a = L[r - 1][c - 1], b = L[r - 1][c], cc = L[r - 1][c + 1], d = L[r][c - 1], e = L[r][c],
+                    f = L[r][c + 1], g = L[r + 1][c - 1], hh = L[r + 1][c], k = L[r + 1][c + 1];
+        const float lxx = ((((((((a - 2.0f * b) + cc) + 2.0f * d) - 4.0f * e) + 2.0f * f) + g) - 2.0f * hh) + k) * 0.0625f;
+        const float lyy = ((((((((a + 2.0f * b) + cc) - 2.0f * d) - 4.0f * e) - 2.0f * f) + g) + 2.0f * hh) + k) * 0.0625f;
+        const float lxy = (((a - cc) - g) + k) * 0.25f;
+        resp = lxx * lyy - lxy * lxy;                                                          // :196
+      }
+      FX[r][c] = resp;
+    }
+  }
+  __syncthreads();
+  // window maximum, separable: along the rows (tile columns only), then down the columns
+  for (int r = R0 + ty; r < LH - R0; r += 4) {
+    const int c = tx;
+    if (c < HALO || c >= HALO + TW) continue;
+    float mx = FX[r][c - NH];
+#pragma unroll
+    for (int d = 1; d <= 2 * NH; ++d) mx = fmaxf(mx, FX[r][c - NH + d]);
+    FY[r][c] = mx;
+  }
+  __syncthreads();
+  for (int r = HALO + ty; r < min(HALO + AS_H, ry1); r += 4) {
+    const int c = tx;
+    if (c < HALO || c >= HALO + TW || c >= cx1) continue;
+    const float resp = FX[r][c];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int d = -NH; d <= NH; ++d) mx = fmaxf(mx, FY[r + d][c]);
+    const float keep = (resp == mx && resp > threshold) ? 1.0f : 0.0f;                       // :223,:245
+    scores[((size_t)img * h + (y0 + r)) * w + (x0 + c)] = fmaxf(resp * keep, 0.0f);          // :249-252
+  }
 }
 
 int grid_for(int n, int h, int w, int &tiles_x, int &tiles_y) {
@@ -249,6 +433,14 @@ extern "C" int mi_akaze_combine(const float *scale_scores, const float *scale_or
   if (orientations && !scale_orientations) return MI_E_NULL;
   if (num_scales <= 0 || n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
   const size_t plane = (size_t)n * h * w;
+  if (!orientations && plane % 4 == 0 && ((uintptr_t)scale_scores | (uintptr_t)scores) % 16 == 0) {
+    const size_t plane4 = plane / 4, blocks4 = (plane4 + 255) / 256;
+    if (blocks4 > 0x7fffffffULL) return MI_E_SHAPE;
+    hipLaunchKernelGGL(combine_scores4_kernel, dim3((unsigned)blocks4), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(scale_scores), num_scales, plane4,
+                       reinterpret_cast<float4 *>(scores));
+    return mi_launch_status();
+  }
   const size_t blocks = (plane + 255) / 256;
   if (blocks > 0x7fffffffULL) return MI_E_SHAPE;
   hipLaunchKernelGGL(combine_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, scale_scores,
@@ -265,4 +457,45 @@ extern "C" int mi_akaze_orientation_at_keypoints(const float *scale_scores, cons
   hipLaunchKernelGGL(combine_kp_kernel, dim3(ceil_div(n * k, 256)), dim3(256), 0, (hipStream_t)stream, scale_scores,
                      scale_theta, num_scales, n, h, w, keypoints, k, theta);
   return mi_launch_status();
+}
+
+// ---- AKAZE.forward's per-scale body in one launch (akaze.py:430-440): l_out = NonLinearDiffusion(l_in) with
+// `iterations` steps, scores = HessianDetector(l_out).  Fused for iterations 1..3 and nms_size 3 / 5 / 7 (the
+// reference's defaults are 3 and 5); other values run the per-step kernels through a scratch image `tmp` (n*h*w
+// floats, only needed then; may be NULL when the fused form applies -- mi_akaze_scale_fused says which).
+extern "C" int mi_akaze_scale_fused(int iterations, int nms_size) {
+  return iterations >= 1 && iterations <= 3 && (nms_size == 3 || nms_size == 5 || nms_size == 7);
+}
+
+extern "C" int mi_akaze_scale(const float *l_in, int n, int h, int w, int iterations, float kappa, float dt,
+                              float threshold, int nms_size, float *l_out, float *scores, float *tmp,
+                              mi_stream_t stream) {
+  MI_ENTER();
+  if (!l_in || !l_out || !scores || l_in == l_out) return MI_E_NULL;
+  if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
+  if (iterations <= 0 || !(kappa > 0.0f) || nms_size <= 0 || (nms_size & 1) == 0 || nms_size > 15) return MI_E_PARAM;
+  hipStream_t s = (hipStream_t)stream;
+  if (mi_akaze_scale_fused(iterations, nms_size)) {
+    const int halo = 2 * iterations + 1 + nms_size / 2;
+    const int tx = ceil_div(w, 64 - 2 * halo), ty = ceil_div(h, AS_H);
+    const long long blocks = (long long)n * tx * ty;
+    if (blocks > 0x7fffffffLL) return MI_E_SHAPE;
+#define AKS(I, NHALF) hipLaunchKernelGGL((akaze_scale_kernel<I, NHALF>), dim3((unsigned)blocks), dim3(256), 0, s, l_in, h, w, kappa, dt, threshold, l_out, scores, tx, ty)
+    const int nh = nms_size / 2;
+    if (iterations == 1) { if (nh == 1) AKS(1, 1); else if (nh == 2) AKS(1, 2); else AKS(1, 3); }
+    else if (iterations == 2) { if (nh == 1) AKS(2, 1); else if (nh == 2) AKS(2, 2); else AKS(2, 3); }
+    else { if (nh == 1) AKS(3, 1); else if (nh == 2) AKS(3, 2); else AKS(3, 3); }
+#undef AKS
+    return mi_launch_status();
+  }
+  // general parameters: the per-step kernels, ping-ponging l_out and tmp so that the last step lands in l_out
+  if (iterations > 1 && !tmp) return MI_E_NULL;
+  const float *cur = l_in;
+  for (int i = 0; i < iterations; ++i) {
+    float *dst = ((iterations - 1 - i) % 2 == 0) ? l_out : tmp;
+    const int e = mi_akaze_diffuse(cur, n, h, w, kappa, dt, dst, stream);
+    if (e != MI_OK) return e;
+    cur = dst;
+  }
+  return mi_akaze_hessian_scores(l_out, n, h, w, threshold, nms_size, scores, stream);
 }

@@ -424,6 +424,22 @@ def akaze_diffuse(image: torch.Tensor, iterations: int, kappa: float, dt: float 
     return cur
 
 
+def akaze_scale(image: torch.Tensor, iterations: int, kappa: float, dt: float, threshold: float, nms_size: int,
+                scores_out: torch.Tensor | None = None):
+    """One AKAZE scale in one launch: (diffused image, Hessian score map) = (NonLinearDiffusion(image),
+    HessianDetector(diffused)); `mi_akaze_scale`."""
+    img = _images(image, "image")
+    n, _, h, w = img.shape
+    out = torch.empty_like(img)
+    scores = scores_out if scores_out is not None else torch.empty_like(img)
+    fused = bool(N.load().mi_akaze_scale_fused(int(iterations), int(nms_size)))
+    tmp = None if fused or iterations <= 1 else torch.empty_like(img)
+    N.call("mi_akaze_scale", N.dev(img, F32, "image"), n, h, w, int(iterations), float(kappa), float(dt), float(threshold),
+           int(nms_size), out.data_ptr(), N.dev(scores, F32, "scores"), tmp.data_ptr() if tmp is not None else None,
+           N.stream_ptr())
+    return out, scores
+
+
 def akaze_hessian_scores(image: torch.Tensor, threshold: float, nms_size: int,
                          out: torch.Tensor | None = None) -> torch.Tensor:
     img = _images(image, "image")

@@ -106,8 +106,12 @@ class AKAZE(nn.Module):
         scale_images = []
         cur = img
         for i in range(self.num_scales):
-            cur = self.diffusion_layers[i](cur)
-            ops.akaze_hessian_scores(cur, self.detector.threshold, self.detector.nms_size, out=scale_scores[i])
+            layer = self.diffusion_layers[i]
+            if layer.num_iterations > 0:                 # one launch per scale: diffusion steps + Hessian + NMS on one tile
+                cur, _ = ops.akaze_scale(cur, layer.num_iterations, layer.kappa, layer.dt, self.detector.threshold,
+                                         self.detector.nms_size, scores_out=scale_scores[i])
+            else:
+                ops.akaze_hessian_scores(cur, self.detector.threshold, self.detector.nms_size, out=scale_scores[i])
             scale_images.append(cur)
         scores, _ = ops.akaze_combine(scale_scores, None)
         return scores, scale_scores, scale_images

@@ -764,6 +764,27 @@ def test_akaze_pipeline_vs_oracle_and_golden(mods, key, div):
     assert ok, worst
 
 
+@pytest.mark.parametrize("shape", [(2, 37, 53), (1, 96, 128), (3, 70, 200), (1, 480, 640)])
+def test_akaze_fused_scale_equals_step_kernels(mods, shape):
+    """mi_akaze_scale (diffusion steps + Hessian + NMS on one LDS-resident tile, one launch) against the per-step
+    kernels it replaces, bit for bit: every fused (iterations, nms_size) instance, the unfused fall-back, image sizes
+    that are not tile multiples, unit-range and uint8-range images."""
+    from onnx_image_processing_amd import _native as N, ops
+    n, h, w = shape
+    img = np.stack([synth_image(3500 + i, h, w) for i in range(n)])[:, None].astype(np.float32)
+    for scale, kappa, thr in ((1.0, 0.05, 0.001), (1.0 / 255.0, 0.05, 1e-5), (1.0, 7.5, 3.0)):
+        x = gpu(img * np.float32(scale))
+        for iters, nms in ((1, 3), (2, 5), (3, 5), (3, 7), (3, 3), (4, 5), (2, 9)):
+            if (h, w) == (480, 640) and (iters, nms) not in ((3, 5), (4, 5)):
+                continue
+            assert bool(N.load().mi_akaze_scale_fused(iters, nms)) == (iters <= 3 and nms <= 7)
+            want_l = ops.akaze_diffuse(x, iters, kappa, 0.25)
+            want_s = ops.akaze_hessian_scores(want_l, thr, nms)
+            got_l, got_s = ops.akaze_scale(x, iters, kappa, 0.25, thr, nms)
+            assert torch.equal(got_l, want_l) and torch.equal(got_s, want_s), (scale, iters, nms)
+            assert int((got_s > 0).sum()) > 0 or scale != 1.0
+
+
 def test_akaze_c4_480x640_k512_golden(mods):
     """BASELINE configs[3] at its own size, AKAZE export-CLI values (what `bench.py --workload c4` times): keypoints
     exact, P within 1e-4 of the recorded reference output, same MNN match set."""
