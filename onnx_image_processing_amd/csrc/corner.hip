@@ -262,6 +262,173 @@ __device__ __forceinline__ void corner_compute(const TILE *__restrict__ tile, fl
   }
 }
 
+// ---- u8 ingest, block 3: the stencil in packed integer arithmetic -------------------------------------------
+// For uint8 pixels every intermediate of the score map up to the box sums is an integer: Sobel sums |.| <= 1020 fit
+// int16 (two per register: v_pk_add/sub_i16, v_pk_mad_i16, neighbours by v_alignbit), products and their 3x3 box sums
+// (<= 9.4e6 < 2^24) fit int32 (v_dot2_i32_i16 forms a product pair's sum in one instruction) and convert to fp32
+// exactly -- so the eigenvalue tail sees the very values the fp32 path computes and the scores are bit-identical,
+// at roughly half the vector instructions in front of the tail (the fp32 kernel is bound by VALU issue, not by HBM,
+// once its input shrinks to one byte per pixel).
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2s as_v2s(uint32_t x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_cast(uint32_t, x); }
+
+// a.lo * b.lo and a.hi * b.hi of two int16 pairs as int32 (v_mad_i32_i16 with op_sel; the compiler's own lowering of
+// the C expression sign-extends both halves first)
+__device__ __forceinline__ int mul_lo16(v2s a, v2s b) {
+  int d;
+  asm("v_mad_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ int mul_hi16(v2s a, v2s b) {
+  int d;
+  asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[1,1,0,0]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
+template <int R>
+__device__ __forceinline__ void corner_compute_u8(const uint32_t *__restrict__ tile, float *__restrict__ score, int img,
+                                                  int h, int w, int x0, int y0, int t) {
+  constexpr int TH = 8 * R, NP = R + 2;
+  const int tx = t & 31, ty = t >> 5;
+  const int x = x0 + 4 * tx;
+  const int ybase = y0 + ty * R;
+  if (x >= w || ybase >= h) return;
+  const bool tile_left = (x0 == 0), tile_right = (x0 + TW >= w);
+  const bool tile_top = (y0 == 0), tile_bottom = (y0 + TH + 1 > h);
+  const bool left_edge = (x == 0), right_edge = (x + 4 >= w), top_edge = (ybase == 0);
+
+  v2s win[3][4];           // rolling rows: image columns x-2 .. x+5 as four (lo, hi) pairs of int16
+  v2s cprev[4];            // row(ir-2) + row(ir-1)
+  int hs[NP][3][4];        // horizontally summed products per product row (xx, yy, xy)
+  int vq[3][4];
+
+#pragma unroll
+  for (int ir = 0; ir < R + 4; ++ir) {
+    {
+      const uint32_t *src = &tile[(ty * R + ir) * LWD + tx];
+      const uint32_t a = src[0], b = src[1], c = src[2];
+      v2s *d = win[ir % 3];
+      d[0] = as_v2s(__builtin_amdgcn_perm(0u, a, 0x0c030c02u));        // (x-2, x-1)
+      d[1] = as_v2s(__builtin_amdgcn_perm(0u, b, 0x0c010c00u));        // (x,   x+1)
+      d[2] = as_v2s(__builtin_amdgcn_perm(0u, b, 0x0c030c02u));        // (x+2, x+3)
+      d[3] = as_v2s(__builtin_amdgcn_perm(0u, c, 0x0c010c00u));        // (x+4, x+5)
+      // replicate padding of the IMAGE in x (the chunks outside the image were fetched from a clamped address)
+      if (tile_left) {
+        MI_KEEP_BRANCH();
+        if (left_edge) d[0] = as_v2s(__builtin_amdgcn_perm(0u, b, 0x0c000c00u));
+      }
+      if (tile_right) {
+        MI_KEEP_BRANCH();
+        if (right_edge) d[3] = as_v2s(__builtin_amdgcn_perm(0u, b, 0x0c030c03u));
+      }
+    }
+    if (ir < 1) continue;
+    const v2s *mid = win[(ir - 1) % 3], *bot = win[ir % 3];
+    v2s cnew[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cnew[k] = mid[k] + bot[k];
+    if (ir < 2) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cprev[k] = cnew[k];
+      continue;
+    }
+    const int pr = ir - 2;                  // product row index, global row ybase - 1 + pr
+    const v2s *top = win[(ir - 2) % 3];
+    const int gy = ybase - 1 + pr;
+    v2s sm[4], df[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sm[k] = cprev[k] + cnew[k];           // top + 2 mid + bot
+      df[k] = bot[k] - top[k];
+      cprev[k] = cnew[k];
+    }
+    // gradient columns j = 0..5 (image columns x-1 .. x+4) as pairs (0,1) (2,3) (4,5)
+    v2s gx[3], gyv[3];
+    const v2s two = {2, 2};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      gx[j] = sm[j + 1] - sm[j];                                                   // sm[c+2] - sm[c]
+      const v2s sh = as_v2s(__builtin_amdgcn_alignbit(as_u32(df[j + 1]), as_u32(df[j]), 16));   // (df[2j+1], df[2j+2])
+      gyv[j] = (sh * two + df[j]) + df[j + 1];                                      // df[c] + 2 df[c+1] + df[c+2]
+    }
+    // replicate padding of the PRODUCT maps == gradients taken at the clamped column
+    if (tile_left) {
+      MI_KEEP_BRANCH();
+      if (left_edge) {
+        gx[0] = as_v2s(__builtin_amdgcn_perm(0u, as_u32(gx[0]), 0x03020302u));
+        gyv[0] = as_v2s(__builtin_amdgcn_perm(0u, as_u32(gyv[0]), 0x03020302u));
+      }
+    }
+    if (tile_right) {
+      MI_KEEP_BRANCH();
+      if (right_edge) {
+        gx[2] = as_v2s(__builtin_amdgcn_perm(0u, as_u32(gx[2]), 0x01000100u));
+        gyv[2] = as_v2s(__builtin_amdgcn_perm(0u, as_u32(gyv[2]), 0x01000100u));
+      }
+    }
+    // products and their sliding 3-sums p0+p1+p2, p1+p2+p3, p2+p3+p4, p3+p4+p5: the odd product out is one
+    // v_mad_i32_i16 (op_sel picks the half, no sign extension needed), the pair's two products join it through one
+    // accumulating v_dot2c_i32_i16 -- two instructions per 3-sum
+    {
+      const v2s *aa[3] = {gx, gyv, gx};
+      const v2s *bb[3] = {gx, gyv, gyv};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const v2s *A = aa[q], *B = bb[q];
+        hs[pr][q][0] = __builtin_amdgcn_sdot2(A[0], B[0], mul_lo16(A[1], B[1]), false);
+        hs[pr][q][1] = __builtin_amdgcn_sdot2(A[1], B[1], mul_hi16(A[0], B[0]), false);
+        hs[pr][q][2] = __builtin_amdgcn_sdot2(A[1], B[1], mul_lo16(A[2], B[2]), false);
+        hs[pr][q][3] = __builtin_amdgcn_sdot2(A[2], B[2], mul_hi16(A[1], B[1]), false);
+      }
+    }
+    // rows below the image repeat the last in-image product row
+    if (tile_bottom) {
+      if (pr > 0 && gy > h - 1) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) hs[pr][q][i] = hs[pr - 1][q][i];
+      }
+    }
+    // rows above the image repeat product row 0 of the image (= local row 1)
+    if (pr == 1) {
+      if (tile_top) {
+        if (top_edge) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hs[0][q][i] = hs[1][q][i];
+        }
+      }
+    }
+    if (pr < 2) continue;
+    const int orow = pr - 2;               // output row ybase + orow
+    int acc[3][4];
+    if ((orow & 1) == 0) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          vq[q][i] = hs[orow + 1][q][i] + hs[orow + 2][q][i];
+          acc[q][i] = hs[orow][q][i] + vq[q][i];
+        }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[q][i] = vq[q][i] + hs[orow + 2][q][i];
+    }
+    if (ybase + orow >= h) continue;
+    float out[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = lambda_min((float)acc[0][i], (float)acc[1][i], (float)acc[2][i]);
+    char *plane = reinterpret_cast<char *>(score + (size_t)img * h * w);
+    *reinterpret_cast<float4 *>(plane + (uint32_t)((ybase + orow) * w + x) * 4u) = make_float4(out[0], out[1], out[2], out[3]);
+  }
+}
+
 template <int BS, int R>
 __global__ __launch_bounds__(256) void corner_tile_kernel(MiSets images,
                                                           float *__restrict__ score, int h, int w,
@@ -401,7 +568,8 @@ __global__ __launch_bounds__(256) void corner_stream_kernel(MiSets images,
     }
     prev_full = (x0 + TW <= w) && (y0 + TH <= h);  // workgroup-uniform
     const CH *tile = &lds[cur * BUF];
-    corner_compute<BS, R>(tile, score, img, h, w, x0, y0, t);
+    if constexpr (U8 && BS == 3) corner_compute_u8<R>(tile, score, img, h, w, x0, y0, t);
+    else corner_compute<BS, R>(tile, score, img, h, w, x0, y0, t);
     img = nimg; x0 = nx0; y0 = ny0;
   }
 }
@@ -462,8 +630,9 @@ int launch_stream(MiSets image, int n, int h, int w, float *score, hipStream_t s
   constexpr int PIECE = std::is_same<PIX, float>::value ? 16 : 4;
   constexpr int LDS_BYTES = 2 * ((LH * LW4 + 255) / 256) * 256 * PIECE;
   constexpr int PER_CU_LDS = (160 * 1024) / LDS_BYTES;
-  // fp32: LDS allows 4 workgroups per CU.  uint8: LDS would allow 16, registers (the same stencil) about 5.
-  constexpr int PER_CU = std::is_same<PIX, float>::value ? (PER_CU_LDS > 8 ? 8 : PER_CU_LDS) : 5;
+  // fp32: LDS allows 4 workgroups per CU.  uint8: LDS would allow 16; the integer stencil needs 78-80 VGPRs at 4 or 5
+  // rows per thread (6 waves per SIMD) and 98 at 8 rows (4-5).
+  constexpr int PER_CU = std::is_same<PIX, float>::value ? (PER_CU_LDS > 8 ? 8 : PER_CU_LDS) : (R <= 5 ? 6 : 4);
   const int resident = 256 * PER_CU;
   const int grid = total < resident ? (int)total : resident;
   hipLaunchKernelGGL((corner_stream_kernel<BS, R, std::is_same<PIX, uint8_t>::value>), dim3(grid), dim3(256), 0, s,
@@ -473,6 +642,7 @@ int launch_stream(MiSets image, int n, int h, int w, float *score, hipStream_t s
 
 std::atomic<int> g_corner_impl{0};   // 0 = streaming (LDS-DMA) kernel, 1 = register-staged tile kernel
 std::atomic<int> g_corner_rows{4};   // rows per thread of the streaming kernel (tile height = 8 * rows)
+std::atomic<int> g_corner_rows_u8_default{1};   // 1 until mi_debug_set(2, .) is called: the uint8 kernel then uses 5 rows
 
 }  // namespace
 
@@ -485,7 +655,7 @@ extern "C" int mi_debug_set(int key, int value) {
   if (key == 9) { mi_g_topk_select = value; return MI_OK; }
   if (key == 7) { mi_g_sinkhorn_persist = value; return MI_OK; }
   if (key == 8) { mi_g_sinkhorn_stamps = value; return MI_OK; }
-  if (key == 2 && (value == 4 || value == 5 || value == 8)) { g_corner_rows = value; return MI_OK; }
+  if (key == 2 && (value == 4 || value == 5 || value == 8)) { g_corner_rows = value; g_corner_rows_u8_default = 0; return MI_OK; }
   return MI_E_PARAM;
 }
 
@@ -504,9 +674,11 @@ int mi_corner_response_sets(MiSets images, int pix_u8, int n, int h, int w, int 
     // 4-pixel DMA pieces: rows must start on a dword (w % 4 == 0, bases 4-byte aligned); score rows are written as float4
     const bool aligned = (w % 4 == 0) && (bases % 4 == 0) && ((uintptr_t)score % 16 == 0);
     if (aligned && h >= 4 && w >= 8 && block_size == 3) {
+      // 5 rows per thread unless the test hook asks otherwise (measured per 448 images: 217 us at 5 rows, 221 at 8,
+      // 259 at 4 -- the fp32 kernel's best -- with 6 workgroups per CU)
       if (rows == 8) return launch_stream<3, 8, uint8_t>(images, n, h, w, score, s);
-      if (rows == 5) return launch_stream<3, 5, uint8_t>(images, n, h, w, score, s);
-      return launch_stream<3, 4, uint8_t>(images, n, h, w, score, s);
+      if (rows == 4 && g_corner_rows_u8_default.load(std::memory_order_relaxed) == 0) return launch_stream<3, 4, uint8_t>(images, n, h, w, score, s);
+      return launch_stream<3, 5, uint8_t>(images, n, h, w, score, s);
     }
     if (blocks > 0x7fffffffULL) return MI_E_SHAPE;
     hipLaunchKernelGGL(corner_generic_kernel<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, s, images, score, n, h, w,

@@ -1,15 +1,28 @@
 #!/bin/bash
 # Round profile on the GPU box (run through gpurun from the repo root):
-#   bench line, rocprofv3 kernel statistics of the same command, and the two PMC passes
-#   (FETCH_SIZE, WRITE_SIZE -- separate runs, --kernel-trace only, as the guide prescribes).
+#   bench line, rocprofv3 kernel statistics of the same command, the PMC passes the guide prescribes for HBM traffic
+#   (FETCH_SIZE, WRITE_SIZE -- separate runs, --kernel-trace only) and the MFMA passes for the cost kernel
+#   (busy cycles and I8 MOPS, separate runs), then the same statistics for the one-pair-per-call path and for
+#   BASELINE configs[2] / [3].  The program itself follows `--` (never a shell or env wrapper).
 # Outputs land in gpurun_out/round/; tools/profile_summarise.py turns them into profiles/<tag>_*.
 set -e -o pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$ROOT/gpurun_out/round"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 python3 "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --cpu-pairs 0 > "$OUT/stats.log" 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-pairs 0 > "$OUT/fetch.log" 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o write -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-pairs 0 > "$OUT/write.log" 2>&1
+B="$ROOT/bench.py"
+timeout -k 10 500 python3 "$B" > "$OUT/bench.json" 2> "$OUT/bench.err"
+echo bench done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats -- python3 "$B" --steps 20 --warmup 3 --cpu-pairs 0 --no-extras > "$OUT/stats.log" 2>&1
+echo stats done
+for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_$c" -o pmc -- python3 "$B" --steps 3 --warmup 1 --cpu-pairs 0 --no-extras > "$OUT/pmc_$c.log" 2>&1
+  echo pmc $c done
+done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/latency" -o latency -- python3 "$ROOT/tools/latency_trace.py" --single-call --graph --iters 50 > "$OUT/latency.log" 2>&1
+echo latency done
+timeout -k 10 300 python3 "$B" --workload c3 --pairs-per-gpu 64 > "$OUT/c3.json" 2> "$OUT/c3.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/c3stats" -o c3 -- python3 "$B" --workload c3 --pairs-per-gpu 64 --steps 5 --warmup 2 > "$OUT/c3stats.log" 2>&1
+timeout -k 10 300 python3 "$B" --workload c4 --pairs-per-gpu 128 > "$OUT/c4.json" 2> "$OUT/c4.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/c4stats" -o c4 -- python3 "$B" --workload c4 --pairs-per-gpu 128 --steps 5 --warmup 2 > "$OUT/c4stats.log" 2>&1
 echo profile_round done

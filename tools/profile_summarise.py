@@ -34,16 +34,45 @@ line = open(os.path.join(SRC, "bench.json")).read().strip().splitlines()[-1]
 PAIRS = int(json.loads(line)["config"]["pairs_per_gpu_per_step"])
 open(os.path.join(dst, f"{tag}_bench.json"), "w").write(line + "\n")
 
-db = sqlite3.connect(os.path.join(SRC, "stats", "stats_results.db"))
-with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --cpu-pairs 0   "
-            f"(1 x MI355X, {PAIRS} pairs/step)\n# name, calls, total_ms, avg_us, pct\n")
-    for name, calls, total, avg, pct in db.execute("select * from top_kernels"):
-        f.write(f"{short(name)}, {calls}, {total / 1e3:.3f}, {avg:.2f}, {pct:.2f}\n")
+def stats_csv(sub, base, out_name, header):
+    path = os.path.join(SRC, sub, f"{base}_results.db")
+    if not os.path.exists(path):
+        return
+    db = sqlite3.connect(path)
+    with open(os.path.join(dst, out_name), "w") as f:
+        f.write(header + "\n# name, calls, total_ms, avg_us, pct\n")
+        for name, calls, total, avg, pct in db.execute("select * from top_kernels"):
+            f.write(f"{short(name)}, {calls}, {total / 1e3:.3f}, {avg:.2f}, {pct:.2f}\n")
+
+
+stats_csv("stats", "stats", f"{tag}_bench_kernel_stats.csv",
+          "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --cpu-pairs 0 --no-extras   "
+          f"(1 x MI355X, {PAIRS} pairs/step)")
+stats_csv("latency", "latency", f"{tag}_latency_kernel_stats.csv",
+          "# rocprofv3 --kernel-trace --stats -- python3 tools/latency_trace.py --single-call --graph --iters 50   "
+          "(ONE 640x480 K=512 pair per call through mi_match_pairs, replayed as a hipGraph; every call synchronised)")
+for wl, pairs in (("c3", 64), ("c4", 128)):
+    stats_csv(wl + "stats", wl, f"{tag}_{wl}_kernel_stats.csv",
+              f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --pairs-per-gpu {pairs} --steps 5 --warmup 2")
+    src = os.path.join(SRC, wl + ".json")
+    if os.path.exists(src):
+        open(os.path.join(dst, f"{tag}_{wl}_bench.json"), "w").write(open(src).read().strip().splitlines()[-1] + "\n")
 
 traffic = collections.defaultdict(dict)
+def pmc_rows(counter):
+    d = sqlite3.connect(os.path.join(SRC, "pmc_" + counter, "pmc_results.db"))
+    cur = d.cursor()
+    cols = [c[0] for c in cur.execute("select * from counters_collection limit 1").description]
+    acc = collections.defaultdict(list)
+    for r in cur.execute("select * from counters_collection"):
+        row = dict(zip(cols, r))
+        if row["counter_name"] == counter:
+            acc[short(row["kernel_name"])].append(row["value"])
+    return acc
+
+
 for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    d = sqlite3.connect(os.path.join(SRC, which, f"{which}_results.db"))
+    d = sqlite3.connect(os.path.join(SRC, "pmc_" + counter, "pmc_results.db"))
     cur = d.cursor()
     cols = [c[0] for c in cur.execute("select * from counters_collection limit 1").description]
     acc = collections.defaultdict(list)
@@ -66,4 +95,24 @@ for k, v in sorted(traffic.items(), key=lambda kv: -kv[1].get("FETCH_SIZE_KB_raw
     out["kernels"][k] = {**{kk: round(vv, 3) for kk, vv in v.items()}, "read_MB_corrected_x2": round(rd, 1),
                          "write_MB": round(wr, 1), "total_MB": round(rd + wr, 1)}
 json.dump(out, open(os.path.join(dst, f"{tag}_bench_pmc_traffic.json"), "w"), indent=1)
+
+# MFMA counters of the cost kernel (north_star: "MFMA utilisation on the cost matrix"); three separate passes
+try:
+    busy, cu, mops = pmc_rows("SQ_VALU_MFMA_BUSY_CYCLES"), pmc_rows("SQ_BUSY_CU_CYCLES"), pmc_rows("SQ_INSTS_VALU_MFMA_MOPS_I8")
+    mf = {"note": "rocprofv3 --pmc, one counter per pass over `bench.py --steps 3 --warmup 1 --no-extras`; per-launch sums over the "
+                  "chip.  SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CU_CYCLES * 4 SIMDs) is the fraction of the kernel's busy "
+                  "SIMD-cycles with the MFMA pipe occupied; MOPS_I8 * 512 = integer multiply-add operations issued",
+          "pairs_per_gpu": PAIRS, "kernels": {}}
+    for k in busy:
+        if "cost" not in k:
+            continue
+        b = sum(busy[k]) / len(busy[k])
+        c = sum(cu.get(k, [0])) / max(1, len(cu.get(k, [0])))
+        m = sum(mops.get(k, [0])) / max(1, len(mops.get(k, [0])))
+        mf["kernels"][k] = {"SQ_VALU_MFMA_BUSY_CYCLES": b, "SQ_BUSY_CU_CYCLES": c, "SQ_INSTS_VALU_MFMA_MOPS_I8": m,
+                            "mfma_busy_fraction_of_busy_simd_cycles": (b / (4.0 * c)) if c else None,
+                            "int8_ops_issued": m * 512.0, "int8_ops_algorithmic": 2.0 * PAIRS * 512 ** 3}
+    json.dump(mf, open(os.path.join(dst, f"{tag}_bench_pmc_mfma.json"), "w"), indent=1)
+except Exception as e:      # noqa: BLE001
+    print("mfma summary skipped:", e)
 print("wrote", tag)
