@@ -261,8 +261,8 @@ def measure_u8_and_streamed(model, a8: np.ndarray, b8: np.ndarray, steps: int) -
     u8 = {"value": B / (resident_ms * 1e-3), "unit": "image-pairs/sec", "ms_per_step": resident_ms, "steps": steps,
           "what": "the default workload on uint8 frames resident in HBM (mi_corner_response_u8 / mi_sparse_bad_u8)",
           "mean_valid_matches_per_pair": float(rec[..., 5].sum().item()) / B,
-          "roofline": k1_roofline(float(np.mean(k1)), 5.0, B, "corner_stream_kernel<3,4,uint8> (mi_corner_response_u8)",
-                                  "corner_stream_kernel<3, 4, true>", B)}
+          "roofline": k1_roofline(float(np.mean(k1)), 5.0, B, "corner_stream_kernel<3,5,uint8> (mi_corner_response_u8)",
+                                  "corner_stream_kernel<3,5,true>", B)}
 
     main = torch.cuda.current_stream()
     copier = torch.cuda.Stream()
@@ -470,7 +470,7 @@ def main() -> None:
             # every pair of this rank, two launches per step
             k1 = per_call["mi_corner_response"][2 * args.warmup:]
             line["roofline"] = k1_roofline(float(np.mean(k1)), 8.0, B, "corner_stream_kernel<3,4,float> (mi_corner_response)",
-                                           "corner_stream_kernel<3, 4, false>", B)
+                                           "corner_stream_kernel<3,4,false>", B)
             # informational: the other stages by their algorithmic bytes / operations
             other = {}
             if "mi_nms_candidates" in stages:
