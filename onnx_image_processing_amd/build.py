@@ -49,6 +49,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     headers = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))) + [os.path.abspath(__file__)]
     hipcc = _hipcc()
+    # development hook for on-box parameter sweeps: MI_BUILD_DEFINES="-DAS_WAVES=16 ..." (forces a full rebuild)
+    extra_defines = os.environ.get("MI_BUILD_DEFINES", "").split()
+    force = force or bool(extra_defines)
     jobs = []
     objs = []
     for src in SOURCES:
@@ -56,7 +59,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _newer(o, [s] + headers):
-            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", s, "-o", o])
+            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), *extra_defines, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

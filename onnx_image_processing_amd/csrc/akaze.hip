@@ -224,7 +224,17 @@ __global__ __launch_bounds__(256) void combine_kp_kernel(const float *__restrict
 // tile still in LDS: 12 B/px per scale (read L, write L, write scores), one launch.  The halo is recomputed per tile
 // (about 1.5x the arithmetic), every expression is the per-step kernels' (same operation order), so the maps equal
 // theirs bit for bit.
-constexpr int AS_H = 32;                 // output tile height; its width is 64 - 2 * halo (see the kernel)
+// (build-time overridable for sweeps on the GPU box: MI_BUILD_DEFINES, build.py.  Measured, 128 pairs per step:
+//  8 waves x 48 rows 3.11 ms; 8 x 32 3.37; 8 x 40 3.37; 8 x 56 3.86; 8 x 64 3.78; 4 x 32 3.68; 4 x 48 3.92;
+//  6 x 48 4.62; 10 x 48 3.96; 12 x 48 3.62; 16 x 32 4.19; 16 x 48 3.49)
+#ifndef MI_AS_H
+#define MI_AS_H 48
+#endif
+#ifndef MI_AS_WAVES
+#define MI_AS_WAVES 8
+#endif
+constexpr int AS_H = MI_AS_H;            // output tile height; its width is 64 - 2 * halo (see the kernel)
+constexpr int AS_WAVES = MI_AS_WAVES;    // waves per workgroup: each phase splits its rows into this many blocks
 
 // Correctly rounded fp32 sqrt and division for the operand ranges of the diffusion step (normal, finite, far from
 // overflow: |g| <= ~255, kappa and 1 + q^2 >= 1e-4), i.e. the compiler's IEEE expansions without their denormal
@@ -250,7 +260,7 @@ __device__ __forceinline__ float ak_div(float a, float b) {
 }
 
 template <int ITERS, int NH>
-__global__ __launch_bounds__(256) void akaze_scale_kernel(const float *__restrict__ lin, int h, int w, float kappa,
+__global__ __launch_bounds__(64 * AS_WAVES) void akaze_scale_kernel(const float *__restrict__ lin, int h, int w, float kappa,
                                                           float dt, float threshold, float *__restrict__ lout,
                                                           float *__restrict__ scores, int tiles_x, int tiles_y) {
   constexpr int HALO = 2 * ITERS + 1 + NH;
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(256) void akaze_scale_kernel(const float *__restric
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   // the image rows / columns the tile covers, in tile coordinates: [ry0, ry1) x [cx0, cx1) lies inside the image
   const int ry0 = max(0, -y0), ry1 = min(LH, h - y0), cx0 = max(0, -x0), cx1 = min(LW, w - x0);
-  for (int r = ty; r < LH; r += 4) {
+  for (int r = ty; r < LH; r += AS_WAVES) {
     const bool rin = r >= ry0 && r < ry1;
     const float *row = src + (size_t)(y0 + r) * w + x0;
     L[r][tx] = (rin && tx >= cx0 && tx < cx1) ? row[tx] : 0.0f;
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(256) void akaze_scale_kernel(const float *__restric
   for (int s = 0; s < ITERS; ++s) {
     // flux on rows / columns [2s+1, L? - 2s - 1): needs L one ring further out
     {
-      const int f0 = 2 * s + 1, nrows = LH - 2 * f0, per = (nrows + 3) / 4;
+      const int f0 = 2 * s + 1, nrows = LH - 2 * f0, per = (nrows + AS_WAVES - 1) / AS_WAVES;
       const int rbeg = f0 + ty * per, rend = min(rbeg + per, LH - f0);
       if (c >= f0 && c < LW - f0 && rbeg < rend) {
         const bool cin = c >= cx0 && c < cx1;
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(256) void akaze_scale_kernel(const float *__restric
     __syncthreads();
     // L += dt * div(flux) on rows / columns [2s+2, L? - 2s - 2), in place (only pixels of the image evolve)
     {
-      const int u0 = 2 * s + 2, nrows = LH - 2 * u0, per = (nrows + 3) / 4;
+      const int u0 = 2 * s + 2, nrows = LH - 2 * u0, per = (nrows + AS_WAVES - 1) / AS_WAVES;
       const int rbeg = max(u0 + ty * per, ry0), rend = min(min(u0 + (ty + 1) * per, LH - u0), ry1);
       if (c >= max(u0, cx0) && c < min(LW - u0, cx1) && rbeg < rend) {
         float xt0 = FX[rbeg - 1][c - 1], xt2 = FX[rbeg - 1][c + 1];
@@ -340,13 +350,13 @@ __global__ __launch_bounds__(256) void akaze_scale_kernel(const float *__restric
   }
   // the diffused tile (AS_W = 64 columns: one column chunk) and the Hessian determinant on the tile + NH (into FX;
   // -inf outside the image: the pool's padding)
-  for (int r = HALO + ty; r < min(HALO + AS_H, ry1); r += 4) {
+  for (int r = HALO + ty; r < min(HALO + AS_H, ry1); r += AS_WAVES) {
     const int c = tx;
     if (c >= HALO && c < HALO + TW && c < cx1) lout[((size_t)img * h + (y0 + r)) * w + (x0 + c)] = L[r][c];
   }
   constexpr int R0 = 2 * ITERS + 1;
 #pragma unroll 2
-  for (int r = R0 + ty; r < LH - R0; r += 4) {
+  for (int r = R0 + ty; r < LH - R0; r += AS_WAVES) {
     const bool rin = r >= ry0 && r < ry1;
     {
       const int c = tx;
@@ -365,7 +375,7 @@ __global__ __launch_bounds__(256) void akaze_scale_kernel(const float *__restric
   }
   __syncthreads();
   // window maximum, separable: along the rows (tile columns only), then down the columns
-  for (int r = R0 + ty; r < LH - R0; r += 4) {
+  for (int r = R0 + ty; r < LH - R0; r += AS_WAVES) {
     const int c = tx;
     if (c < HALO || c >= HALO + TW) continue;
     float mx = FX[r][c - NH];
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(256) void akaze_scale_kernel(const float *__restric
     FY[r][c] = mx;
   }
   __syncthreads();
-  for (int r = HALO + ty; r < min(HALO + AS_H, ry1); r += 4) {
+  for (int r = HALO + ty; r < min(HALO + AS_H, ry1); r += AS_WAVES) {
     const int c = tx;
     if (c < HALO || c >= HALO + TW || c >= cx1) continue;
     const float resp = FX[r][c];
@@ -480,7 +490,7 @@ extern "C" int mi_akaze_scale(const float *l_in, int n, int h, int w, int iterat
     const int tx = ceil_div(w, 64 - 2 * halo), ty = ceil_div(h, AS_H);
     const long long blocks = (long long)n * tx * ty;
     if (blocks > 0x7fffffffLL) return MI_E_SHAPE;
-#define AKS(I, NHALF) hipLaunchKernelGGL((akaze_scale_kernel<I, NHALF>), dim3((unsigned)blocks), dim3(256), 0, s, l_in, h, w, kappa, dt, threshold, l_out, scores, tx, ty)
+#define AKS(I, NHALF) hipLaunchKernelGGL((akaze_scale_kernel<I, NHALF>), dim3((unsigned)blocks), dim3(64 * AS_WAVES), 0, s, l_in, h, w, kappa, dt, threshold, l_out, scores, tx, ty)
     const int nh = nms_size / 2;
     if (iterations == 1) { if (nh == 1) AKS(1, 1); else if (nh == 2) AKS(1, 2); else AKS(1, 3); }
     else if (iterations == 2) { if (nh == 1) AKS(2, 1); else if (nh == 2) AKS(2, 2); else AKS(2, 3); }

@@ -289,3 +289,34 @@ def test_reference_import_lines_resolve_to_this_package(lib_path):
         importlib.import_module("pytorch_model.vo")
     with pytest.raises(RuntimeError, match="no CPU path"):
         probability_ratio_filter(torch.rand(4, 4))
+
+
+def test_argument_validation_of_the_round2_entries(lib_path):
+    """Host-side MI_E_* checks of the entry points added in round 2 (no launch happens: safe without a GPU)."""
+    lib = ctypes.CDLL(lib_path)
+    buf = ctypes.create_string_buffer(256)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    q = ctypes.c_void_p(p.value + 64)
+    vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    lib.mi_corner_response_u8.argtypes = [vp, ci, ci, ci, ci, vp, vp]
+    assert lib.mi_corner_response_u8(None, 1, 8, 8, 3, p, None) == -1
+    assert lib.mi_corner_response_u8(p, 1, 0, 8, 3, p, None) == -2
+    assert lib.mi_corner_response_u8(p, 1, 8, 8, 2, p, None) == -3
+    lib.mi_convert_u8_f32.argtypes = [vp, ctypes.c_longlong, vp, vp]
+    assert lib.mi_convert_u8_f32(p, 0, p, None) == -2 and lib.mi_convert_u8_f32(None, 4, p, None) == -1
+    lib.mi_sparse_bad_u8.argtypes = [vp, ci, ci, ci, vp, ci, vp, vp, ci, ci, cf, ci, vp, vp, vp, vp, vp]
+    assert lib.mi_sparse_bad_u8(p, 1, 64, 64, p, 4, p, p, 100, 2, 0.0, 1, p, None, None, None, None) == -3   # pairs % 64
+    assert lib.mi_sparse_bad_u8(p, 1, 64, 64, p, 4, p, p, 256, 0, 0.0, 1, p, p, None, None, None) == -3     # bits need HARD
+    lib.mi_match_filter_masks.argtypes = [vp, ci, ci, ci, ci, cf, cf, vp, vp]
+    assert lib.mi_match_filter_masks(p, 1, 4, 4, 0, 2.0, 0.3, p, None) == -3        # a margin test needs the dustbin column
+    assert lib.mi_match_filter_masks(None, 1, 4, 4, 1, 2.0, 0.3, p, None) == -1
+    lib.mi_akaze_scale.argtypes = [vp, ci, ci, ci, ci, cf, cf, cf, ci, vp, vp, vp, vp]
+    assert lib.mi_akaze_scale(p, 1, 8, 8, 3, 0.05, 0.25, 0.001, 5, p, q, None, None) == -1     # l_out aliases l_in
+    assert lib.mi_akaze_scale(p, 1, 8, 8, 0, 0.05, 0.25, 0.001, 5, q, q, None, None) == -3     # no iterations
+    assert lib.mi_akaze_scale(p, 1, 8, 8, 3, 0.05, 0.25, 0.001, 4, q, q, None, None) == -3     # even NMS window
+    assert lib.mi_akaze_scale(p, 1, 8, 8, 4, 0.05, 0.25, 0.001, 5, q, q, None, None) == -1     # unfused form needs tmp
+    assert lib.mi_akaze_scale_fused(3, 5) == 1 and lib.mi_akaze_scale_fused(4, 5) == 0 and lib.mi_akaze_scale_fused(2, 9) == 0
+    lib.mi_sinkhorn_dots_workspace_bytes.restype = ctypes.c_size_t
+    small, big = lib.mi_sinkhorn_dots_workspace_bytes(8, 512, 512), lib.mi_sinkhorn_dots_workspace_bytes(9, 512, 512)
+    assert small > big * 8 // 9          # up to 8 pairs the workspace also holds the single-launch form's hand-off area
+    lib.mi_release_stream_resources.argtypes = [vp]
