@@ -226,6 +226,21 @@ def measure_latency(model, img1, img2, a8, b8, iters: int = 200) -> dict:
             graph = timed(graphed.graph.replay)
             row[name] = {"eager_ms": eager, "graph_ms": graph, "eager_pairs_per_sec": b / (eager * 1e-3),
                          "graph_pairs_per_sec": b / (graph * 1e-3)}
+        if b == 1:
+            # the reference harness's own situation (sample/image_matching.py:313-328): frames are HOST arrays and the
+            # results are wanted on the host -- uint8 frames from pinned memory in, keypoint / match records out
+            h1, h2 = torch.from_numpy(a8[:1]).pin_memory(), torch.from_numpy(b8[:1]).pin_memory()
+            graphed8 = GraphedModule(one_call, u1, u2)
+            rec_host = torch.empty((1, 100, 6), dtype=torch.float32).pin_memory()
+
+            def from_host():
+                graphed8.static_inputs[0].copy_(h1, non_blocking=True)
+                graphed8.static_inputs[1].copy_(h2, non_blocking=True)
+                graphed8.graph.replay()
+                o = graphed8.static_outputs
+                rec_host.copy_(torch.cat([o[0], o[1], o[2].unsqueeze(-1), o[3].float().unsqueeze(-1)], -1), non_blocking=True)
+            row["single_call_u8_from_host"] = {"graph_ms": timed(from_host), "what": "H2D of both uint8 frames + replay + D2H "
+                                               "of the 100 match records, host synchronised after every call"}
         out[f"pairs_per_call_{b}"] = row
     out["what"] = ("MatchExtractionWrapper(ShiTomasiSparseBADSinkhornMatcher), frames resident in HBM, host synchronised "
                    f"after every call, mean of {iters} calls; forms: see bench.py measure_latency")
@@ -266,35 +281,51 @@ def measure_u8_and_streamed(model, a8: np.ndarray, b8: np.ndarray, steps: int) -
 
     main = torch.cuda.current_stream()
     copier = torch.cuda.Stream()
-    copied = [torch.cuda.Event() for _ in range(2)]
-    done = [torch.cuda.Event() for _ in range(2)]
 
-    def streamed_loop(n):
-        for i in range(n):
-            s = i & 1
-            with torch.cuda.stream(copier):
-                if i >= 2:
-                    copier.wait_event(done[s])                                  # the step that last used this slot is finished
-                slots[s].copy_(host, non_blocking=True)
-                copied[s].record(copier)
-            main.wait_event(copied[s])
-            rec = step(s)
-            done[s].record(main)
-        return rec
+    def streamed(host_t, slot_ts, n_steps):
+        """n_steps steps with the H2D copy of step i+1 under the compute of step i; -> (ms per step, last records)"""
+        copied = [torch.cuda.Event() for _ in range(2)]
+        done = [torch.cuda.Event() for _ in range(2)]
 
-    streamed_loop(4)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    rec = streamed_loop(steps)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) * 1e3 / steps
+        def loop(n):
+            rec = None
+            for i in range(n):
+                s = i & 1
+                with torch.cuda.stream(copier):
+                    if i >= 2:
+                        copier.wait_event(done[s])                              # the step that last used this slot is finished
+                    slot_ts[s].copy_(host_t, non_blocking=True)
+                    copied[s].record(copier)
+                main.wait_event(copied[s])
+                rec = D.pack_records(*model(slot_ts[s][0], slot_ts[s][1]))
+                done[s].record(main)
+            return rec
+
+        loop(4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rec = loop(n_steps)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / n_steps, rec
+
+    ms, rec = streamed(host, slots, steps)
     nbytes = host.numel()
-    streamed = {"value": B / (ms * 1e-3), "unit": "image-pairs/sec", "ms_per_step": ms, "steps": steps,
-                "h2d_bytes_per_step": nbytes, "pcie_GBps_achieved": nbytes / (ms * 1e-3) / 1e9,
-                "what": "uint8 frames in pinned host memory, H2D inside the timed region on a copy stream, double-buffered "
-                        "against compute (two device slots); 0.61 MB per pair instead of 2.46 MB for float32 frames",
-                "mean_valid_matches_per_pair": float(rec[..., 5].sum().item()) / B}
-    return u8, streamed
+    out = {"value": B / (ms * 1e-3), "unit": "image-pairs/sec", "ms_per_step": ms, "steps": steps,
+           "h2d_bytes_per_step": nbytes, "pcie_GBps_achieved": nbytes / (ms * 1e-3) / 1e9,
+           "what": "uint8 frames in pinned host memory, H2D inside the timed region on a copy stream, double-buffered "
+                   "against compute (two device slots); 0.61 MB per pair instead of 2.46 MB for float32 frames",
+           "mean_valid_matches_per_pair": float(rec[..., 5].sum().item()) / B}
+    # the same with float32 frames (what the reference's hosts hand over), for comparison: four times the bytes
+    del slots
+    fsteps = max(4, steps // 5)
+    host32 = torch.empty(host.shape, dtype=torch.float32).pin_memory()
+    host32.copy_(host)
+    slots32 = [torch.empty_like(host32, device=dev) for _ in range(2)]
+    ms32, _ = streamed(host32, slots32, fsteps)
+    out["float32_frames"] = {"value": B / (ms32 * 1e-3), "ms_per_step": ms32, "steps": fsteps,
+                             "h2d_bytes_per_step": host32.numel() * 4,
+                             "pcie_GBps_achieved": host32.numel() * 4 / (ms32 * 1e-3) / 1e9}
+    return u8, out
 
 
 # ----------------------------------------------------------------------------------------------- configs[2] / [3]

@@ -632,7 +632,11 @@ int launch_stream(MiSets image, int n, int h, int w, float *score, hipStream_t s
   constexpr int PER_CU_LDS = (160 * 1024) / LDS_BYTES;
   // fp32: LDS allows 4 workgroups per CU.  uint8: LDS would allow 16; the integer stencil needs 78-80 VGPRs at 4 or 5
   // rows per thread (6 waves per SIMD) and 98 at 8 rows (4-5).
+#ifdef MI_K1_U8_PER_CU
+  constexpr int PER_CU = std::is_same<PIX, float>::value ? (PER_CU_LDS > 8 ? 8 : PER_CU_LDS) : MI_K1_U8_PER_CU;
+#else
   constexpr int PER_CU = std::is_same<PIX, float>::value ? (PER_CU_LDS > 8 ? 8 : PER_CU_LDS) : (R <= 5 ? 6 : 4);
+#endif
   const int resident = 256 * PER_CU;
   const int grid = total < resident ? (int)total : resident;
   hipLaunchKernelGGL((corner_stream_kernel<BS, R, std::is_same<PIX, uint8_t>::value>), dim3(grid), dim3(256), 0, s,
