@@ -265,18 +265,18 @@ def measure_u8_and_streamed(model, a8: np.ndarray, b8: np.ndarray, steps: int) -
     for _ in range(3):
         step(0)
     torch.cuda.synchronize()
-    _native.enable_timing(True, only={"mi_corner_response_u8"})
+    _native.enable_timing(True, only={"mi_corner_response_balanced"})
     t0 = time.perf_counter()
     for i in range(steps):
         rec = step(i & 1)
     torch.cuda.synchronize()
     resident_ms = (time.perf_counter() - t0) * 1e3 / steps
-    k1 = _native.timings_ms()["mi_corner_response_u8"]
+    k1 = _native.timings_ms()["mi_corner_response_balanced"]
     _native.enable_timing(False)
     u8 = {"value": B / (resident_ms * 1e-3), "unit": "image-pairs/sec", "ms_per_step": resident_ms, "steps": steps,
-          "what": "the default workload on uint8 frames resident in HBM (mi_corner_response_u8 / mi_sparse_bad_u8)",
+          "what": "the default workload on uint8 frames resident in HBM (mi_corner_response_balanced / mi_sparse_bad_u8)",
           "mean_valid_matches_per_pair": float(rec[..., 5].sum().item()) / B,
-          "roofline": k1_roofline(float(np.mean(k1)), 5.0, B, "corner_stream_kernel<3,5,uint8> (mi_corner_response_u8)",
+          "roofline": k1_roofline(float(np.mean(k1)), 5.0, B, "corner_stream_kernel<3,5,uint8> (mi_corner_response_balanced)",
                                   "corner_stream_kernel<3,5,true>", B)}
 
     main = torch.cuda.current_stream()
@@ -342,7 +342,7 @@ def side_workload(args, rank, world, dev) -> None:
         h, w, k = 1080, 1920, 1024
         base = ShiTomasiSparseBADSinkhornMatcher(max_keypoints=k, **CFG)
         what = "Shi-Tomasi sparse pipeline, 1920x1080, K=1024 (BASELINE configs[2])"
-        roof = ("mi_corner_response", "corner_stream_kernel<3,4> (mi_corner_response)", 8.0, 1)
+        roof = ("mi_corner_response_balanced", "corner_stream_kernel<3,4> (mi_corner_response_balanced)", 8.0, 1)
     else:
         h, w, k = H, W, K
         # export_akaze_sparse_bad_sinkhorn.py defaults: 256 pairs, no binarisation, NMS radius 3
@@ -455,7 +455,7 @@ def main() -> None:
 
     # HIP events around the roofline kernel's calls only (two per step) inside the timed region; the per-stage table
     # below comes from extra steps after it, so its 24 events per step do not sit in the measurement
-    _native.enable_timing(True, only=None if args.single_call else {"mi_corner_response"})
+    _native.enable_timing(True, only=None if args.single_call else {"mi_corner_response_balanced"})
     elapsed_ms, per_step, out = run_timed(step, args.steps, args.warmup, world, dev, torch.cuda.synchronize)
     per_call = _native.timings_ms()
     _native.enable_timing(False)
@@ -499,8 +499,8 @@ def main() -> None:
         if not args.single_call:
             # K1 corner response: 8 algorithmic bytes per pixel (4 read + 4 written); one launch covers one image of
             # every pair of this rank, two launches per step
-            k1 = per_call["mi_corner_response"][2 * args.warmup:]
-            line["roofline"] = k1_roofline(float(np.mean(k1)), 8.0, B, "corner_stream_kernel<3,4,float> (mi_corner_response)",
+            k1 = per_call["mi_corner_response_balanced"][2 * args.warmup:]
+            line["roofline"] = k1_roofline(float(np.mean(k1)), 8.0, B, "corner_stream_kernel<3,4,float> (mi_corner_response_balanced)",
                                            "corner_stream_kernel<3,4,false>", B)
             # informational: the other stages by their algorithmic bytes / operations
             other = {}

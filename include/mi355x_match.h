@@ -73,6 +73,14 @@ int mi_corner_response(const float *image, int n, int h, int w, int block_size, 
 int mi_corner_response_u8(const uint8_t *image, int n, int h, int w, int block_size, float *score,
                           mi_stream_t stream);
 int mi_convert_u8_f32(const uint8_t *src, long long count, float *dst, mi_stream_t stream);
+/* mi_corner_response / _u8 (pixels_are_u8 = 0 / 1) with dynamic tile scheduling for large batches: tile_counter =
+ * MI_TILE_COUNTER_BYTES of device memory that are ZERO when the call is issued; the kernel leaves them zero, so one
+ * counter block serves every call of one stream (calls on different streams need different blocks).  NULL = the static
+ * schedule of the two entry points above.  Same scores; equally sized static shares do not finish together because
+ * the SIMDs issue oldest-first, tickets make them. */
+#define MI_TILE_COUNTER_BYTES 16640
+int mi_corner_response_balanced(const void *image, int pixels_are_u8, int n, int h, int w, int block_size, float *score,
+                                uint32_t *tile_counter, mi_stream_t stream);
 
 /* ---- utils/keypoint_utils.py:12-44  apply_nms_maxpool ---------------------------------------
  * mask = 1.0f where score >= max over the (2r+1)^2 window (outside image = -inf) - 1e-7. */

@@ -24,6 +24,8 @@ extern "C" {
 int mi_debug_set(int key, int value);
 /* top-k kernel phase time stamps (100 MHz clock) of workgroup 0 into `buffer` (8 x uint64, device memory); NULL = off */
 int mi_debug_topk_stamps(void *buffer);
+/* streaming corner kernel: {shader clock, 100 MHz clock} at entry and exit of workgroup 0 into `buffer` (4 x uint64) */
+int mi_debug_clock_probe(void *buffer);
 
 #ifdef __cplusplus
 }

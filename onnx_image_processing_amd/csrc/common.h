@@ -164,7 +164,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // include/mi355x_match.h with `MiSets` in place of a single batch pointer.  mi_match_pairs uses them to put both images
 // of every pair behind one launch per stage when the batch is small (the one-pair-per-call latency path).
 int mi_corner_response_sets(MiSets images, int pix_u8, int n, int h, int w, int block_size, float *score,
-                            mi_stream_t stream);
+                            unsigned *tile_ctr, mi_stream_t stream);
 int mi_topk_keypoints_sets(const uint64_t *cand, const uint32_t *count, int segments, int segment_capacity, int n, int w,
                            int k, MiSets keypoints, float *kscores, mi_stream_t stream);
 int mi_sparse_bad_sets(MiSets images, int pix_u8, int n, int h, int w, MiSets keypoints, int k, const uint32_t *pair_geom,

@@ -26,7 +26,15 @@ extern std::atomic<int> mi_g_sinkhorn_stamps;
 
 namespace {
 
+std::atomic<unsigned long long *> g_corner_clk{nullptr};   // mi_debug_clock_probe (development aid)
+
 constexpr int TW = 128;  // tile width: 32 threads x 4 pixels
+#ifndef MI_K1_POOLS
+#define MI_K1_POOLS 64
+#endif
+constexpr int K1_POOLS = MI_K1_POOLS;          // ticket counters of the dynamic tile schedule (corner_stream_kernel)
+constexpr int K1_POOL_STRIDE = 64;             // words between them: 256 B, one memory channel each
+static_assert((K1_POOLS * K1_POOL_STRIDE + 1) * 4 <= MI_TILE_COUNTER_BYTES, "include/mi355x_match.h: MI_TILE_COUNTER_BYTES");
 constexpr int LPAD = 4;  // LDS padding each side, one float4 (>= 1 + block/2 for block <= 7)
 constexpr int LW4 = (TW + 2 * LPAD) / 4;
 
@@ -497,15 +505,40 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(MiSets images,
 // PIX = float: 16-byte pieces (global_load_lds_dwordx4), 8 B/px of HBM traffic per pixel (4 read + 4 written).
 // PIX = uint8_t (the u8 ingest path): the same chunk grid with 4-byte pieces (global_load_lds_dword, 4 pixels
 // each), 5 B/px; the tile is a quarter of the LDS, the stencil converts on the LDS read (load_window).
+// Tile schedule.  Static (tile_ctr == NULL): workgroup b takes tiles b, b + G, b + 2G, ...  Measured on 448 images
+// (mi_debug_clock_probe): every workgroup starts within 0.7 us, yet they finish between 132 and 226 us (uint8: 63 ...
+// 232 us) although each owns the same number of tiles, and the lifetime grows with blockIdx -- the SIMDs issue
+// oldest-first, so of the 4-6 workgroups sharing a CU the first dispatched runs at nearly full speed and the last gets
+// what is left; the kernel lasts as long as the youngest workgroup, the CUs thinning out on the way.
+// Dynamic (tile_ctr != NULL): the first two tiles are static, every further one comes from a ticket counter, so all
+// workgroups finish together.  K1_POOLS counters, 256 B apart: workgroup b draws from pool b % K1_POOLS (its members sit
+// on one XCD and come from every dispatch-age class), ticket k of pool p is tile 2G + k * K1_POOLS + p.  ONE counter
+// does not do: same-address atomics retire at about one per 12 ns, 32,000 tickets then take 390 us (measured) where
+// the whole kernel should take 200.  Lane 0 draws the ticket of tile i + 2 at the start of tile i, BEFORE the DMA
+// pieces of tile i + 1, as inline asm returning into an AGPR: a compiler-visible returning atomic makes hipcc wait
+// vmcnt(0) where its value joins the control flow (which drains the DMA just issued), whereas here the value is waited
+// for with a COUNTED wait at the end of the tile (vmcnt(NCH + R): in-order retirement, the DMA pieces and the tile's
+// stores were issued after it) and the AGPR keeps the register allocator from copying it while it is in flight.
 template <int BS, int R, bool U8>
 __global__ __launch_bounds__(256) void corner_stream_kernel(MiSets images,
                                                             float *__restrict__ score, int h, int w,
-                                                            int tiles_x, int tiles_y, int total_tiles) {
+                                                            int tiles_x, int tiles_y, int total_tiles,
+                                                            unsigned *tile_ctr, unsigned long long *clk) {
+  // development aid (mi_debug_clock_probe): every workgroup records the shader clock (s_memtime) and the constant
+  // 100 MHz clock at entry and exit -> the SCLK the kernel ran at and the workgroups' lifetimes
+  if (clk && threadIdx.x == 0) { clk[4 * blockIdx.x + 0] = clock64(); clk[4 * blockIdx.x + 1] = wall_clock64(); }
   using CH = typename std::conditional<U8, uint32_t, float4>::type;   // 4 pixels
   constexpr int HP = BS / 2, HL = HP + 1, TH = 8 * R, LH = TH + 2 * HL;
   constexpr int NCH = (LH * LW4 + 255) / 256;   // DMA pieces per wave per tile
   constexpr int BUF = NCH * 256;                // chunk slots per buffer (tail slots are scratch)
+  // ONE LDS object on purpose, and not a byte more than the two tile buffers (fp32: 2 x 20 KiB, exactly four workgroups
+  // per CU): the ticket travels through the last scratch slot of the buffer that has just been computed -- no DMA is in
+  // flight for it, the next one is issued only after the slot has been read.  With a second __shared__ variable the LDS
+  // lowering attaches alias scopes, the waitcnt pass then knows that the tile reads may
+  // alias the LDS-DMA writes and puts `s_waitcnt vmcnt(0)` in front of the first tile read of every iteration -- which
+  // drains the DMA just issued for the NEXT tile (checked in the .s: the only vmcnt waits are the two hand-placed ones)
   __shared__ CH lds[2 * BUF];
+  static_assert(LH * LW4 < BUF, "the ticket slot needs one scratch chunk slot");
 
   const int t = threadIdx.x;
   const int wave_base = t & ~63;
@@ -545,24 +578,35 @@ __global__ __launch_bounds__(256) void corner_stream_kernel(MiSets images,
     }
   };
 
+  const int G = (int)gridDim.x;
+  unsigned *my_ctr = tile_ctr + (blockIdx.x % K1_POOLS) * K1_POOL_STRIDE;
+  const int pool_base = 2 * G + (int)(blockIdx.x % K1_POOLS);
   int v = blockIdx.x;
   if (v >= total_tiles) return;
   int img, x0, y0;
   decode(v, img, x0, y0);
   issue(img, x0, y0, 0);
   bool prev_full = false;                         // previous tile issued exactly R stores per lane
-  for (int it = 0; v < total_tiles; v += gridDim.x, ++it) {
+  for (int it = 0; v < total_tiles; ++it) {
     const int cur = it & 1;
-    const int nxt = v + (int)gridDim.x;
     // This tile's DMA pieces were issued BEFORE the previous tile's R stores, and vmcnt retires
     // in issue order: leaving R operations outstanding waits for the DMA but not for the stores.
     if (prev_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tile_ctr) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // lane 0's ticket slot write
     // One barrier per tile: every wave's pieces have landed, and every wave has finished
     // computing the previous tile, whose buffer the next DMA is about to overwrite.
     __builtin_amdgcn_s_barrier();
+    int nxt = v + G;                               // static schedule; also the dynamic one's second tile
+    if (tile_ctr && it > 0) nxt = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(&lds[(cur ^ 1) * BUF + BUF - 1]));
     int nimg = 0, nx0 = 0, ny0 = 0;
-    if (nxt < total_tiles) {
+    const bool more = nxt < total_tiles;           // workgroup-uniform
+    unsigned ticket = 0u;
+    if (more) {
+      if (tile_ctr && t == 0) {
+        const unsigned zero = 0u, one = 1u;
+        asm volatile("global_atomic_add %0, %1, %2, %3 sc0 ; MI_TICKET_DRAW" : "=a"(ticket) : "v"(zero), "a"(one), "s"(my_ctr) : "memory");
+      }
       decode(nxt, nimg, nx0, ny0);
       issue(nimg, nx0, ny0, cur ^ 1);
     }
@@ -570,8 +614,27 @@ __global__ __launch_bounds__(256) void corner_stream_kernel(MiSets images,
     const CH *tile = &lds[cur * BUF];
     if constexpr (U8 && BS == 3) corner_compute_u8<R>(tile, score, img, h, w, x0, y0, t);
     else corner_compute<BS, R>(tile, score, img, h, w, x0, y0, t);
-    img = nimg; x0 = nx0; y0 = ny0;
+    if (tile_ctr && more) {
+      // the ticket (tile it + 2): NCH DMA pieces and, on a full tile, R stores were issued after the atomic
+      // (one tied statement only: with two, the register copy of the other path lands before its wait)
+      if (!prev_full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%1) ; MI_TICKET_WAIT" : "+a"(ticket) : "n"(NCH + R) : "memory");
+      if (t == 0) *reinterpret_cast<int *>(&lds[cur * BUF + BUF - 1]) = pool_base + (int)min(ticket, 0x1ffffffu) * K1_POOLS;
+    }
+    v = nxt; img = nimg; x0 = nx0; y0 = ny0;
   }
+  if (tile_ctr && t < 64) {
+    // leave the counters as they were found (zero): the workgroup that reports done last resets them (every ticket of
+    // a workgroup has been waited for before it reports, so no late increment can follow the reset)
+    unsigned done = 0u;
+    if (t == 0) done = atomicAdd(tile_ctr + K1_POOLS * K1_POOL_STRIDE, 1u);
+    done = (unsigned)__builtin_amdgcn_readfirstlane((int)done);
+    if (done == (unsigned)G - 1u) {
+      for (int p = t; p < K1_POOLS; p += 64) __hip_atomic_store(tile_ctr + p * K1_POOL_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == 0) __hip_atomic_store(tile_ctr + K1_POOLS * K1_POOL_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (clk && threadIdx.x == 0) { clk[4 * blockIdx.x + 2] = clock64(); clk[4 * blockIdx.x + 3] = wall_clock64(); }
 }
 
 // Generic path: any width, any odd block size.  One thread per pixel, straight from global
@@ -621,7 +684,7 @@ int launch_tile(MiSets image, int n, int h, int w, float *score, hipStream_t s) 
 
 // Persistent grid: 2 workgroups per CU (2 x 80 KiB of LDS) on the 256 CUs of an MI355X.
 template <int BS, int R, typename PIX>
-int launch_stream(MiSets image, int n, int h, int w, float *score, hipStream_t s) {
+int launch_stream(MiSets image, int n, int h, int w, float *score, unsigned *tile_ctr, hipStream_t s) {
   const int tiles_x = ceil_div(w, TW), tiles_y = ceil_div(h, 8 * R);
   const long long total = (long long)n * tiles_x * tiles_y;
   if (total > 0x7fffffffLL) return MI_E_SHAPE;
@@ -630,17 +693,19 @@ int launch_stream(MiSets image, int n, int h, int w, float *score, hipStream_t s
   constexpr int PIECE = std::is_same<PIX, float>::value ? 16 : 4;
   constexpr int LDS_BYTES = 2 * ((LH * LW4 + 255) / 256) * 256 * PIECE;
   constexpr int PER_CU_LDS = (160 * 1024) / LDS_BYTES;
-  // fp32: LDS allows 4 workgroups per CU.  uint8: LDS would allow 16; the integer stencil needs 78-80 VGPRs at 4 or 5
-  // rows per thread (6 waves per SIMD) and 98 at 8 rows (4-5).
+  // fp32: LDS allows 4 workgroups per CU.  uint8: LDS would allow 16; the integer stencil needs 82-86 VGPRs at 4 or 5
+  // rows per thread (5 waves per SIMD) and 102 at 8 rows (4).
 #ifdef MI_K1_U8_PER_CU
   constexpr int PER_CU = std::is_same<PIX, float>::value ? (PER_CU_LDS > 8 ? 8 : PER_CU_LDS) : MI_K1_U8_PER_CU;
 #else
-  constexpr int PER_CU = std::is_same<PIX, float>::value ? (PER_CU_LDS > 8 ? 8 : PER_CU_LDS) : (R <= 5 ? 6 : 4);
+  constexpr int PER_CU = std::is_same<PIX, float>::value ? (PER_CU_LDS > 8 ? 8 : PER_CU_LDS) : (R <= 5 ? 5 : 4);
 #endif
   const int resident = 256 * PER_CU;
   const int grid = total < resident ? (int)total : resident;
-  hipLaunchKernelGGL((corner_stream_kernel<BS, R, std::is_same<PIX, uint8_t>::value>), dim3(grid), dim3(256), 0, s,
-                     image, score, h, w, tiles_x, tiles_y, (int)total);
+  // dynamic schedule only when a workgroup owns more than two tiles
+  unsigned *ctr = total > 2LL * grid ? tile_ctr : nullptr;
+  hipLaunchKernelGGL((corner_stream_kernel<BS, R, std::is_same<PIX, uint8_t>::value>), dim3(grid), dim3(256), 0,
+                     s, image, score, h, w, tiles_x, tiles_y, (int)total, ctr, g_corner_clk.load(std::memory_order_relaxed));
   return mi_launch_status();
 }
 
@@ -652,6 +717,14 @@ std::atomic<int> g_corner_rows_u8_default{1};   // 1 until mi_debug_set(2, .) is
 
 // Development/test hook (include/mi355x_match_debug.h, not part of the product ABI): select between equivalent
 // kernel implementations (results identical).  Process-wide atomics: a value set here is seen by every later call.
+// development aid (include/mi355x_match_debug.h): every workgroup of the streaming corner kernel writes
+// {s_memtime, 100 MHz clock} at entry and exit into `buffer` (4 x uint64 per workgroup of the persistent grid,
+// <= 2048 workgroups; device memory); NULL = off
+extern "C" int mi_debug_clock_probe(void *buffer) {
+  g_corner_clk = reinterpret_cast<unsigned long long *>(buffer);
+  return MI_OK;
+}
+
 extern "C" int mi_debug_set(int key, int value) {
   if (key == 1) { g_corner_impl = value; return MI_OK; }
   if (key == 4) { mi_g_sinkhorn_log_partials = value; return MI_OK; }
@@ -665,7 +738,7 @@ extern "C" int mi_debug_set(int key, int value) {
 
 // The shared launcher: `images` names one batch or two (MiSets), n = the total number of images.
 int mi_corner_response_sets(MiSets images, int pix_u8, int n, int h, int w, int block_size, float *score,
-                            mi_stream_t stream) {
+                            unsigned *tile_ctr, mi_stream_t stream) {
   if (!images.a || (images.per_set < n && !images.b) || !score) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
   if (block_size <= 0 || (block_size & 1) == 0) return MI_E_PARAM;
@@ -680,9 +753,9 @@ int mi_corner_response_sets(MiSets images, int pix_u8, int n, int h, int w, int 
     if (aligned && h >= 4 && w >= 8 && block_size == 3) {
       // 5 rows per thread unless the test hook asks otherwise (measured per 448 images: 217 us at 5 rows, 221 at 8,
       // 259 at 4 -- the fp32 kernel's best -- with 6 workgroups per CU)
-      if (rows == 8) return launch_stream<3, 8, uint8_t>(images, n, h, w, score, s);
-      if (rows == 4 && g_corner_rows_u8_default.load(std::memory_order_relaxed) == 0) return launch_stream<3, 4, uint8_t>(images, n, h, w, score, s);
-      return launch_stream<3, 5, uint8_t>(images, n, h, w, score, s);
+      if (rows == 8) return launch_stream<3, 8, uint8_t>(images, n, h, w, score, tile_ctr, s);
+      if (rows == 4 && g_corner_rows_u8_default.load(std::memory_order_relaxed) == 0) return launch_stream<3, 4, uint8_t>(images, n, h, w, score, tile_ctr, s);
+      return launch_stream<3, 5, uint8_t>(images, n, h, w, score, tile_ctr, s);
     }
     if (blocks > 0x7fffffffULL) return MI_E_SHAPE;
     hipLaunchKernelGGL(corner_generic_kernel<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, s, images, score, n, h, w,
@@ -692,9 +765,9 @@ int mi_corner_response_sets(MiSets images, int pix_u8, int n, int h, int w, int 
   const bool aligned = (w % 4 == 0) && ((bases | (uintptr_t)score) % 16 == 0);
   if (aligned && h >= 4 && w >= 8) {
     if (block_size == 3 && g_corner_impl.load(std::memory_order_relaxed) == 0) {
-      if (rows == 4) return launch_stream<3, 4, float>(images, n, h, w, score, s);
-      if (rows == 5) return launch_stream<3, 5, float>(images, n, h, w, score, s);
-      return launch_stream<3, 8, float>(images, n, h, w, score, s);
+      if (rows == 4) return launch_stream<3, 4, float>(images, n, h, w, score, tile_ctr, s);
+      if (rows == 5) return launch_stream<3, 5, float>(images, n, h, w, score, tile_ctr, s);
+      return launch_stream<3, 8, float>(images, n, h, w, score, tile_ctr, s);
     }
     if (block_size == 3) return launch_tile<3, 8>(images, n, h, w, score, s);
     if (block_size == 5) return launch_tile<5, 8>(images, n, h, w, score, s);
@@ -709,7 +782,7 @@ int mi_corner_response_sets(MiSets images, int pix_u8, int n, int h, int w, int 
 extern "C" int mi_corner_response(const float *image, int n, int h, int w, int block_size, float *score,
                                   mi_stream_t stream) {
   MI_ENTER();
-  return mi_corner_response_sets(mi_one_set(image, n), 0, n, h, w, block_size, score, stream);
+  return mi_corner_response_sets(mi_one_set(image, n), 0, n, h, w, block_size, score, nullptr, stream);
 }
 
 // u8 ingest (the camera-frame path of sample/visual_odometry.py:65-92 without the host-side
@@ -717,5 +790,17 @@ extern "C" int mi_corner_response(const float *image, int n, int h, int w, int b
 extern "C" int mi_corner_response_u8(const uint8_t *image, int n, int h, int w, int block_size, float *score,
                                      mi_stream_t stream) {
   MI_ENTER();
-  return mi_corner_response_sets(mi_one_set(image, n), 1, n, h, w, block_size, score, stream);
+  return mi_corner_response_sets(mi_one_set(image, n), 1, n, h, w, block_size, score, nullptr, stream);
+}
+
+// The same two calls with a tile counter: 8 bytes of device memory (two uint32, 4-byte aligned) that are ZERO when the
+// call is issued and that the kernel leaves zero, owned by one stream at a time.  With it, large batches hand the
+// tiles of the streaming kernel out dynamically (see the schedule note at corner_stream_kernel): same scores, the
+// launch ends when the work does instead of when the youngest workgroup's fixed share does.
+extern "C" int mi_corner_response_balanced(const void *image, int pixels_are_u8, int n, int h, int w, int block_size,
+                                           float *score, uint32_t *tile_counter, mi_stream_t stream) {
+  MI_ENTER();
+  if (tile_counter && ((uintptr_t)tile_counter % 4) != 0) return MI_E_ALIGN;
+  return mi_corner_response_sets(mi_one_set(image, n), pixels_are_u8 ? 1 : 0, n, h, w, block_size, score, tile_counter,
+                                 stream);
 }

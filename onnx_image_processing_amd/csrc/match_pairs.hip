@@ -42,6 +42,7 @@ struct Layout {
   float *kscores;               // (batch, K), scratch (keypoint scores are not an output of the wrapper)
   uint32_t *bits1, *bits2;      // (batch, K, P/32)
   uint8_t *status;              // (sides * batch, K)
+  uint32_t *tile_ctr;           // K1's ticket counters (MI_TILE_COUNTER_BYTES, cleared per call)
   uint16_t *dots;               // (batch, K, pitch)
   float *row_info, *col_info;   // (batch, K, 2)
   float *u, *v;                 // (batch, K+1)
@@ -71,6 +72,7 @@ int lay_out(void *ws, int batch, int h, int w, int k, int num_pairs, Layout *L) 
   L->bits1 = c.take<uint32_t>(2 * (size_t)batch * k * (num_pairs / 32));
   L->bits2 = L->bits1 + (size_t)batch * k * (num_pairs / 32);
   L->status = c.take<uint8_t>(nb * k);
+  L->tile_ctr = c.take<uint32_t>(MI_TILE_COUNTER_BYTES / 4);
   L->dots = c.take<uint16_t>((size_t)batch * k * L->pitch);
   L->row_info = c.take<float>((size_t)batch * k * 2);
   L->col_info = c.take<float>((size_t)batch * k * 2);
@@ -100,8 +102,8 @@ extern "C" size_t mi_match_pairs_workspace_bytes(int batch, int h, int w, const 
 }
 
 namespace {
-int corner_of(const float *im, int n, int h, int w, int bs, float *score, mi_stream_t s) { return mi_corner_response(im, n, h, w, bs, score, s); }
-int corner_of(const uint8_t *im, int n, int h, int w, int bs, float *score, mi_stream_t s) { return mi_corner_response_u8(im, n, h, w, bs, score, s); }
+int corner_of(const float *im, int n, int h, int w, int bs, float *score, uint32_t *ctr, mi_stream_t s) { return mi_corner_response_balanced(im, 0, n, h, w, bs, score, ctr, s); }
+int corner_of(const uint8_t *im, int n, int h, int w, int bs, float *score, uint32_t *ctr, mi_stream_t s) { return mi_corner_response_balanced(im, 1, n, h, w, bs, score, ctr, s); }
 int bad_bits_of(const float *im, int n, int h, int w, const float *kp, int k, const mi_match_params *p, uint32_t *bits,
                 uint8_t *status, mi_stream_t s) {
   return mi_sparse_bad(im, n, h, w, kp, k, p->pair_geom, p->pair_thr, p->num_pairs, MI_BAD_HARD, 0.0f,
@@ -136,7 +138,7 @@ int match_pairs_impl(const PIX *image1, const PIX *image2, int batch, int h, int
     // both images of every pair behind one launch per stage (items 0..batch-1 = image1, batch..2*batch-1 = image2)
     const MiSets imgs{image1, image2, batch}, kps{keypoints1, keypoints2, batch};
     const int n2 = 2 * batch;
-    if ((e = mi_corner_response_sets(imgs, U8, n2, h, w, params->block_size, L.score, stream)) != MI_OK) return e;
+    if ((e = mi_corner_response_sets(imgs, U8, n2, h, w, params->block_size, L.score, nullptr, stream)) != MI_OK) return e;
     if ((e = mi_nms_candidates(L.score, n2, h, w, params->nms_radius, params->score_threshold, params->border_margin, L.cand,
                                L.count, stream)) != MI_OK)
       return e;
@@ -146,12 +148,14 @@ int match_pairs_impl(const PIX *image1, const PIX *image2, int batch, int h, int
                                 params->bad_plan ? L.status : nullptr, stream)) != MI_OK)
       return e;
   } else {
+    // one image side per launch; K1 hands its tiles out dynamically (counter cleared here, left zero by the kernel)
+    if (hipMemsetAsync(L.tile_ctr, 0, MI_TILE_COUNTER_BYTES, (hipStream_t)stream) != hipSuccess) return mi_launch_status() ? mi_launch_status() : MI_E_PARAM;
     const PIX *images[2] = {image1, image2};
     float *kpts[2] = {keypoints1, keypoints2};
     uint32_t *bits[2] = {L.bits1, L.bits2};
     for (int side = 0; side < 2; ++side) {
       // detector/shi_tomasi.py:66-112, utils/keypoint_utils.py:12-117 (mask never materialised)
-      if ((e = corner_of(images[side], batch, h, w, params->block_size, L.score, stream)) != MI_OK) return e;
+      if ((e = corner_of(images[side], batch, h, w, params->block_size, L.score, L.tile_ctr, stream)) != MI_OK) return e;
       if ((e = mi_nms_candidates(L.score, batch, h, w, params->nms_radius, params->score_threshold, params->border_margin,
                                  L.cand, L.count, stream)) != MI_OK)
         return e;

@@ -63,15 +63,39 @@ __global__ __launch_bounds__(256) void mnn_col_kernel(const float *__restrict__ 
   }
 }
 
+// col_part != NULL (m <= 1024): the per-band column winners of mnn_band_kernel are merged here, in the prologue, instead
+// of by a separate mnn_colmerge_kernel launch (one dependent launch less; what one pair per call is made of)
 __global__ __launch_bounds__(MX_THREADS) void mnn_select_kernel(
     int n, int m, const uint64_t *__restrict__ row_best, const uint64_t *__restrict__ col_best,
+    const uint64_t *__restrict__ col_part, int nb,
     const float *__restrict__ kpts1, const float *__restrict__ kpts2, int max_matches, float threshold,
     float *__restrict__ mk1, float *__restrict__ mk2, float *__restrict__ scores,
     uint8_t *__restrict__ valid, int32_t *__restrict__ match_ij) {
   __shared__ uint64_t keys[MX_MAX];
+  __shared__ uint64_t cmerged[1024];
   const int t = threadIdx.x, b = blockIdx.x;
   const uint64_t *rb = row_best + (size_t)b * n;
   const uint64_t *cb = col_best + (size_t)b * m;
+  if (col_part) {
+    for (int j = t; j < m; j += MX_THREADS) {
+      uint64_t k = 0ull;
+      int band = 0;
+      for (; band + 8 <= nb; band += 8) {            // eight loads in flight
+        uint64_t c[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c[q] = col_part[((size_t)b * nb + band + q) * m + j];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) k = c[q] > k ? c[q] : k;
+      }
+      for (; band < nb; ++band) {
+        const uint64_t c = col_part[((size_t)b * nb + band) * m + j];
+        k = c > k ? c : k;
+      }
+      cmerged[j] = k;
+    }
+    __syncthreads();
+    cb = cmerged;
+  }
   int npad = 2;
   while (npad < n) npad <<= 1;
   for (int i = t; i < npad; i += MX_THREADS) {
@@ -349,10 +373,17 @@ int mnn_from_source(SRC src, const float2 *col_info, int batch, int n, int m, co
     hipLaunchKernelGGL((mnn_band_kernel<SRC, 2, 4, 8>), dim3(nb, batch), dim3(512), 0, s, src, n, m, u, v, col_info,
                        w.row_best, w.col_part);
   }
+  if (batch <= 32) {
+    // few pairs: the select kernel merges the bands' column winners itself (one launch less on the latency path)
+    hipLaunchKernelGGL(mnn_select_kernel, dim3(batch), dim3(MX_THREADS), 0, s, n, m, w.row_best, w.col_best,
+                       (const uint64_t *)w.col_part, nb, kpts1, kpts2, max_matches, threshold, mk1, mk2, scores, valid,
+                       match_ij);
+    return mi_launch_status();
+  }
   hipLaunchKernelGGL(mnn_colmerge_kernel, dim3(ceil_div(m, 256), batch), dim3(256), 0, s, w.col_part, nb, m,
                      w.col_best);
-  hipLaunchKernelGGL(mnn_select_kernel, dim3(batch), dim3(MX_THREADS), 0, s, n, m, w.row_best, w.col_best, kpts1,
-                     kpts2, max_matches, threshold, mk1, mk2, scores, valid, match_ij);
+  hipLaunchKernelGGL(mnn_select_kernel, dim3(batch), dim3(MX_THREADS), 0, s, n, m, w.row_best, w.col_best,
+                     (const uint64_t *)nullptr, 0, kpts1, kpts2, max_matches, threshold, mk1, mk2, scores, valid, match_ij);
   return mi_launch_status();
 }
 
@@ -408,8 +439,8 @@ extern "C" int mi_mnn_extract(const float *p, int batch, int n, int m, const flo
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(mnn_row_kernel, dim3(ceil_div(n, 4), batch), dim3(256), 0, s, p, n, m, row_best);
   hipLaunchKernelGGL(mnn_col_kernel, dim3(ceil_div(m, 64), batch), dim3(256), 0, s, p, n, m, col_best);
-  hipLaunchKernelGGL(mnn_select_kernel, dim3(batch), dim3(MX_THREADS), 0, s, n, m, row_best, col_best, kpts1,
-                     kpts2, max_matches, threshold, mk1, mk2, scores, valid, match_ij);
+  hipLaunchKernelGGL(mnn_select_kernel, dim3(batch), dim3(MX_THREADS), 0, s, n, m, row_best, col_best,
+                     (const uint64_t *)nullptr, 0, kpts1, kpts2, max_matches, threshold, mk1, mk2, scores, valid, match_ij);
   return mi_launch_status();
 }
 

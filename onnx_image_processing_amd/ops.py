@@ -36,16 +36,27 @@ def _images(image: torch.Tensor, what: str, keep_u8: bool = False) -> torch.Tens
     return image.float().contiguous()
 
 
+TILE_COUNTER_BYTES = 16640          # include/mi355x_match.h MI_TILE_COUNTER_BYTES
+_tile_counters: dict = {}
+
+
+def _tile_counter(device: torch.device) -> torch.Tensor:
+    """K1's tile counter (mi_corner_response_balanced): MI_TILE_COUNTER_BYTES zero bytes per (device, stream); the kernel leaves them zero."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ctr = _tile_counters.get(key)
+    if ctr is None:
+        ctr = torch.zeros(TILE_COUNTER_BYTES // 4, dtype=torch.int32, device=device)
+        _tile_counters[key] = ctr
+    return ctr
+
+
 def corner_response(image: torch.Tensor, block_size: int) -> torch.Tensor:
     img = _images(image, "image", keep_u8=True)
     n, _, h, w = img.shape
     out = torch.empty(img.shape, dtype=F32, device=img.device)
-    if img.dtype == U8:
-        N.call("mi_corner_response_u8", N.dev(img, U8, "image"), n, h, w, int(block_size), N.dev(out, F32, "score"),
-               N.stream_ptr())
-    else:
-        N.call("mi_corner_response", N.dev(img, F32, "image"), n, h, w, int(block_size), N.dev(out, F32, "score"),
-               N.stream_ptr())
+    u8 = img.dtype == U8
+    N.call("mi_corner_response_balanced", N.dev(img, U8 if u8 else F32, "image"), int(u8), n, h, w, int(block_size),
+           N.dev(out, F32, "score"), _tile_counter(img.device).data_ptr(), N.stream_ptr())
     return out
 
 

@@ -1176,6 +1176,26 @@ def test_corner_u8_equals_f32_and_oracle(mods, shape):
     assert torch.equal(mods["ShiTomasiScore"](3)(view), mods["ShiTomasiScore"](3)(gpu(img)))
 
 
+def test_corner_ticket_schedule_equals_static(mods):
+    """mi_corner_response_balanced on a batch large enough for the ticket schedule (> 2 tiles per persistent workgroup):
+    the score map is the static schedule's (mi_corner_response / _u8) bit for bit, the counter block is left zero, and
+    a second call on the same block gives the same map; rows of the oracle spot-checked."""
+    from onnx_image_processing_amd import _native as N, ops
+    n, h, w = 120, 480, 640                                      # 9,000 tiles of 128 x 32 on 1,024 workgroups
+    base = np.stack([synth_image(900 + i, h, w) for i in range(6)])[:, None]
+    img8 = gpu(np.tile(base, (n // 6, 1, 1, 1)))
+    ctr = torch.zeros(ops.TILE_COUNTER_BYTES // 4, dtype=torch.int32, device=DEV)
+    for x, u8, static in ((img8.float(), 0, "mi_corner_response"), (img8, 1, "mi_corner_response_u8")):
+        want = torch.empty((n, 1, h, w), dtype=torch.float32, device=DEV)
+        N.call(static, x.data_ptr(), n, h, w, 3, want.data_ptr(), N.stream_ptr())
+        for _ in range(2):
+            got = torch.full((n, 1, h, w), -1.0, dtype=torch.float32, device=DEV)
+            N.call("mi_corner_response_balanced", x.data_ptr(), u8, n, h, w, 3, got.data_ptr(), ctr.data_ptr(), N.stream_ptr())
+            assert torch.equal(got, want)
+            assert int(ctr.abs().sum()) == 0
+    assert np.array_equal(want[:6].cpu().numpy(), O.shi_tomasi_score(base.astype(np.float32), 3))
+
+
 def test_u8_pipeline_equals_f32_on_the_c2_fixture(mods):
     """The north-star pair as uint8 frames: keypoints, packed bits, P, matches all `torch.equal` to the float32 path
     (which the other tests pin to the oracle and to the reference output), module path and the one-call form."""

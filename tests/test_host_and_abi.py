@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib_path):
 def test_binding_covers_the_header(lib_path):
     from onnx_image_processing_amd import _native
     assert sorted(_native.SIGNATURES) == header_functions()
-    assert sorted(_native.DEBUG_SIGNATURES) == header_functions(DEBUG_HEADER) == ["mi_debug_set", "mi_debug_topk_stamps"]
+    assert sorted(_native.DEBUG_SIGNATURES) == header_functions(DEBUG_HEADER) == ["mi_debug_clock_probe", "mi_debug_set", "mi_debug_topk_stamps"]
     _native.load()
 
 
@@ -223,7 +223,7 @@ def test_match_pairs_host_side_checks(lib_path):
     # up to 32 pairs both images share one launch per stage: 2 x (score map 1.2 MB + candidates 2.4 MB) + dots 0.5 MB +
     # the single-launch Sinkhorn's granules 0.13 MB + ...
     assert 7_500_000 < per_pair < 9_500_000
-    assert lib.mi_match_pairs_workspace_bytes(8, 480, 640, ctypes.byref(prm)) >= 8 * (per_pair - 8192)
+    assert lib.mi_match_pairs_workspace_bytes(8, 480, 640, ctypes.byref(prm)) >= 8 * (per_pair - 32768)   # fixed part: alignment + K1 ticket counters
     big = lib.mi_match_pairs_workspace_bytes(64, 480, 640, ctypes.byref(prm))     # one image side at a time
     assert 64 * 4_000_000 < big < 64 * 6_000_000
     for field, bad in (("max_keypoints", 2000), ("num_pairs", 100), ("block_size", 4), ("sinkhorn_iterations", 0),

@@ -31,3 +31,24 @@ for rows in (4, 5, 8):
         ms = s0.elapsed_time(e0) / 40
         print(f"rows {rows} {name}: {ms * 1e3:.1f} us per {n} images, {bpp * n * 480 * 640 / ms / 1e6:.0f} GB/s = {bpp * n * 480 * 640 / ms / 1e6 / 8000:.3f} of 8 TB/s")
 lib.mi_debug_set(2, 4)
+# per-workgroup lifetimes of the persistent grid: are all workgroups resident together?
+buf = torch.zeros(4 * 2048, dtype=torch.int64, device='cuda')
+lib.mi_debug_clock_probe(buf.data_ptr())
+for name, x in (("f32", img32), ("u8", img8)):
+    for _ in range(3):
+        buf.zero_()
+        ops.corner_response(x, 3)
+    torch.cuda.synchronize()
+    c = buf.cpu().numpy().astype(np.int64).reshape(-1, 4)
+    c = c[c[:, 1] > 0]
+    t0 = c[:, 1].min()
+    start, end = (c[:, 1] - t0) * 0.01, (c[:, 3] - t0) * 0.01
+    mhz = ((c[:, 2] - c[:, 0]) / np.maximum(1, (c[:, 3] - c[:, 1]) * 0.01)).mean()
+    life = end - start
+    bx = np.arange(len(c))
+    print("  lifetime by blockIdx % 8 (XCD):", np.array([life[bx % 8 == k].mean() for k in range(8)]).round(0))
+    print("  lifetime by (blockIdx // 8) % 32 :", np.array([life[(bx // 8) % 32 == k].mean() for k in range(32)]).round(0))
+    print("  lifetime by blockIdx quarter:", np.array([life[bx * 4 // len(c) == k].mean() for k in range(4)]).round(0))
+    print(f"{name}: {len(c)} workgroups, kernel {end.max():.1f} us, clock {mhz:.0f} MHz; starts: {np.percentile(start, [0, 50, 75, 90, 100]).round(1)} "
+          f"ends: {np.percentile(end, [0, 25, 50, 75, 100]).round(1)} lifetimes: {np.percentile(end - start, [0, 50, 100]).round(1)}")
+lib.mi_debug_clock_probe(None)
