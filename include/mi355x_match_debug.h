@@ -7,6 +7,8 @@
 #ifndef MI355X_MATCH_DEBUG_H
 #define MI355X_MATCH_DEBUG_H
 
+#include <stdint.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -24,8 +26,12 @@ extern "C" {
 int mi_debug_set(int key, int value);
 /* top-k kernel phase time stamps (100 MHz clock) of workgroup 0 into `buffer` (8 x uint64, device memory); NULL = off */
 int mi_debug_topk_stamps(void *buffer);
-/* streaming corner kernel: {shader clock, 100 MHz clock} at entry and exit of workgroup 0 into `buffer` (4 x uint64) */
+/* streaming corner kernel: every workgroup of the persistent grid writes {shader clock, 100 MHz clock} at entry and
+ * exit into `buffer` (4 x uint64 per workgroup, <= 2048 workgroups; device memory); NULL = off */
 int mi_debug_clock_probe(void *buffer);
+/* fast BAD kernel: LDS passes per keypoint of its gather schedule (csrc/bad_plan_opt.h) for a HOST copy of a pair table,
+ * as the table stands and as mi_bad_plan_build schedules it (num_pairs / 4 = conflict-free).  Host only, no GPU. */
+int mi_debug_bad_plan_passes(const uint32_t *pair_geom_host, int num_pairs, int *canonical, int *scheduled);
 
 #ifdef __cplusplus
 }

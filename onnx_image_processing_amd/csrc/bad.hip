@@ -29,8 +29,12 @@
 
 #include <math.h>
 
+#include <memory>
+#include <mutex>
 #include <type_traits>
 #include <vector>
+
+#include "bad_plan_opt.h"
 
 namespace {
 
@@ -41,14 +45,17 @@ constexpr int FR = 33;           // fast-path SAT rows / columns in use (32x32 w
 constexpr int FW = 35;           // its row pitch: odd (the table build walks rows and columns conflict-free) and, of
                                  // 33..39, the pitch with the fewest bank-conflict passes of the pair gathers (-8 % vs 33)
 
-// Device-resident plan for the fast path, built once per pair table by mi_bad_plan_build:
-// header, then uint4 offs[P] (eight 16-bit BYTE offsets into the int32 table of 33 rows, pitch FW: the four corners that
-// enter s1 - s2 with + in x, y, the four with - in z, w, low half first, in the order order_reads chose), then
-// int tint[P] = floor(thr * area).
+// Device-resident plan for the fast path, built once per pair table by mi_bad_plan_build.  Arrays indexed by
+// EXECUTION slot e = round * 64 + lane (bad_plan_opt.h: lane l evaluates its pairs l, l + 64, ... in the order that
+// minimises LDS bank conflicts): header, then uint4 offs[P] (eight 16-bit BYTE offsets into the int32 table of 33 rows,
+// pitch FW: the four corners that enter s1 - s2 with + in x, y, the four with - in z, w, low half first, in the
+// scheduled order), int tint[P] = floor(thr * area), uint32 geom[P] (the pair's table word, for the border branch), then
+// uint64 masks[rounds][rounds]: masks[g][G] = the lanes whose round-g pair belongs to the canonical 64-pair group G.
 struct BadPlan {
   int geometry_ok;   // every box of the table stays inside the 32x32 patch
   int num_pairs;
-  int pad[2];
+  int passes;        // LDS passes per keypoint of the scheduled gathers (num_pairs / 4 = conflict-free)
+  int passes_canonical;
 };
 
 // ATen grid_sampler semantics used by bad.py:518-556 (align_corners=True, padding "border",
@@ -137,6 +144,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   for (int r = 0; r < 16; ++r) px[r] = *reinterpret_cast<const PIX *>(reinterpret_cast<const char *>(im) + off[r]);
   const uint4 *plan_offs = reinterpret_cast<const uint4 *>(plan + 1);
   const int *plan_tint = reinterpret_cast<const int *>(plan_offs + num_pairs);
+  const uint32_t *plan_geom = reinterpret_cast<const uint32_t *>(plan_tint + num_pairs);
+  const unsigned long long *plan_masks = reinterpret_cast<const unsigned long long *>(plan_geom + num_pairs);
   // the first pair-table words ride behind the window gather instead of waiting for the table build
   constexpr int NPRE = GROUPS ? 3 : 0;
   uint4 o_pre[NPRE ? NPRE : 1];
@@ -166,6 +175,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   for (int r = 0; r < 16; ++r) isat[(16 * half + r + 1) * FW + c + 1] = col[r] + (half ? upper : 0);
   __builtin_amdgcn_wave_barrier();                 // same wave: DS operations execute in order
   {
+    // (the row direction as a DPP prefix sum in registers -- 96 more VALU, 32 fewer LDS instructions -- measured 8 %
+    // SLOWER: the kernel saturates VALU issue and the LDS array at the same time, PMC in DESIGN.md K4)
     int *row = isat + (c + 1) * FW + 16 * half + 1;   // lane = (half, row c): 16 entries of row c
     int v[16];
 #pragma unroll
@@ -179,15 +190,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   }
   __builtin_amdgcn_wave_barrier();
   const char *sbase = reinterpret_cast<const char *>(isat);
+  // round g of lane l evaluates a pair of some canonical 64-pair group G (same lane l): masks[g][G] = the lanes
+  // whose round-g pair belongs to group G, so word G of the packed descriptor, in the table's order, is the OR over
+  // the rounds of ballot & mask -- scalar work (the masks arrive by s_load), the vector unit only compares
   unsigned long long wordv[GMAX];
   int pop = 0;
-  auto emit = [&](int g, int d, int tint) {
-    const unsigned long long word = __ballot(d <= tint);                 // bad.py:567
-    wordv[g] = word;
-    pop += (int)__popcll(word);
-  };
 #pragma unroll
   for (int g = 0; g < GMAX; ++g) wordv[g] = 0ull;
+  auto emit = [&](int g, int d, int tint) {
+    const unsigned long long hit = __ballot(d <= tint);                   // bad.py:567
+    pop += (int)__popcll(hit);
+#pragma unroll
+    for (int G = 0; G < GMAX; ++G)
+      if (G < groups) wordv[G] |= hit & plan_masks[g * groups + G];
+  };
   if (interior) {                                                          // wave-uniform
     auto at = [&](uint32_t byte_off) { return *reinterpret_cast<const int *>(sbase + byte_off); };
 #pragma unroll
@@ -207,7 +223,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
     for (int g = 0; g < GMAX; ++g) {
       if (g < groups) {
-        const uint32_t q = geom[g * 64 + lane];
+        const uint32_t q = plan_geom[g * 64 + lane];
         const int tint = plan_tint[g * 64 + lane];
         const int rad = (int)((q >> 20) & 15u);
         auto box = [&](int offx, int offy) {
@@ -386,88 +402,90 @@ __global__ __launch_bounds__(64) void sparse_bad_kernel(MiSets images, int h, in
 
 // ---- plan construction (host) ---------------------------------------------------------------------
 // s1 - s2 = [(b,r)1 + (a,l)1 + (a,r)2 + (b,l)2] - [(a,r)1 + (b,l)1 + (b,r)2 + (a,l)2]: four table corners enter
-// with +, four with -, and inside a sign class the order in which a lane reads its corners is free.  The fast
-// kernel is bound by LDS bank conflicts on exactly these reads (64 scattered addresses per instruction, 3.5
-// passes on average), and the addresses are the same for every keypoint, so the order is chosen here, once per
-// table: for every group of 64 pairs (= the 64 lanes of a wave) and sign class, a few greedy sweeps over the
-// lanes pick, per lane, the permutation of its four corners that minimises the sum over the four read
-// instructions of the worst bank load (32 banks of 4 bytes, the two half-waves separately; equal addresses
-// broadcast); best of four starts.  450 -> 326 conflict passes on the 512-pair table at pitch 35 (216 -> 163 on the
-// 256-pair table; 128 / 64 would be conflict-free).
-int bank_passes(const uint16_t (&addr)[64][4], int slot) {
-  int total = 0;
-  for (int half = 0; half < 2; ++half) {
-    uint16_t words[32][32];
-    int count[32] = {};
-    int worst = 0;
-    for (int l = 32 * half; l < 32 * half + 32; ++l) {
-      const uint16_t word = addr[l][slot] >> 2;
-      const int bank = word & 31;
-      bool dup = false;
-      for (int k = 0; k < count[bank]; ++k) dup = dup || words[bank][k] == word;
-      if (!dup) words[bank][count[bank]++] = word;
-      worst = count[bank] > worst ? count[bank] : worst;
-    }
-    total += worst;
+// with +, four with -.  The fast kernel is bound by LDS bank conflicts on exactly these reads (64 scattered addresses
+// per instruction, 3.3 passes on average as the table stands), and the addresses are the same for every keypoint, so
+// their schedule -- which round a lane evaluates each of its pairs in, and in which order it reads the corners of a
+// sign class -- is chosen here, once per table: bad_plan_opt.h (420 -> 184 passes on the 512-pair table, 128 =
+// conflict-free; measured per 448 x 512 keypoints: uint8 frames 213 -> 180 us, fp32 frames 244 -> 240 us -- those wait
+// on their four times larger window gather instead).  The search takes a few hundred milliseconds, so schedules are kept per table content.
+struct HostPlan {
+  std::vector<uint32_t> geom;          // key: the table
+  bool geometry_ok = false;
+  mi::BadGatherSchedule sched;
+};
+
+std::vector<uint16_t> table_corners(const std::vector<uint32_t> &geom, bool *all_inside) {
+  const int num_pairs = (int)geom.size();
+  std::vector<uint16_t> c((size_t)num_pairs * 8);
+  bool ok = true;
+  auto word = [](int row, int col) { return (uint16_t)(row * FW + col); };
+  for (int p = 0; p < num_pairs; ++p) {
+    const uint32_t q = geom[p];
+    const int x1 = (int)(q & 31u), x2 = (int)((q >> 5) & 31u);
+    const int y1 = (int)((q >> 10) & 31u), y2 = (int)((q >> 15) & 31u);
+    const int r = (int)((q >> 20) & 15u);
+    const bool in = x1 - r >= 0 && x2 - r >= 0 && y1 - r >= 0 && y2 - r >= 0 && x1 + r <= 31 && x2 + r <= 31 &&
+                    y1 + r <= 31 && y2 + r <= 31;
+    ok = ok && in;
+    const int cx1 = in ? x1 : 16, cy1 = in ? y1 : 16, cx2 = in ? x2 : 16, cy2 = in ? y2 : 16, cr = in ? r : 0;
+    uint16_t *pos = &c[(size_t)p * 8], *neg = pos + 4;
+    pos[0] = word(cy1 + cr + 1, cx1 + cr + 1);   // (b,r) of box 1
+    pos[1] = word(cy1 - cr, cx1 - cr);           // (a,l) of box 1
+    pos[2] = word(cy2 - cr, cx2 + cr + 1);       // (a,r) of box 2
+    pos[3] = word(cy2 + cr + 1, cx2 - cr);       // (b,l) of box 2
+    neg[0] = word(cy1 - cr, cx1 + cr + 1);       // (a,r) of box 1
+    neg[1] = word(cy1 + cr + 1, cx1 - cr);       // (b,l) of box 1
+    neg[2] = word(cy2 + cr + 1, cx2 + cr + 1);   // (b,r) of box 2
+    neg[3] = word(cy2 - cr, cx2 - cr);           // (a,l) of box 2
   }
-  return total;
+  *all_inside = ok;
+  return c;
 }
 
-int group_passes(const uint16_t (&addr)[64][4]) {
-  return bank_passes(addr, 0) + bank_passes(addr, 1) + bank_passes(addr, 2) + bank_passes(addr, 3);
-}
-
-void order_reads(uint16_t (&addr)[64][4]) {
-  static const int perm[24][4] = {{0, 1, 2, 3}, {0, 1, 3, 2}, {0, 2, 1, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {0, 3, 2, 1},
-                                  {1, 0, 2, 3}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 2, 3, 0}, {1, 3, 0, 2}, {1, 3, 2, 0},
-                                  {2, 0, 1, 3}, {2, 0, 3, 1}, {2, 1, 0, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {2, 3, 1, 0},
-                                  {3, 0, 1, 2}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 1, 2, 0}, {3, 2, 0, 1}, {3, 2, 1, 0}};
-  uint16_t best[64][4];
-  int best_cost = 1 << 30;
-  uint32_t rng = 12345u;                                  // fixed seed: the plan is a deterministic function of the table
-  for (int start = 0; start < 4; ++start) {               // the table's own order, then three shuffled starts
-    uint16_t cur[64][4];
-    for (int l = 0; l < 64; ++l) {
-      const int p = start == 0 ? 0 : (int)(((rng = rng * 1664525u + 1013904223u) >> 8) % 24u);
-      for (int q = 0; q < 4; ++q) cur[l][q] = addr[l][perm[p][q]];
-    }
-    for (int sweep = 0; sweep < 4; ++sweep) {
-      bool changed = false;
-      for (int l = 0; l < 64; ++l) {
-        const uint16_t base[4] = {cur[l][0], cur[l][1], cur[l][2], cur[l][3]};
-        int pick = 0, pick_cost = 1 << 30;
-        for (int p = 0; p < 24; ++p) {
-          for (int q = 0; q < 4; ++q) cur[l][q] = base[perm[p][q]];
-          const int cost = group_passes(cur);
-          if (cost < pick_cost) { pick_cost = cost; pick = p; }
-        }
-        for (int q = 0; q < 4; ++q) cur[l][q] = base[perm[pick][q]];
-        changed = changed || pick != 0;
-      }
-      if (!changed) break;
-    }
-    const int cost = group_passes(cur);
-    if (cost < best_cost) {
-      best_cost = cost;
-      for (int l = 0; l < 64; ++l)
-        for (int q = 0; q < 4; ++q) best[l][q] = cur[l][q];
-    }
+// schedules by table content: a process builds plans for a handful of tables (one per descriptor size), many times
+std::shared_ptr<const HostPlan> host_plan_for(const std::vector<uint32_t> &geom) {
+  static std::mutex mu;
+  static std::vector<std::shared_ptr<const HostPlan>> *cache = new std::vector<std::shared_ptr<const HostPlan>>();
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &hp : *cache)
+      if (hp->geom == geom) return hp;
   }
-  for (int l = 0; l < 64; ++l)
-    for (int q = 0; q < 4; ++q) addr[l][q] = best[l][q];
+  auto hp = std::make_shared<HostPlan>();
+  hp->geom = geom;
+  const std::vector<uint16_t> corners = table_corners(geom, &hp->geometry_ok);
+  hp->sched = mi::schedule_bad_gathers(corners, (int)geom.size());
+  std::lock_guard<std::mutex> lock(mu);
+  if (cache->size() >= 16) cache->erase(cache->begin());
+  cache->push_back(hp);
+  return hp;
 }
 
 }  // namespace
 
 extern "C" size_t mi_bad_plan_bytes(int num_pairs) {
   if (num_pairs <= 0) return 0;
-  return sizeof(BadPlan) + (size_t)num_pairs * (sizeof(uint4) + sizeof(int));
+  return sizeof(BadPlan) + (size_t)num_pairs * (sizeof(uint4) + sizeof(int) + sizeof(uint32_t)) +
+         (size_t)(num_pairs / 64) * (num_pairs / 64) * sizeof(uint64_t);
+}
+
+// development aid (include/mi355x_match_debug.h): the LDS passes per keypoint of the gather schedule for a HOST copy
+// of a pair table, as the table stands and as scheduled -- no GPU involved
+extern "C" int mi_debug_bad_plan_passes(const uint32_t *pair_geom_host, int num_pairs, int *canonical, int *scheduled) {
+  if (!pair_geom_host || !canonical || !scheduled) return MI_E_NULL;
+  if (num_pairs <= 0 || num_pairs % 64 != 0 || num_pairs > 1024) return MI_E_PARAM;
+  const auto hp = host_plan_for(std::vector<uint32_t>(pair_geom_host, pair_geom_host + num_pairs));
+  for (int e = 0; e < num_pairs; ++e)
+    if (hp->sched.exec_pair[e] % 64 != e % 64) return MI_E_PARAM;          // a lane only reorders its own pairs
+  *canonical = hp->sched.passes_canonical;
+  *scheduled = hp->sched.passes;
+  return MI_OK;
 }
 
 extern "C" int mi_bad_plan_build(const uint32_t *pair_geom, const float *pair_thr, int num_pairs, void *plan,
                                  mi_stream_t stream) {
   MI_ENTER();
-  // Set-up call, once per pair table: it copies the table to the host, builds the plan there (see order_reads)
+  // Set-up call, once per pair table: it copies the table to the host, builds the plan there (see above)
   // and uploads it, synchronising `stream` twice.  Not capturable into a hipGraph; everything else is.
   if (!pair_geom || !pair_thr || !plan) return MI_E_NULL;
   if (num_pairs <= 0 || num_pairs % 64 != 0 || num_pairs > 1024) return MI_E_PARAM;
@@ -479,48 +497,29 @@ extern "C" int mi_bad_plan_build(const uint32_t *pair_geom, const float *pair_th
       hipMemcpyAsync(thr.data(), pair_thr, sizeof(float) * num_pairs, hipMemcpyDeviceToHost, s) != hipSuccess ||
       hipStreamSynchronize(s) != hipSuccess)
     return mi_launch_status() ? mi_launch_status() : MI_E_PARAM;
+  const auto sched = host_plan_for(geom);
   std::vector<char> host(mi_bad_plan_bytes(num_pairs));
   BadPlan *hp = reinterpret_cast<BadPlan *>(host.data());
   uint4 *offs = reinterpret_cast<uint4 *>(hp + 1);
   int *tint = reinterpret_cast<int *>(offs + num_pairs);
-  bool ok = true;
-  auto off = [](int row, int col) { return (uint16_t)((row * FW + col) * 4); };
-  for (int g = 0; g < num_pairs / 64; ++g) {
-    uint16_t pos[64][4], neg[64][4];
-    for (int l = 0; l < 64; ++l) {
-      const int p = g * 64 + l;
-      const uint32_t q = geom[p];
-      const int x1 = (int)(q & 31u), x2 = (int)((q >> 5) & 31u);
-      const int y1 = (int)((q >> 10) & 31u), y2 = (int)((q >> 15) & 31u);
-      const int r = (int)((q >> 20) & 15u);
-      const bool in = x1 - r >= 0 && x2 - r >= 0 && y1 - r >= 0 && y2 - r >= 0 && x1 + r <= 31 && x2 + r <= 31 &&
-                      y1 + r <= 31 && y2 + r <= 31;
-      ok = ok && in;
-      const int cx1 = in ? x1 : 16, cy1 = in ? y1 : 16, cx2 = in ? x2 : 16, cy2 = in ? y2 : 16, cr = in ? r : 0;
-      pos[l][0] = off(cy1 + cr + 1, cx1 + cr + 1);   // (b,r) of box 1
-      pos[l][1] = off(cy1 - cr, cx1 - cr);           // (a,l) of box 1
-      pos[l][2] = off(cy2 - cr, cx2 + cr + 1);       // (a,r) of box 2
-      pos[l][3] = off(cy2 + cr + 1, cx2 - cr);       // (b,l) of box 2
-      neg[l][0] = off(cy1 - cr, cx1 + cr + 1);       // (a,r) of box 1
-      neg[l][1] = off(cy1 + cr + 1, cx1 - cr);       // (b,l) of box 1
-      neg[l][2] = off(cy2 + cr + 1, cx2 + cr + 1);   // (b,r) of box 2
-      neg[l][3] = off(cy2 - cr, cx2 - cr);           // (a,l) of box 2
-      tint[p] = (int)floor((double)thr[p] * (double)((2 * r + 1) * (2 * r + 1)));
-    }
-    order_reads(pos);
-    order_reads(neg);
-    for (int l = 0; l < 64; ++l) {
-      uint4 o;
-      o.x = (uint32_t)pos[l][0] | ((uint32_t)pos[l][1] << 16);
-      o.y = (uint32_t)pos[l][2] | ((uint32_t)pos[l][3] << 16);
-      o.z = (uint32_t)neg[l][0] | ((uint32_t)neg[l][1] << 16);
-      o.w = (uint32_t)neg[l][2] | ((uint32_t)neg[l][3] << 16);
-      offs[g * 64 + l] = o;
-    }
+  uint32_t *xgeom = reinterpret_cast<uint32_t *>(tint + num_pairs);
+  uint64_t *masks = reinterpret_cast<uint64_t *>(xgeom + num_pairs);
+  const int rounds = num_pairs / 64;
+  for (int i = 0; i < rounds * rounds; ++i) masks[i] = 0;
+  for (int e = 0; e < num_pairs; ++e) {
+    const int p = sched->sched.exec_pair[e], lane = e % 64, round = e / 64;
+    const uint16_t *pos = &sched->sched.pos[(size_t)e * 4], *neg = &sched->sched.neg[(size_t)e * 4];
+    auto two = [](uint16_t lo, uint16_t hi) { return (uint32_t)(lo * 4u) | ((uint32_t)(hi * 4u) << 16); };   // byte offsets
+    offs[e] = make_uint4(two(pos[0], pos[1]), two(pos[2], pos[3]), two(neg[0], neg[1]), two(neg[2], neg[3]));
+    const int r = (int)((geom[p] >> 20) & 15u);
+    tint[e] = (int)floor((double)thr[p] * (double)((2 * r + 1) * (2 * r + 1)));
+    xgeom[e] = geom[p];
+    masks[round * rounds + p / 64] |= (uint64_t)1 << lane;
   }
-  hp->geometry_ok = ok ? 1 : 0;
+  hp->geometry_ok = sched->geometry_ok ? 1 : 0;
   hp->num_pairs = num_pairs;
-  hp->pad[0] = hp->pad[1] = 0;
+  hp->passes = sched->sched.passes;
+  hp->passes_canonical = sched->sched.passes_canonical;
   if (hipMemcpyAsync(plan, host.data(), host.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
       hipStreamSynchronize(s) != hipSuccess)
     return mi_launch_status() ? mi_launch_status() : MI_E_PARAM;

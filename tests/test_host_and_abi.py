@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(lib_path):
 def test_binding_covers_the_header(lib_path):
     from onnx_image_processing_amd import _native
     assert sorted(_native.SIGNATURES) == header_functions()
-    assert sorted(_native.DEBUG_SIGNATURES) == header_functions(DEBUG_HEADER) == ["mi_debug_clock_probe", "mi_debug_set", "mi_debug_topk_stamps"]
+    assert sorted(_native.DEBUG_SIGNATURES) == header_functions(DEBUG_HEADER) == ["mi_debug_bad_plan_passes", "mi_debug_clock_probe", "mi_debug_set", "mi_debug_topk_stamps"]
     _native.load()
 
 
@@ -320,3 +320,25 @@ def test_argument_validation_of_the_round2_entries(lib_path):
     small, big = lib.mi_sinkhorn_dots_workspace_bytes(8, 512, 512), lib.mi_sinkhorn_dots_workspace_bytes(9, 512, 512)
     assert small > big * 8 // 9          # up to 8 pairs the workspace also holds the single-launch form's hand-off area
     lib.mi_release_stream_resources.argtypes = [vp]
+
+
+def test_bad_gather_schedule_is_lane_local_and_cuts_bank_conflicts(lib_path):
+    """csrc/bad_plan_opt.h through mi_debug_bad_plan_passes (host only): on the reference's pair tables the scheduled
+    gathers need far fewer LDS passes than the table as it stands, every lane keeps its own pairs (the entry point
+    checks exec_pair % 64 == lane, which is what lets the kernel rebuild the canonical bit order), and the schedule
+    is a deterministic function of the table."""
+    from onnx_image_processing_amd import _native as N
+    from onnx_image_processing_amd.pytorch_model.descriptor.bad import SparseBAD
+    lib = N.load()
+    for pairs, bound in ((512, 200), (256, 110)):
+        geom = np.ascontiguousarray(SparseBAD(num_pairs=pairs).pair_geom.numpy().astype(np.uint32))
+        got = []
+        for _ in range(2):
+            canonical, scheduled = ctypes.c_int(0), ctypes.c_int(0)
+            assert lib.mi_debug_bad_plan_passes(geom.ctypes.data, pairs, ctypes.byref(canonical), ctypes.byref(scheduled)) == 0
+            got.append((canonical.value, scheduled.value))
+        assert got[0] == got[1]
+        assert pairs // 4 <= got[0][1] <= bound < got[0][0], (pairs, got[0])
+    a, b = ctypes.c_int(0), ctypes.c_int(0)
+    assert lib.mi_debug_bad_plan_passes(None, 512, ctypes.byref(a), ctypes.byref(b)) == -1
+    assert lib.mi_debug_bad_plan_passes(geom.ctypes.data, 100, ctypes.byref(a), ctypes.byref(b)) == -3
