@@ -573,6 +573,9 @@ __global__ __launch_bounds__(256) void corner_stream_kernel(MiSets images,
       const int gy = clampi(y0 + prow[q], 0, h - 1);
       const int gx = clampi(x0 + pcol[q], 0, w - 4);
       auto *dst = (__attribute__((address_space(3))) void *)&lds[buf * BUF + q * 256 + wave_base];
+      // the last scratch slot of a buffer carries the ticket (below): its lane sits the last piece out, or a wave that
+      // has read the ticket and issued this DMA could overwrite it before a slower wave has read it
+      if (q == NCH - 1 && t == 255) continue;
       if constexpr (U8) __builtin_amdgcn_global_load_lds(imb + (gy * w + gx), dst, 4, 0, 0);
       else __builtin_amdgcn_global_load_lds(imf + (gy * w + gx), dst, 16, 0, 0);
     }
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(256) void corner_stream_kernel(MiSets images,
   decode(v, img, x0, y0);
   issue(img, x0, y0, 0);
   bool prev_full = false;                         // previous tile issued exactly R stores per lane
-  for (int it = 0; v < total_tiles; ++it) {
+  for (int it = 0; (unsigned)v < (unsigned)total_tiles; ++it) {
     const int cur = it & 1;
     // This tile's DMA pieces were issued BEFORE the previous tile's R stores, and vmcnt retires
     // in issue order: leaving R operations outstanding waits for the DMA but not for the stores.
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(256) void corner_stream_kernel(MiSets images,
     int nxt = v + G;                               // static schedule; also the dynamic one's second tile
     if (tile_ctr && it > 0) nxt = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(&lds[(cur ^ 1) * BUF + BUF - 1]));
     int nimg = 0, nx0 = 0, ny0 = 0;
-    const bool more = nxt < total_tiles;           // workgroup-uniform
+    const bool more = (unsigned)nxt < (unsigned)total_tiles;   // workgroup-uniform (unsigned: a corrupt counter block cannot send a tile index below zero)
     unsigned ticket = 0u;
     if (more) {
       if (tile_ctr && t == 0) {
