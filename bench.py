@@ -524,10 +524,15 @@ def main() -> None:
             line["roofline_other"] = other
         if world == 1 and not args.single_call:
             records = out[:args.cpu_pairs].cpu().numpy() if 0 < args.cpu_pairs <= B else None
+            def stage(name):                                     # progress on stderr: locates a stage that hangs or faults
+                print(f"[bench] {name}", file=sys.stderr, flush=True)
             if not args.no_extras:
+                stage("u8 ingest + streamed input")
                 line["u8_ingest"], line["streamed"] = measure_u8_and_streamed(model, a8, b8, min(args.steps, 100))
+                stage("one-pair-per-call latency")
                 line["latency"] = measure_latency(model, img1, img2, a8, b8)
             if args.cpu_pairs > 0:
+                stage("cpu_baseline")
                 line["cpu_baseline"] = cpu_baseline(min(args.cpu_pairs, B), records)
         print(json.dumps(line), flush=True)
     if world > 1:
