@@ -1188,7 +1188,7 @@ def test_corner_ticket_schedule_equals_static(mods):
     for x, u8, static in ((img8.float(), 0, "mi_corner_response"), (img8, 1, "mi_corner_response_u8")):
         want = torch.empty((n, 1, h, w), dtype=torch.float32, device=DEV)
         N.call(static, x.data_ptr(), n, h, w, 3, want.data_ptr(), N.stream_ptr())
-        for _ in range(2):
+        for _ in range(6):                                       # repeated: the hand-off of a ticket between waves is timing dependent
             got = torch.full((n, 1, h, w), -1.0, dtype=torch.float32, device=DEV)
             N.call("mi_corner_response_balanced", x.data_ptr(), u8, n, h, w, 3, got.data_ptr(), ctr.data_ptr(), N.stream_ptr())
             assert torch.equal(got, want)

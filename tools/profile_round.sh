@@ -4,7 +4,8 @@
 #   (FETCH_SIZE, WRITE_SIZE -- separate runs, --kernel-trace only) and the MFMA passes for the cost kernel
 #   (busy cycles and I8 MOPS, separate runs), then the same statistics for the one-pair-per-call path and for
 #   BASELINE configs[2] / [3].  The program itself follows `--` (never a shell or env wrapper).
-# Outputs land in gpurun_out/round/; tools/profile_summarise.py turns them into profiles/<tag>_*.
+# Outputs land in gpurun_out/round/; tools/profile_summarise.py turns them into gpurun_out/round/summary/<tag>_*
+# (copy those into profiles/).
 set -e -o pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$ROOT/gpurun_out/round"
@@ -19,10 +20,16 @@ for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INS
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_$c" -o pmc -- python3 "$B" --steps 3 --warmup 1 --cpu-pairs 0 --no-extras > "$OUT/pmc_$c.log" 2>&1
   echo pmc $c done
 done
+# issue picture of every kernel: SQ counters in ONE pass (8 SQ slots)
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU -d "$OUT/pmc_SQ" -o pmc -- python3 "$B" --steps 3 --warmup 1 --cpu-pairs 0 --no-extras > "$OUT/pmc_SQ.log" 2>&1
+echo pmc SQ done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/latency" -o latency -- python3 "$ROOT/tools/latency_trace.py" --single-call --graph --iters 50 > "$OUT/latency.log" 2>&1
 echo latency done
 timeout -k 10 300 python3 "$B" --workload c3 --pairs-per-gpu 64 > "$OUT/c3.json" 2> "$OUT/c3.err"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/c3stats" -o c3 -- python3 "$B" --workload c3 --pairs-per-gpu 64 --steps 5 --warmup 2 > "$OUT/c3stats.log" 2>&1
 timeout -k 10 300 python3 "$B" --workload c4 --pairs-per-gpu 128 > "$OUT/c4.json" 2> "$OUT/c4.err"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/c4stats" -o c4 -- python3 "$B" --workload c4 --pairs-per-gpu 128 --steps 5 --warmup 2 > "$OUT/c4stats.log" 2>&1
+# summarise here and drop the databases: gpurun copies at most 64 MiB back
+python3 "$ROOT/tools/profile_summarise.py" "${PROFILE_TAG:-r02}" "$OUT/summary"
+find "$OUT" -name '*.db' -delete
 echo profile_round done

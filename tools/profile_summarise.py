@@ -2,6 +2,8 @@
 """Turn gpurun_out/round/ (tools/profile_round.sh) into the committed summaries under profiles/.
 
     python tools/profile_summarise.py r01        # writes profiles/r01_bench.json, _kernel_stats.csv, _pmc_traffic.json
+    python tools/profile_summarise.py r01 DIR    # ... into DIR (profile_round.sh summarises on the GPU box, because the
+                                                 # rocprofv3 databases are too large to travel back)
 """
 import collections
 import json
@@ -12,7 +14,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "round")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-dst = os.path.join(ROOT, "profiles")
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
@@ -116,3 +119,33 @@ try:
 except Exception as e:      # noqa: BLE001
     print("mfma summary skipped:", e)
 print("wrote", tag)
+
+
+# SQ issue counters of every kernel of the batched step (one pass): fractions of the kernel's wave cycles
+try:
+    d = sqlite3.connect(os.path.join(SRC, "pmc_SQ", "pmc_results.db"))
+    cur = d.cursor()
+    cols = [c[0] for c in cur.execute("select * from counters_collection limit 1").description]
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in cur.execute("select * from counters_collection"):
+        row = dict(zip(cols, r))
+        k = short(row["kernel_name"])
+        if k.startswith("at::") or k.startswith("__amd") or "elementwise" in k or "Cat" in k or "reduce_kernel" in k:
+            continue
+        acc[k][row["counter_name"]].append(row["value"])
+    sq = {"note": "rocprofv3 --pmc, eight SQ counters in one pass over `bench.py --steps 3 --warmup 1 --no-extras`; per-launch "
+                  "sums over the chip (SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles per wave) and their "
+                  "fraction of the kernel's wave cycles: WAIT_ANY = parked on s_waitcnt / barrier, WAIT_INST_ANY = ready but "
+                  "not issued, ACTIVE_INST_ANY = issuing; LDS_BANK_CONFLICT / LDS_IDX_ACTIVE = conflict share of the LDS array's "
+                  "busy cycles", "pairs_per_gpu": PAIRS, "kernels": {}}
+    for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("SQ_WAVE_CYCLES", [0]))):
+        wc = sum(v["SQ_WAVE_CYCLES"]) / len(v["SQ_WAVE_CYCLES"])
+        ent = {"launches": len(v["SQ_WAVE_CYCLES"])}
+        for c, vals in sorted(v.items()):
+            m = sum(vals) / len(vals)
+            ent[c] = round(m)
+            ent[c + "_per_wave_cycle"] = round(m / wc, 4) if wc else None
+        sq["kernels"][k] = ent
+    json.dump(sq, open(os.path.join(dst, f"{tag}_bench_pmc_sq.json"), "w"), indent=1)
+except Exception as e:                                           # the pass is optional
+    print("no SQ pass:", e)
