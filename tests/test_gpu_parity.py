@@ -1270,10 +1270,13 @@ def test_odd_image_sizes_vs_oracle(mods, h, w):
 
 # ------------------------------------------------------------------ the whole path in one C-ABI call
 @pytest.mark.parametrize("shape,k,normalize", [((3, 480, 640), 512, True), ((2, 120, 160), 96, True),
-                                               ((1, 97, 132), 64, False), ((2, 240, 320), 256, True)])
+                                               ((1, 97, 132), 64, False), ((2, 240, 320), 256, True),
+                                               ((40, 120, 160), 96, True), ((36, 480, 640), 512, True)])
 def test_match_pairs_single_call_equals_module_path(mods, shape, k, normalize):
     """mi_match_pairs (one call, caller-provided workspace) against MatchExtractionWrapper.forward, which issues
-    the same entry points one by one: keypoints, matches, scores and validity identical bit for bit."""
+    the same entry points one by one: keypoints, matches, scores and validity identical bit for bit.  Up to 32 pairs
+    both images of every pair share one launch per stage; the last two cases take the other branch (one image side
+    per launch, the 36 x 640x480 one with K1's ticket counters carved out of the workspace)."""
     n, h, w = shape
     a, b = synth_batch(4000 + h, n, h, w)
     model = mods["MatchExtractionWrapper"](
