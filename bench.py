@@ -412,6 +412,9 @@ def main() -> None:
                          "line carries no roofline object")
     ap.add_argument("--two-step", action="store_true",
                     help="materialise P and run the extractor on it (default: matches straight from the duals)")
+    ap.add_argument("--frames", choices=["f32", "u8"], default="f32",
+                    help="pixel type of the frames resident in HBM for the main line (f32 = the reference's input form; "
+                         "u8 is the line `u8_ingest` reports, selectable here so that profilers can be pointed at it)")
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
                     help="c2 (default, the metric's configuration); c3 = 1080x1920 K=1024; c4 = AKAZE front end")
     args = ap.parse_args()
@@ -444,6 +447,9 @@ def main() -> None:
     a8, b8 = synth_batch_u8(1000 + begin, B, H, W)
     # float32 [0,255] (B,1,H,W): the reference's input form, resident in HBM before timing
     img1, img2 = torch.from_numpy(a8).to(dev).float(), torch.from_numpy(b8).to(dev).float()
+    u8_main = args.frames == "u8"
+    if u8_main:
+        img1, img2 = torch.from_numpy(a8).to(dev), torch.from_numpy(b8).to(dev)
     # the reference's deployment form of "matcher + match extraction" (match_extraction_wrapper.py:82-113)
     model = MatchExtractionWrapper(ShiTomasiSparseBADSinkhornMatcher(max_keypoints=K, **CFG),
                                    max_matches=MNN["max_matches"], match_threshold=MNN["threshold"]).to(dev)
@@ -484,14 +490,14 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32",                                      # the arithmetic type of the path (uint8 frames too)
             "data": "synthetic",
             "config": {"workload": "Shi-Tomasi(3) + NMS(r=5)/top-k + sparse BAD(512, hard) + Sinkhorn(20, eps 0.05) "
                                    "+ MNN(100, 0.1), 640x480 gray pairs, K=512 (BASELINE configs[1])"
                                    + (", issued as one mi_match_pairs call per step" if args.single_call else ""),
                        "pairs_per_gpu_per_step": B, "global_pairs_per_step": pairs_per_step,
                        "height": H, "width": W, "max_keypoints": K, "parallelism": f"pair-sharded x{world}",
-                       "input": "float32 frames resident in HBM",
+                       "input": ("uint8" if u8_main else "float32") + " frames resident in HBM",
                        "mean_valid_matches_per_pair": float(out[..., 5].sum().item()) / pairs_per_step},
             "step_ms": step_stats(per_step),
             "kernels": kernels,
@@ -500,8 +506,12 @@ def main() -> None:
             # K1 corner response: 8 algorithmic bytes per pixel (4 read + 4 written); one launch covers one image of
             # every pair of this rank, two launches per step
             k1 = per_call["mi_corner_response_balanced"][2 * args.warmup:]
-            line["roofline"] = k1_roofline(float(np.mean(k1)), 8.0, B, "corner_stream_kernel<3,4,float> (mi_corner_response_balanced)",
-                                           "corner_stream_kernel<3,4,false>", B)
+            if u8_main:
+                line["roofline"] = k1_roofline(float(np.mean(k1)), 5.0, B, "corner_stream_kernel<3,5,uint8> (mi_corner_response_balanced)",
+                                               "corner_stream_kernel<3,5,true>", B)
+            else:
+                line["roofline"] = k1_roofline(float(np.mean(k1)), 8.0, B, "corner_stream_kernel<3,4,float> (mi_corner_response_balanced)",
+                                               "corner_stream_kernel<3,4,false>", B)
             # informational: the other stages by their algorithmic bytes / operations
             other = {}
             if "mi_nms_candidates" in stages:
@@ -522,7 +532,7 @@ def main() -> None:
                     "bytes_written_per_call": 2.0 * B * K * K,
                     "note": "co-limited by its uint16 store stream; MFMA busy counters in profiles/ (DESIGN.md K5)"}
             line["roofline_other"] = other
-        if world == 1 and not args.single_call:
+        if world == 1 and not args.single_call and not u8_main:
             records = out[:args.cpu_pairs].cpu().numpy() if 0 < args.cpu_pairs <= B else None
             def stage(name):                                     # progress on stderr: locates a stage that hangs or faults
                 print(f"[bench] {name}", file=sys.stderr, flush=True)

@@ -20,6 +20,11 @@ for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INS
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_$c" -o pmc -- python3 "$B" --steps 3 --warmup 1 --cpu-pairs 0 --no-extras > "$OUT/pmc_$c.log" 2>&1
   echo pmc $c done
 done
+# the same two traffic passes on uint8 frames (u8 ingest: K1 at 5 B/px, K4 on 1 KB windows)
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_u8_$c" -o pmc -- python3 "$B" --frames u8 --steps 3 --warmup 1 --cpu-pairs 0 --no-extras > "$OUT/pmc_u8_$c.log" 2>&1
+  echo pmc u8 $c done
+done
 # issue picture of every kernel: SQ counters in ONE pass (8 SQ slots)
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU -d "$OUT/pmc_SQ" -o pmc -- python3 "$B" --steps 3 --warmup 1 --cpu-pairs 0 --no-extras > "$OUT/pmc_SQ.log" 2>&1
 echo pmc SQ done
