@@ -302,6 +302,11 @@ def test_argument_validation_of_the_round2_entries(lib_path):
     assert lib.mi_corner_response_u8(None, 1, 8, 8, 3, p, None) == -1
     assert lib.mi_corner_response_u8(p, 1, 0, 8, 3, p, None) == -2
     assert lib.mi_corner_response_u8(p, 1, 8, 8, 2, p, None) == -3
+    lib.mi_corner_response_balanced.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp]
+    assert lib.mi_corner_response_balanced(None, 0, 1, 8, 8, 3, p, p, None) == -1
+    assert lib.mi_corner_response_balanced(p, 1, 1, 8, 0, 3, p, p, None) == -2
+    assert lib.mi_corner_response_balanced(p, 0, 1, 8, 8, 4, p, None, None) == -3
+    assert lib.mi_corner_response_balanced(p, 0, 1, 8, 8, 3, p, ctypes.c_void_p(p.value + 2), None) == -5    # counter block alignment
     lib.mi_convert_u8_f32.argtypes = [vp, ctypes.c_longlong, vp, vp]
     assert lib.mi_convert_u8_f32(p, 0, p, None) == -2 and lib.mi_convert_u8_f32(None, 4, p, None) == -1
     lib.mi_sparse_bad_u8.argtypes = [vp, ci, ci, ci, vp, ci, vp, vp, ci, ci, cf, ci, vp, vp, vp, vp, vp]
