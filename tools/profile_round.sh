@@ -30,8 +30,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_W
 echo pmc SQ done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/latency" -o latency -- python3 "$ROOT/tools/latency_trace.py" --single-call --graph --iters 50 > "$OUT/latency.log" 2>&1
 echo latency done
-timeout -k 10 300 python3 "$B" --workload c3 --pairs-per-gpu 64 > "$OUT/c3.json" 2> "$OUT/c3.err"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/c3stats" -o c3 -- python3 "$B" --workload c3 --pairs-per-gpu 64 --steps 5 --warmup 2 > "$OUT/c3stats.log" 2>&1
+timeout -k 10 300 python3 "$B" --workload c3 --pairs-per-gpu 128 > "$OUT/c3.json" 2> "$OUT/c3.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/c3stats" -o c3 -- python3 "$B" --workload c3 --pairs-per-gpu 128 --steps 5 --warmup 2 > "$OUT/c3stats.log" 2>&1
 timeout -k 10 300 python3 "$B" --workload c4 --pairs-per-gpu 128 > "$OUT/c4.json" 2> "$OUT/c4.err"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/c4stats" -o c4 -- python3 "$B" --workload c4 --pairs-per-gpu 128 --steps 5 --warmup 2 > "$OUT/c4stats.log" 2>&1
 # summarise here and drop the databases: gpurun copies at most 64 MiB back

@@ -54,7 +54,7 @@ stats_csv("stats", "stats", f"{tag}_bench_kernel_stats.csv",
 stats_csv("latency", "latency", f"{tag}_latency_kernel_stats.csv",
           "# rocprofv3 --kernel-trace --stats -- python3 tools/latency_trace.py --single-call --graph --iters 50   "
           "(ONE 640x480 K=512 pair per call through mi_match_pairs, replayed as a hipGraph; every call synchronised)")
-for wl, pairs in (("c3", 64), ("c4", 128)):
+for wl, pairs in (("c3", 128), ("c4", 128)):
     stats_csv(wl + "stats", wl, f"{tag}_{wl}_kernel_stats.csv",
               f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --pairs-per-gpu {pairs} --steps 5 --warmup 2")
     src = os.path.join(SRC, wl + ".json")
