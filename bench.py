@@ -4,6 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs-per-gpu B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work for N > 1: under torchrun the ranks exist already; a bare `python bench.py --gpus N` starts N fresh rank
+processes itself (launch_ranks) before touching the GPU.  The N > 1 line records the world size the backend actually
+formed (`ranks_seen`, `backend`) and every rank's own ms per step.
+
 One "step" = one pass of the whole path (Shi-Tomasi -> NMS/top-k -> sparse BAD -> cost -> Sinkhorn -> mutual-NN match
 extraction; the reference's MatchExtractionWrapper form) over a batch of B synthetic pairs per GPU that is already
 resident in HBM as float32 (the reference's input type), followed (N > 1) by the RCCL gather of the match records to
@@ -66,9 +70,10 @@ class StepClock:
         return [(b - a) * 1e3 for a, b in zip(self.stamps, self.stamps[1:])]
 
 
-def run_timed(step, steps: int, warmup: int, world: int, device, sync) -> tuple[float, list[float], object]:
+def run_timed(step, steps: int, warmup: int, world: int, device, sync) -> tuple[float, list[float], object, float]:
     """The contract's timed region: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by a barrier + device
-    synchronisation on both sides; returns (elapsed ms, MAX over ranks; per-step ms of this rank; last step's output).
+    synchronisation on both sides; returns (elapsed ms, MAX over ranks; per-step ms of this rank; last step's output;
+    this rank's own elapsed ms up to its last synchronise, before the closing barrier).
     `step()` returns what rank 0 needs (the gathered records); `sync()` is torch.cuda.synchronize on a GPU."""
     from onnx_image_processing_amd import distributed as D
     out = None
@@ -85,10 +90,11 @@ def run_timed(step, steps: int, warmup: int, world: int, device, sync) -> tuple[
         out = step()
         clock.mark(i + 1)
     sync()
+    own_ms = (time.perf_counter() - t0) * 1e3
     if world > 1:
         dist.barrier()
     elapsed_ms = (time.perf_counter() - t0) * 1e3
-    return D.barrier_max_ms(elapsed_ms, device), clock.per_step_ms(), out
+    return D.barrier_max_ms(elapsed_ms, device), clock.per_step_ms(), out, own_ms
 
 
 def step_stats(per_step_ms: list[float]) -> dict:
@@ -365,7 +371,8 @@ def side_workload(args, rank, world, dev) -> None:
         return D.gather_records(D.pack_records(*model(img1, img2)), dst=0)
 
     _native.enable_timing(True, only={roof[0]})
-    elapsed_ms, per_step, out = run_timed(step, args.steps, args.warmup, world, dev, torch.cuda.synchronize)
+    elapsed_ms, per_step, out, own_ms = run_timed(step, args.steps, args.warmup, world, dev, torch.cuda.synchronize)
+    facts = world_facts(own_ms, args.steps, dev)
     timed = _native.timings_ms().get(roof[0], [])
     timed = timed[-len(timed) * args.steps // (args.steps + args.warmup):] if timed else timed     # drop the warm-up calls
     _native.enable_timing(True)
@@ -381,7 +388,7 @@ def side_workload(args, rank, world, dev) -> None:
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": what, "pairs_per_gpu_per_step": B,
                        "mean_valid_matches_per_pair": float(out[..., 5].sum().item()) / (B * world)},
-            "step_ms": step_stats(per_step),
+            "step_ms": step_stats(per_step), **facts,
             "kernels": {kk: {"ms_per_step": float(np.sum(v)) / 3, "calls_per_step": len(v) / 3} for kk, v in per_call.items()}}
         if timed:
             nbytes = roof[2] * B * h * w * roof[3]
@@ -391,6 +398,103 @@ def side_workload(args, rank, world, dev) -> None:
                                 "traffic": None, "bytes_per_launch": nbytes, "bytes_per_pixel": roof[2],
                                 "ms_per_launch": t_ms}
         print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------- N > 1 launcher
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """`python bench.py --gpus N` outside torchrun: THIS process -- which has made no GPU call (importing torch does
+    not initialise HIP) and never will -- starts N fresh rank processes of this script, one per GPU, with the torchrun
+    environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), relays rank 0's JSON line on stdout
+    and returns non-zero if any rank fails.  Child processes, never an exec: a process that has touched the GPU must
+    not be replaced (the pool's rule), and children started before any GPU call inherit no HIP state.  stderr of the
+    ranks passes through.  When one rank dies the others are terminated (they would wait in a collective forever)."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", "0")) or _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0:
+                print(f"[bench] rank {r} exited with code {code}", file=sys.stderr, flush=True)
+                rc = rc or code or 1
+                for q in pending:                                    # the exact children started above, by handle
+                    procs[q].terminate()
+        if pending:
+            time.sleep(0.05)
+    out = procs[0].stdout.read() if procs[0].stdout else ""
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if rc == 0 and len(lines) != 1:
+        print(f"[bench] expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr, flush=True)
+        rc = 1
+    for ln in lines:
+        print(ln, flush=True)
+    return rc
+
+
+def world_facts(elapsed_ms_this_rank: float, steps: int, device) -> dict:
+    """What the process group actually formed (not what --gpus asked for) and every rank's own ms per step."""
+    if not dist.is_initialized():
+        return {"ranks_seen": 1, "backend": None, "ms_per_step_per_rank": [elapsed_ms_this_rank / steps]}
+    t = torch.tensor([elapsed_ms_this_rank / steps], dtype=torch.float64, device=device)
+    every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, t)
+    return {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+            "ms_per_step_per_rank": [float(x.item()) for x in every]}
+
+
+def dry_run(args, rank: int, world: int) -> None:
+    """--dry-run: the launcher, rendezvous, sharding, timed region, gather and output line with the per-pair compute
+    STUBBED (deterministic records, no GPU, backend gloo).  It exists so that the N > 1 start-up path is tested on CPU
+    (tests/test_distributed_gloo.py); its line says so and is not a measurement."""
+    from onnx_image_processing_amd import distributed as D
+    B = args.pairs_per_gpu
+    begin, end = D.shard_range(B * world, rank, world)
+    g = torch.Generator().manual_seed(1000 + begin)
+    rec = torch.rand((end - begin, MNN["max_matches"], D.RECORD_FIELDS), generator=g)
+    rec[..., 5] = 1.0
+    rec[:, :, 0] = torch.arange(begin, end, dtype=torch.float32)[:, None]      # the global pair index, for the order check
+
+    if os.environ.get("MI_BENCH_DRY_RUN_FAIL_RANK") == str(rank):              # test hook of the dry run only: a rank that dies
+        raise SystemExit(3)
+
+    def step():
+        time.sleep(0.001 * (rank + 1))
+        return D.gather_records(rec, dst=0, total=B * world)
+
+    elapsed_ms, per_step, out, own_ms = run_timed(step, args.steps, args.warmup, world, "cpu", lambda: None)
+    facts = world_facts(own_ms, args.steps, "cpu")
+    if rank == 0:
+        ms = elapsed_ms / args.steps
+        ordered = bool(torch.equal(out[:, 0, 0], torch.arange(B * world, dtype=torch.float32)))
+        print(json.dumps({"metric": "image-pairs/sec (640x480, K=512)", "value": B * world / (ms * 1e-3),
+                          "unit": "image-pairs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "DRY RUN: stubbed compute on CPU over gloo -- not a measurement",
+                          "dry_run": True, "gathered_in_global_pair_order": ordered,
+                          "config": {"workload": "launcher / rendezvous / gather control flow only",
+                                     "pairs_per_gpu_per_step": B, "global_pairs_per_step": B * world,
+                                     "parallelism": f"pair-sharded x{world}"},
+                          "step_ms": step_stats(per_step), **facts}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -417,16 +521,25 @@ def main() -> None:
                          "u8 is the line `u8_ingest` reports, selectable here so that profilers can be pointed at it)")
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
                     help="c2 (default, the metric's configuration); c3 = 1080x1920 K=1024; c4 = AKAZE front end")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="control flow only: stubbed compute on CPU over gloo (tests the N > 1 launcher; not a measurement)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks ourselves -- BEFORE anything touches the
+    # GPU in this process (nothing above does; this process only waits for its children and relays rank 0's line)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     from onnx_image_processing_amd import _native, distributed as D
     from onnx_image_processing_amd.pytorch_model.feature_detection import (MatchExtractionWrapper,
                                                                            ShiTomasiSparseBADSinkhornMatcher)
     from onnx_image_processing_amd.synth import synth_batch_u8
 
-    rank, world, local = D.init()
+    rank, world, local = D.init(backend="gloo" if args.dry_run else None)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher's WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local)
@@ -462,7 +575,8 @@ def main() -> None:
     # HIP events around the roofline kernel's calls only (two per step) inside the timed region; the per-stage table
     # below comes from extra steps after it, so its 24 events per step do not sit in the measurement
     _native.enable_timing(True, only=None if args.single_call else {"mi_corner_response_balanced"})
-    elapsed_ms, per_step, out = run_timed(step, args.steps, args.warmup, world, dev, torch.cuda.synchronize)
+    elapsed_ms, per_step, out, own_ms = run_timed(step, args.steps, args.warmup, world, dev, torch.cuda.synchronize)
+    facts = world_facts(own_ms, args.steps, dev)
     per_call = _native.timings_ms()
     _native.enable_timing(False)
     stage_steps = 3
@@ -500,6 +614,7 @@ def main() -> None:
                        "input": ("uint8" if u8_main else "float32") + " frames resident in HBM",
                        "mean_valid_matches_per_pair": float(out[..., 5].sum().item()) / pairs_per_step},
             "step_ms": step_stats(per_step),
+            **facts,                                             # ranks_seen / backend / ms_per_step_per_rank: what ran
             "kernels": kernels,
         }
         if not args.single_call:

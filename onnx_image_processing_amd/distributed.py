@@ -27,6 +27,8 @@ def init(backend: str | None = None) -> tuple[int, int, int]:
     rank, world, local = env_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the pool's host driver supports only dmabuf IPC: with the legacy mode RCCL's peer-buffer exchange fails in
+        # hipIpcGetMemHandle ("invalid argument").  The image exports this already; set here for a bare environment.
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
