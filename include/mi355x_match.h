@@ -18,7 +18,19 @@
  *   - threads and devices: the device of `stream` must be the calling thread's current device.  Calls
  *     on DIFFERENT streams may run concurrently from different host threads; calls on the SAME
  *     stream must be serialised by the caller (as for any HIP stream).  The library holds no other
- *     mutable state (include/mi355x_match_debug.h's test hook aside);
+ *     mutable state and has no process-wide switches (the kernel-variant test hooks of
+ *     include/mi355x_match_debug.h exist only in the separate libmi355x_match_debug.so);
+ *   - co-residency: ONE kernel of this library needs its whole grid resident on the device at the same
+ *     time -- the single-launch Sinkhorn form mi_sinkhorn_dots / mi_match_pairs use for <= 8 pairs
+ *     (<= 128 workgroups of 512 threads whose bands hand column sums to each other inside the launch).
+ *     The library checks on the host that the grid fits the device it sees (occupancy x compute units;
+ *     a CU-masked or partitioned device takes the multi-launch form instead), and work on other streams
+ *     only delays it: its workgroups become resident as that work drains.  A band that still has not
+ *     arrived after ~1 s of polling is a failure, and a loud one: the call's status word
+ *     (mi_sinkhorn_dots_status_word) becomes non-zero, the pair's duals are NaN (so is P), and
+ *     mi_mnn_from_duals_dots / mi_match_pairs return valid = 0 for every match of the call.  A caller
+ *     that cannot accept that risk (a GPU shared with long-running foreign kernels) passes
+ *     MI_SOLVER_MULTI_LAUNCH and gets the form with no cross-workgroup dependency;
  *   - tensors are dense row-major float32 unless stated; images are (n, 1, h, w);
  *   - return value: 0 = launched; > 0 = hipError_t of the failed launch; < 0 = MI_E_*
  *     argument error detected on the host before any launch.
@@ -28,6 +40,9 @@
 
 #include <stddef.h>
 #include <stdint.h>
+
+/* the exported symbols: the library is built with -fvisibility=hidden, only these declarations are visible */
+#define MI_API __attribute__((visibility("default")))
 
 #ifdef __cplusplus
 extern "C" {
@@ -50,19 +65,21 @@ enum { MI_BAD_RAW = 0, MI_BAD_SOFT = 1, MI_BAD_HARD = 2 };
 enum { MI_DIST_L2 = 0, MI_DIST_L1 = 1 };
 /* smallest epsilon of the packed (uint16 dot product) Sinkhorn form, see mi_sinkhorn_dots */
 #define MI_DOTS_MIN_EPSILON 0.005
+/* flags of mi_sinkhorn_dots / mi_match_params (see "co-residency" above) */
+enum { MI_SOLVER_DEFAULT = 0, MI_SOLVER_MULTI_LAUNCH = 1 /* never the single-launch Sinkhorn form */ };
 
-int mi_abi_version(void);
-const char *mi_error_string(int code);
+MI_API int mi_abi_version(void);
+MI_API const char *mi_error_string(int code);
 /* Frees the helper streams / events held for (current device, stream), see the conventions above.  Call it
  * before destroying a stream that was passed to mi_sinkhorn_dots / mi_match_pairs with >= 64 pairs; the
  * stream's helper work must have completed (synchronise the stream first). */
-int mi_release_stream_resources(mi_stream_t stream);
+MI_API int mi_release_stream_resources(mi_stream_t stream);
 
 /* ---- detector/shi_tomasi.py:66-112  ShiTomasiScore.forward ---------------------------------
  * score[n,1,h,w] = max(0, (a+c)/2 - sqrt(((a-c)/2)^2 + b^2 + 1e-10)) of the Sobel structure
  * tensor summed over block_size^2 (replicate padding of image and of the product maps).
  * block_size: positive odd.  Bit-exact vs the reference for uint8-valued input, block 3. */
-int mi_corner_response(const float *image, int n, int h, int w, int block_size, float *score,
+MI_API int mi_corner_response(const float *image, int n, int h, int w, int block_size, float *score,
                        mi_stream_t stream);
 /* ---- u8 ingest (sample/visual_odometry.py:65-92 load_image_from_array, sample/image_matching.py:42-46: a uint8 gray
  * frame is converted to float32 (1,1,H,W) on the host before the model sees it).  The _u8 entry points take the
@@ -70,21 +87,22 @@ int mi_corner_response(const float *image, int n, int h, int w, int block_size, 
  * of 4 bytes per pixel read (corner response: 5 instead of 8 B/px of HBM traffic; a pair costs 0.6 instead of
  * 2.5 MB of PCIe when frames are streamed from the host).  mi_convert_u8_f32 is that conversion on the device, for
  * the entry points that have no uint8 form. */
-int mi_corner_response_u8(const uint8_t *image, int n, int h, int w, int block_size, float *score,
+MI_API int mi_corner_response_u8(const uint8_t *image, int n, int h, int w, int block_size, float *score,
                           mi_stream_t stream);
-int mi_convert_u8_f32(const uint8_t *src, long long count, float *dst, mi_stream_t stream);
+MI_API int mi_convert_u8_f32(const uint8_t *src, long long count, float *dst, mi_stream_t stream);
 /* mi_corner_response / _u8 (pixels_are_u8 = 0 / 1) with dynamic tile scheduling for large batches: tile_counter =
- * MI_TILE_COUNTER_BYTES of device memory that are ZERO when the call is issued; the kernel leaves them zero, so one
- * counter block serves every call of one stream (calls on different streams need different blocks).  NULL = the static
- * schedule of the two entry points above.  Same scores; equally sized static shares do not finish together because
- * the SIMDs issue oldest-first, tickets make them. */
+ * MI_TILE_COUNTER_BYTES of device memory, 4-byte aligned, of ANY content: the call clears the block on `stream`
+ * (a memset node) ahead of the kernel that draws tickets from it, so a block left dirty by a launch that died cannot
+ * make a later call skip tiles.  A block must not be shared by calls that may run concurrently (different streams
+ * need different blocks).  NULL = the static schedule of the two entry points above.  Same scores; equally sized
+ * static shares do not finish together because the SIMDs issue oldest-first, tickets make them. */
 #define MI_TILE_COUNTER_BYTES 16640
-int mi_corner_response_balanced(const void *image, int pixels_are_u8, int n, int h, int w, int block_size, float *score,
+MI_API int mi_corner_response_balanced(const void *image, int pixels_are_u8, int n, int h, int w, int block_size, float *score,
                                 uint32_t *tile_counter, mi_stream_t stream);
 
 /* ---- utils/keypoint_utils.py:12-44  apply_nms_maxpool ---------------------------------------
  * mask = 1.0f where score >= max over the (2r+1)^2 window (outside image = -inf) - 1e-7. */
-int mi_nms_mask(const float *score, int n, int h, int w, int radius, float *mask, mi_stream_t stream);
+MI_API int mi_nms_mask(const float *score, int n, int h, int w, int radius, float *mask, mi_stream_t stream);
 
 /* ---- utils/keypoint_utils.py:71-92 (candidate stage of select_topk_keypoints) ---------------
  * Emits one 64-bit key per surviving pixel:
@@ -96,10 +114,10 @@ int mi_nms_mask(const float *score, int n, int h, int w, int radius, float *mask
  * overflow), and no global atomics are used; the order inside a segment is unspecified.
  * mi_nms_candidates fuses the NMS of mi_nms_mask (mask never materialised);
  * mi_select_candidates takes an explicit mask (the reference's two-call form). */
-int mi_candidate_layout(int h, int w, int *segments, int *segment_capacity);
-int mi_nms_candidates(const float *score, int n, int h, int w, int radius, float score_threshold,
+MI_API int mi_candidate_layout(int h, int w, int *segments, int *segment_capacity);
+MI_API int mi_nms_candidates(const float *score, int n, int h, int w, int radius, float score_threshold,
                       int border_margin, uint64_t *cand, uint32_t *count, mi_stream_t stream);
-int mi_select_candidates(const float *score, const float *mask, int n, int h, int w,
+MI_API int mi_select_candidates(const float *score, const float *mask, int n, int h, int w,
                          float score_threshold, int border_margin, uint64_t *cand, uint32_t *count,
                          mi_stream_t stream);
 
@@ -107,7 +125,7 @@ int mi_select_candidates(const float *score, const float *mask, int n, int h, in
  * For each image: the k largest keys over all its segments, descending => (score desc, linear
  * index asc).  keypoints[n,k,2] = (y, x) as float, (-1,-1) beyond the candidate count;
  * kscores[n,k].  1 <= k <= 4096. */
-int mi_topk_keypoints(const uint64_t *cand, const uint32_t *count, int segments, int segment_capacity,
+MI_API int mi_topk_keypoints(const uint64_t *cand, const uint32_t *count, int segments, int segment_capacity,
                       int n, int w, int k, float *keypoints, float *kscores, mi_stream_t stream);
 
 /* ---- descriptor/bad.py:436-576  SparseBAD.forward (non-oriented, sampling_mode="nearest") ---
@@ -124,16 +142,16 @@ int mi_topk_keypoints(const uint64_t *cand, const uint32_t *count, int segments,
  * mi_bad_plan_build is the one set-up call of this ABI that synchronises: it reads the table back,
  * orders every pair's table-corner reads on the host so that the fast kernel's LDS gathers hit as few
  * banks twice as possible, and uploads the plan (two stream synchronisations; not hipGraph-capturable). */
-size_t mi_bad_plan_bytes(int num_pairs);
-int mi_bad_plan_build(const uint32_t *pair_geom, const float *pair_thr, int num_pairs, void *plan,
+MI_API size_t mi_bad_plan_bytes(int num_pairs);
+MI_API int mi_bad_plan_build(const uint32_t *pair_geom, const float *pair_thr, int num_pairs, void *plan,
                       mi_stream_t stream);
-int mi_sparse_bad(const float *image, int n, int h, int w, const float *keypoints, int k,
+MI_API int mi_sparse_bad(const float *image, int n, int h, int w, const float *keypoints, int k,
                   const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
                   float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
                   uint8_t *status, mi_stream_t stream);
 
 /* u8 ingest form of mi_sparse_bad (see mi_corner_response_u8): identical results from a uint8 image. */
-int mi_sparse_bad_u8(const uint8_t *image, int n, int h, int w, const float *keypoints, int k,
+MI_API int mi_sparse_bad_u8(const uint8_t *image, int n, int h, int w, const float *keypoints, int k,
                      const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
                      float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
                      uint8_t *status, mi_stream_t stream);
@@ -144,14 +162,14 @@ int mi_sparse_bad_u8(const uint8_t *image, int n, int h, int w, const float *key
  * (the reference's fp32 integral image is itself inexact above 2^24).
  * mi_gather_descriptors: descriptor/bad.py:221-333, (batch,d,h,w) map sampled at keypoints
  * (batch,nk,2) -> (batch,nk,d); bilinear = 0: integer truncation, 1: grid_sample bilinear/border. */
-int mi_bad_dense(const float *image, int n, int h, int w, const uint32_t *pair_geom, const float *pair_thr,
+MI_API int mi_bad_dense(const float *image, int n, int h, int w, const uint32_t *pair_geom, const float *pair_thr,
                  int num_pairs, int mode, float temperature, float *out, mi_stream_t stream);
 /* descriptor/bad.py:112-187 (_compute_diff_map_oriented): the same map with every pixel's pair offsets
  * rotated by orientation (n,1,h,w) there and the box means sampled bilinearly (exact box sums). */
-int mi_bad_dense_oriented(const float *image, const float *orientation, int n, int h, int w,
+MI_API int mi_bad_dense_oriented(const float *image, const float *orientation, int n, int h, int w,
                           const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
                           float temperature, float *out, mi_stream_t stream);
-int mi_gather_descriptors(const float *descriptor_map, int batch, int d, int h, int w, const float *keypoints,
+MI_API int mi_gather_descriptors(const float *descriptor_map, int batch, int d, int h, int w, const float *keypoints,
                           int nk, int bilinear, float *out, mi_stream_t stream);
 
 /* ---- orientation/angle_estimation.py:86-172  AngleEstimator.forward --------------------------
@@ -159,9 +177,9 @@ int mi_gather_descriptors(const float *descriptor_map, int batch, int d, int h, 
  * moment_kernels: the module's (2,1,ps,ps) weight buffer (x*G then y*G), patch_size odd <= 31.
  * mi_angle_map writes the dense (n,1,h,w) map; mi_angle_at_keypoints writes theta (n,k) only at
  * the keypoints (what descriptor/bad.py:487-500 samples from the map, same nearest rounding). */
-int mi_angle_map(const float *image, int n, int h, int w, int patch_size, const float *moment_kernels,
+MI_API int mi_angle_map(const float *image, int n, int h, int w, int patch_size, const float *moment_kernels,
                  float *angle, mi_stream_t stream);
-int mi_angle_at_keypoints(const float *image, int n, int h, int w, const float *keypoints, int k,
+MI_API int mi_angle_at_keypoints(const float *image, int n, int h, int w, const float *keypoints, int k,
                           int patch_size, const float *moment_kernels, float *theta, mi_stream_t stream);
 
 /* ---- descriptor/bad.py:487-517  SparseBAD.forward, oriented branch; and sampling_mode "bilinear" --
@@ -172,7 +190,7 @@ int mi_angle_at_keypoints(const float *image, int n, int h, int w, const float *
  * sign test in fp32.  The non-oriented bilinear case is angle 0 for every keypoint.
  * status (optional): n*k bytes of workspace; when given, keypoints on uint8-valued windows are done
  * with an int32 table (half the LDS, same results) and only the rest with the fp64 one. */
-int mi_sparse_bad_oriented(const float *image, int n, int h, int w, const float *keypoints, int k,
+MI_API int mi_sparse_bad_oriented(const float *image, int n, int h, int w, const float *keypoints, int k,
                            const float *orientation_map, const float *keypoint_angles,
                            const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
                            float temperature, int normalize, int bilinear, float *desc, uint32_t *bits,
@@ -188,10 +206,10 @@ int mi_sparse_bad_oriented(const float *image, int n, int h, int w, const float 
  *     desc = bit/sqrt(popcount) (cost = 2 - 2 dot/sqrt(pa pb)) or desc = bit (cost = Hamming).
  *     Dot products are exact (v_mfma_i32_32x32x32_i8 on 0/1 bytes).
  * _f32: arbitrary float descriptors (n,d)/(m,d); L2 via v_mfma_f32_32x32x2_f32, L1 on the VALU. */
-int mi_cost_logscores_bits(const uint32_t *bits1, const uint32_t *bits2, int batch, int n, int m,
+MI_API int mi_cost_logscores_bits(const uint32_t *bits1, const uint32_t *bits2, int batch, int n, int m,
                            int num_bits, int normalized, double epsilon, float *z, int pitch,
                            mi_stream_t stream);
-int mi_cost_logscores_f32(const float *desc1, const float *desc2, int batch, int n, int m, int d,
+MI_API int mi_cost_logscores_f32(const float *desc1, const float *desc2, int batch, int n, int m, int d,
                           int distance, double epsilon, float *z, int pitch, mi_stream_t stream);
 
 /* ---- matching/sinkhorn.py:112-147,187-206  log-space Sinkhorn with dustbins ------------------
@@ -202,8 +220,8 @@ int mi_cost_logscores_f32(const float *desc1, const float *desc2, int batch, int
  * iteration that reads Z once per iteration (per-band column partials); with workspace == NULL
  * (or m > 1024, for which the query returns 0) the two-pass form runs -- same results up to
  * fp32 summation order. */
-size_t mi_sinkhorn_workspace_bytes(int batch, int n, int m);
-int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, float dustbin_logscore,
+MI_API size_t mi_sinkhorn_workspace_bytes(int batch, int n, int m);
+MI_API int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, float dustbin_logscore,
                 int iterations, float *u, float *v, float *p, void *workspace, size_t workspace_bytes,
                 mi_stream_t stream);
 
@@ -225,27 +243,34 @@ int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, float dustbi
  * descriptors, num_bits otherwise), or 0 if unknown.  With a bound small enough that
  * 2 * sqnorm_bound / epsilon < ~62 the row pass shifts every row of a pair by one analytic bound
  * instead of each row's own maximum (same result to fp32 rounding, fewer instructions); a bound the
- * data exceeds is a contract violation (exponent overflow).  0 always takes the per-row-maximum path. */
-int mi_cost_dots_bits(const uint32_t *bits1, const uint32_t *bits2, int batch, int n, int m, int num_bits,
+ * data exceeds is a contract violation (exponent overflow).  0 always takes the per-row-maximum path.
+ * flags: MI_SOLVER_DEFAULT, or MI_SOLVER_MULTI_LAUNCH to rule out the single-launch form (which otherwise runs for
+ * batch <= 8, n, m <= 512 when its grid fits the device; same duals bit for bit either way).
+ * mi_sinkhorn_dots_status_word: the device address, inside `workspace`, of the call's 32-bit status word -- written by
+ * every mi_sinkhorn_dots call with these extents: 0 = solved, non-zero = a hand-off of the single-launch form timed out
+ * and u, v (and p) of the affected pairs are NaN.  Read it after synchronising, or hand it to mi_mnn_from_duals_dots. */
+MI_API int mi_cost_dots_bits(const uint32_t *bits1, const uint32_t *bits2, int batch, int n, int m, int num_bits,
                       int normalized, uint16_t *dots, int pitch, float *row_info, float *col_info,
                       mi_stream_t stream);
-size_t mi_sinkhorn_dots_workspace_bytes(int batch, int n, int m);
-int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch, int n,
+MI_API size_t mi_sinkhorn_dots_workspace_bytes(int batch, int n, int m);
+MI_API int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch, int n,
                      int m, int pitch, double epsilon, double unused_score, double sqnorm_bound, int iterations,
-                     float *u, float *v, float *p, void *workspace, size_t workspace_bytes, mi_stream_t stream);
+                     float *u, float *v, float *p, void *workspace, size_t workspace_bytes, int flags,
+                     mi_stream_t stream);
+MI_API const uint32_t *mi_sinkhorn_dots_status_word(const void *workspace, int batch, int n, int m);
 
 /* ---- matching/sinkhorn.py:317-465  SinkhornMatcherWithFilters (filter stage) -----------------
  * In place on p (batch, n+1, m+1): per row i < n, best/second-best core probability and the
  * dustbin entry decide valid[b,i] (ratio_threshold <= 0 / dustbin_margin < 0 disable a filter);
  * failing rows get core * 0 and dustbin entry 1, as the reference writes them. */
-int mi_match_filters(float *p, int batch, int n, int m, float ratio_threshold, float dustbin_margin,
+MI_API int mi_match_filters(float *p, int batch, int n, int m, float ratio_threshold, float dustbin_margin,
                      uint8_t *valid, mi_stream_t stream);
 /* ---- matching/outlier_filters.py:11-116  probability_ratio_filter / dustbin_margin_filter ------
  * The same two tests as masks only (p is not modified): valid[b,i] for i < n.
  * has_dustbin = 1: p is (batch, n+1, m+1) with the dustbin column (dustbin_margin_filter's argument; both tests
  * available); 0: p is the (batch, n, m) core (probability_ratio_filter's argument; dustbin_margin must be < 0).
  * ratio_threshold <= 0 / dustbin_margin < 0 disable a test. */
-int mi_match_filter_masks(const float *p, int batch, int n, int m, int has_dustbin, float ratio_threshold,
+MI_API int mi_match_filter_masks(const float *p, int batch, int n, int m, int has_dustbin, float ratio_threshold,
                           float dustbin_margin, uint8_t *valid, mi_stream_t stream);
 
 /* ---- matching/match_extraction.py:72-181  MutualNearestNeighborMatcher.forward --------------
@@ -253,7 +278,7 @@ int mi_match_filter_masks(const float *p, int batch, int n, int m, int has_dustb
  * col_best (batch*m) u64.  Outputs mk1/mk2 (batch,max_matches,2), scores (batch,max_matches),
  * valid (batch,max_matches) u8, match_ij (batch,max_matches,2) i32 (may be NULL).
  * n <= 4096.  Ties: first index (argmax), then (score desc, row asc) for the top-max_matches. */
-int mi_mnn_extract(const float *p, int batch, int n, int m, const float *kpts1, const float *kpts2,
+MI_API int mi_mnn_extract(const float *p, int batch, int n, int m, const float *kpts1, const float *kpts2,
                    int max_matches, float threshold, uint64_t *row_best, uint64_t *col_best,
                    float *mk1, float *mk2, float *scores, uint8_t *valid, int32_t *match_ij,
                    mi_stream_t stream);
@@ -264,17 +289,19 @@ int mi_mnn_extract(const float *p, int batch, int n, int m, const float *kpts1, 
  * mi_sinkhorn's final pass does, so the outputs are bit-identical to mi_sinkhorn(p != NULL) followed
  * by mi_mnn_extract.  z/pitch (or dots/row_info/col_info/pitch/epsilon) and u, v are what was
  * passed to / returned by mi_sinkhorn (mi_sinkhorn_dots) with p == NULL.  m <= 1024, n <= 4096.
- * workspace: mi_mnn_duals_workspace_bytes(batch, n, m) bytes (0 = unsupported size), 8-byte aligned. */
-size_t mi_mnn_duals_workspace_bytes(int batch, int n, int m);
-int mi_mnn_from_duals(const float *z, int batch, int n, int m, int pitch, const float *u, const float *v,
+ * workspace: mi_mnn_duals_workspace_bytes(batch, n, m) bytes (0 = unsupported size), 8-byte aligned.
+ * solver_status (mi_mnn_from_duals_dots; may be NULL): the status word of the mi_sinkhorn_dots call that produced
+ * u, v.  When it is non-zero on the device every match of this call comes back with score -1 / valid 0 / match_ij -1. */
+MI_API size_t mi_mnn_duals_workspace_bytes(int batch, int n, int m);
+MI_API int mi_mnn_from_duals(const float *z, int batch, int n, int m, int pitch, const float *u, const float *v,
                       const float *kpts1, const float *kpts2, int max_matches, float threshold, void *workspace,
                       size_t workspace_bytes, float *mk1, float *mk2, float *scores, uint8_t *valid,
                       int32_t *match_ij, mi_stream_t stream);
-int mi_mnn_from_duals_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch, int n,
+MI_API int mi_mnn_from_duals_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch, int n,
                            int m, int pitch, double epsilon, const float *u, const float *v, const float *kpts1,
                            const float *kpts2, int max_matches, float threshold, void *workspace,
-                           size_t workspace_bytes, float *mk1, float *mk2, float *scores, uint8_t *valid,
-                           int32_t *match_ij, mi_stream_t stream);
+                           size_t workspace_bytes, const uint32_t *solver_status, float *mk1, float *mk2,
+                           float *scores, uint8_t *valid, int32_t *match_ij, mi_stream_t stream);
 
 /* ---- detector/akaze.py  AKAZE (BASELINE config 4), all maps fp32 (n,1,h,w) ---------------------
  * mi_akaze_diffuse: one explicit step of NonLinearDiffusion.forward (akaze.py:98-131):
@@ -289,30 +316,30 @@ int mi_mnn_from_duals_dots(const uint16_t *dots, const float *row_info, const fl
  * mi_akaze_orientation_at_keypoints: the same selection evaluated only at keypoints (n,k,2):
  *   scale_theta (num_scales,n,k) from mi_angle_at_keypoints per scale -> theta (n,k); equal to
  *   sampling the combined map the way descriptor/bad.py:487-500 does. */
-int mi_akaze_diffuse(const float *l_in, int n, int h, int w, float kappa, float dt, float *l_out,
+MI_API int mi_akaze_diffuse(const float *l_in, int n, int h, int w, float kappa, float dt, float *l_out,
                      mi_stream_t stream);
 /* One scale of AKAZE.forward (akaze.py:430-440) in one launch: l_out = `iterations` diffusion steps of l_in,
  * scores = mi_akaze_hessian_scores(l_out); identical maps, 12 instead of 8 * iterations + 8 bytes per pixel of HBM
  * traffic (the steps run on an LDS-resident tile).  Fused for iterations 1..3 and nms_size 3 / 5 / 7
  * (mi_akaze_scale_fused returns 1); other values run the per-step kernels and then need `tmp` (n*h*w floats) when
  * iterations > 1.  l_out must not alias l_in. */
-int mi_akaze_scale_fused(int iterations, int nms_size);
-int mi_akaze_scale(const float *l_in, int n, int h, int w, int iterations, float kappa, float dt, float threshold,
+MI_API int mi_akaze_scale_fused(int iterations, int nms_size);
+MI_API int mi_akaze_scale(const float *l_in, int n, int h, int w, int iterations, float kappa, float dt, float threshold,
                    int nms_size, float *l_out, float *scores, float *tmp, mi_stream_t stream);
-int mi_akaze_hessian_scores(const float *l, int n, int h, int w, float threshold, int nms_size, float *scores,
+MI_API int mi_akaze_hessian_scores(const float *l, int n, int h, int w, float threshold, int nms_size, float *scores,
                             mi_stream_t stream);
-int mi_akaze_combine(const float *scale_scores, const float *scale_orientations, int num_scales, int n, int h,
+MI_API int mi_akaze_combine(const float *scale_scores, const float *scale_orientations, int num_scales, int n, int h,
                      int w, float *scores, float *orientations, mi_stream_t stream);
-int mi_akaze_orientation_at_keypoints(const float *scale_scores, const float *scale_theta, int num_scales,
+MI_API int mi_akaze_orientation_at_keypoints(const float *scale_scores, const float *scale_theta, int num_scales,
                                       int n, int h, int w, const float *keypoints, int k, float *theta,
                                       mi_stream_t stream);
 
 /* ---- matching/sinkhorn.py:228-259  SinkhornMatcherWithScores: maxima of P[:n,:m] per row / column */
-int mi_core_maxima(const float *p, int batch, int n, int m, float *row_max, float *col_max, mi_stream_t stream);
+MI_API int mi_core_maxima(const float *p, int batch, int n, int m, float *row_max, float *col_max, mi_stream_t stream);
 
 /* ---- feature_detection/..._essential_matrix.py:334-360: `count` keypoints (y, x) in pixels -> normalised
  * image coordinates (x, y), the first two rows of k_inv (3x3 row-major, device memory) times [x, y, 1]. */
-int mi_normalise_keypoints(const float *keypoints, long long count, const float *k_inv, float *points,
+MI_API int mi_normalise_keypoints(const float *keypoints, long long count, const float *k_inv, float *points,
                            mi_stream_t stream);
 
 /* ---- geometry/essential_matrix_estimator.py:302-431  EssentialMatrixEstimator.forward and the
@@ -324,7 +351,7 @@ int mi_normalise_keypoints(const float *keypoints, long long count, const float 
  * eigenvector, denormalisation, projection onto singular values (s, s, 0) with n_iter_manifold steps.
  * pts1 (batch, n, 2), pts2 (batch, m, 2): NORMALISED image coordinates (x, y) = K^-1 [px, py, 1].
  * e (batch, 3, 3).  n, m <= 1024, 1 <= top_k <= min(8, n, m).  Deterministic. */
-int mi_essential_matrix(const float *p, int batch, int n, int m, const float *pts1, const float *pts2,
+MI_API int mi_essential_matrix(const float *p, int batch, int n, int m, const float *pts1, const float *pts2,
                         const uint8_t *valid1, const uint8_t *valid2, int top_k, int n_iter,
                         int n_iter_manifold, float *e, mi_stream_t stream);
 
@@ -337,8 +364,8 @@ int mi_essential_matrix(const float *p, int batch, int n, int m, const float *pt
  * (their exact 1-D factors).  2 <= num_scales <= 8, kernel_size odd <= 49.
  * score (n,1,h,w), optional: max over scales of |DoG| (DoGDetectorWithScore.forward, dog.py:182-204);
  * out or score may be NULL, not both. */
-int mi_fast_score(const float *image, int n, int h, int w, float threshold, float *score, mi_stream_t stream);
-int mi_dog_responses(const float *image, int n, int h, int w, const float *weights_1d, int num_scales,
+MI_API int mi_fast_score(const float *image, int n, int h, int w, float threshold, float *score, mi_stream_t stream);
+MI_API int mi_dog_responses(const float *image, int n, int h, int w, const float *weights_1d, int num_scales,
                      int kernel_size, float *out, float *score, mi_stream_t stream);
 
 /* ---- feature_detection/match_extraction_wrapper.py:82-113 over shi_tomasi_sparse_bad_sinkhorn.py:79-182
@@ -367,15 +394,16 @@ typedef struct mi_match_params {
   int sinkhorn_iterations;
   int max_matches;           /* MutualNearestNeighborMatcher */
   float match_threshold;
+  int flags;                 /* MI_SOLVER_DEFAULT or MI_SOLVER_MULTI_LAUNCH (see "co-residency" in the conventions) */
 } mi_match_params;
-size_t mi_match_pairs_workspace_bytes(int batch, int h, int w, const mi_match_params *params);
-int mi_match_pairs(const float *image1, const float *image2, int batch, int h, int w,
+MI_API size_t mi_match_pairs_workspace_bytes(int batch, int h, int w, const mi_match_params *params);
+MI_API int mi_match_pairs(const float *image1, const float *image2, int batch, int h, int w,
                    const mi_match_params *params, float *keypoints1, float *keypoints2, float *matched1,
                    float *matched2, float *match_scores, uint8_t *match_valid, int32_t *match_ij,
                    void *workspace, size_t workspace_bytes, mi_stream_t stream);
 
 /* u8 ingest form of mi_match_pairs: uint8 frames (batch,1,h,w), same workspace, identical results. */
-int mi_match_pairs_u8(const uint8_t *image1, const uint8_t *image2, int batch, int h, int w,
+MI_API int mi_match_pairs_u8(const uint8_t *image1, const uint8_t *image2, int batch, int h, int w,
                       const mi_match_params *params, float *keypoints1, float *keypoints2, float *matched1,
                       float *matched2, float *match_scores, uint8_t *match_valid, int32_t *match_ij,
                       void *workspace, size_t workspace_bytes, mi_stream_t stream);

@@ -1,37 +1,48 @@
 /*
- * mi355x_match_debug.h -- development / test hooks of libmi355x_match.so.  NOT part of the product ABI
- * (include/mi355x_match.h): nothing here changes results, only which of two equivalent kernel
- * implementations runs, and the setting is process-wide (atomics), so a product binding must not call it.
- * tests/ use it to compare the alternatives bit for bit; tools/kbench.py to time them.
+ * mi355x_match_debug.h -- development / test hooks.  NOT part of the product ABI (include/mi355x_match.h) and NOT in
+ * the product library: these entry points exist only in libmi355x_match_debug.so, a second build of the same sources
+ * with -DMI_DEBUG_HOOKS (csrc/hooks.h) that also exports everything of include/mi355x_match.h.  Nothing here changes
+ * results, only which of two equivalent kernel implementations runs; the setting is process-wide (atomics).
+ * tests/ load the debug library to compare the alternatives bit for bit; tools/ to time them.
  */
 #ifndef MI355X_MATCH_DEBUG_H
 #define MI355X_MATCH_DEBUG_H
 
 #include <stdint.h>
 
+#ifndef MI_API
+#define MI_API __attribute__((visibility("default")))
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 
 /* Choose between equivalent kernel implementations (results are
- * identical).  key 1: corner response, 0 = streaming LDS-DMA kernel (default), 1 = register-
+ * identical).  key 0: reset every selector to the product library's value and switch the probes off.  key 1: corner response, 0 = streaming LDS-DMA kernel (default), 1 = register-
  * staged tile kernel.  key 2: rows per thread of the streaming corner kernel (4, 5 or 8).
  * key 6: number of batch parts mi_sinkhorn_dots runs on separate streams (1..4, default 2).
  * key 7: mi_sinkhorn_dots for <= 8 pairs (n, m <= 512), 1 = single-launch form (default), 0 = multi-launch form.
  * key 8: 1 = the single-launch Sinkhorn kernel records phase time stamps behind its workspace's fail word (tools/).
  * key 9: top-k, 1 = radix-select the k-th key and sort only the k winners when k << candidates
  * (default), 0 = always sort every candidate.
+ * key 10: workgroups per image of the top-k histogram passes when the candidates are selected from global memory
+ * (-1 = automatic, the default; 1 = the single-workgroup form).
  * key 4: Sinkhorn band kernel, 0 = probability form, lean instruction stream (default), 2 = first
  * probability-form kernel, 1 = log-domain (max,sum) partials (results agree to fp32 rounding). */
-int mi_debug_set(int key, int value);
+MI_API int mi_debug_set(int key, int value);
 /* top-k kernel phase time stamps (100 MHz clock) of workgroup 0 into `buffer` (8 x uint64, device memory); NULL = off */
-int mi_debug_topk_stamps(void *buffer);
+MI_API int mi_debug_topk_stamps(void *buffer);
 /* streaming corner kernel: every workgroup of the persistent grid writes {shader clock, 100 MHz clock} at entry and
  * exit into `buffer` (4 x uint64 per workgroup, <= 2048 workgroups; device memory); NULL = off */
-int mi_debug_clock_probe(void *buffer);
+MI_API int mi_debug_clock_probe(void *buffer);
 /* fast BAD kernel: LDS passes per keypoint of its gather schedule (csrc/bad_plan_opt.h) for a HOST copy of a pair table,
  * as the table stands and as mi_bad_plan_build schedules it (num_pairs / 4 = conflict-free).  Host only, no GPU. */
-int mi_debug_bad_plan_passes(const uint32_t *pair_geom_host, int num_pairs, int *canonical, int *scheduled);
+MI_API int mi_debug_bad_plan_passes(const uint32_t *pair_geom_host, int num_pairs, int *canonical, int *scheduled);
+/* which Sinkhorn form mi_sinkhorn_dots chooses (1 = single launch, 0 = multi launch) for these extents and flags on a
+ * device that can hold `blocks_per_cu` workgroups of the single-launch kernel on each of `cus` compute units: the pure
+ * host decision function the library applies to the occupancy query's answer.  Host only, no GPU. */
+MI_API int mi_debug_sinkhorn_dots_form(int batch, int n, int m, int flags, int blocks_per_cu, int cus);
 
 #ifdef __cplusplus
 }

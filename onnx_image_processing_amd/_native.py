@@ -53,7 +53,8 @@ SIGNATURES = {
                           c_void_p],
     "mi_sinkhorn_dots_workspace_bytes": [c_int, c_int, c_int],
     "mi_sinkhorn_dots": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_int,
-                         c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
+                         c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p],
+    "mi_sinkhorn_dots_status_word": [c_void_p, c_int, c_int, c_int],
     "mi_match_filters": [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p],
     "mi_match_filter_masks": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p],
     "mi_mnn_extract": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
@@ -63,7 +64,7 @@ SIGNATURES = {
                           c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mi_mnn_from_duals_dots": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_int, c_float, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_void_p, c_void_p],
+                               c_void_p, c_void_p, c_void_p, c_void_p],
     "mi_core_maxima": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mi_normalise_keypoints": [c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p],
     "mi_essential_matrix": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -87,41 +88,79 @@ class MatchParams(ctypes.Structure):
                 ("border_margin", c_int), ("num_pairs", c_int), ("pair_geom", c_void_p), ("pair_thr", c_void_p),
                 ("bad_plan", c_void_p), ("normalize_descriptors", c_int), ("epsilon", c_double),
                 ("unused_score", c_double), ("sinkhorn_iterations", c_int), ("max_matches", c_int),
-                ("match_threshold", c_float)]
+                ("match_threshold", c_float), ("flags", c_int)]
 
 
 SIGNATURES["mi_match_pairs_workspace_bytes"] = [c_int, c_int, c_int, ctypes.POINTER(MatchParams)]
 SIGNATURES["mi_match_pairs"] = [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(MatchParams), c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
-# include/mi355x_match_debug.h: test / tooling hooks, not part of the product ABI (nothing in this package calls them)
+# include/mi355x_match_debug.h: test / tooling hooks -- exported only by lib/libmi355x_match_debug.so (debug_library()),
+# not part of the product ABI; nothing in this package calls them
 DEBUG_SIGNATURES = {"mi_debug_set": [c_int, c_int], "mi_debug_topk_stamps": [c_void_p], "mi_debug_clock_probe": [c_void_p],
-                    "mi_debug_bad_plan_passes": [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]}
+                    "mi_debug_bad_plan_passes": [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
+                    "mi_debug_sinkhorn_dots_form": [c_int, c_int, c_int, c_int, c_int, c_int]}
 SIGNATURES["mi_match_pairs_u8"] = SIGNATURES["mi_match_pairs"]
-_RESTYPE = {"mi_match_pairs_workspace_bytes": c_size_t, "mi_error_string": c_char_p, "mi_sinkhorn_workspace_bytes": c_size_t, "mi_bad_plan_bytes": c_size_t,
+_RESTYPE = {"mi_sinkhorn_dots_status_word": c_void_p, "mi_match_pairs_workspace_bytes": c_size_t, "mi_error_string": c_char_p, "mi_sinkhorn_workspace_bytes": c_size_t, "mi_bad_plan_bytes": c_size_t,
             "mi_sinkhorn_dots_workspace_bytes": c_size_t, "mi_mnn_duals_workspace_bytes": c_size_t}
 
 MI_BAD_RAW, MI_BAD_SOFT, MI_BAD_HARD = 0, 1, 2
 MI_DIST_L2, MI_DIST_L1 = 0, 1
 
-_lib = None
+DEBUG_LIB_PATH = os.path.join(_PKG, "lib", "libmi355x_match_debug.so")
+
+_lib = None            # the library every call() goes through: the product, unless inside debug_library()
+_product = None
+_debug = None
+
+
+def _open(path: str, signatures: dict) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP library is not built. Run "
+            "`python -m onnx_image_processing_amd.build` (there is no CPU fallback)."
+        )
+    lib = ctypes.CDLL(path)
+    for name, argtypes in signatures.items():
+        fn = getattr(lib, name)            # AttributeError if the ABI and the binding diverge
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, c_int)
+    return lib
 
 
 def load() -> ctypes.CDLL:
-    """Load the library once; raise loudly when it has not been built."""
-    global _lib
+    """The library in use (the product library unless a debug_library() block is active), loaded once; raises loudly
+    when it has not been built."""
+    global _lib, _product
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f"{LIB_PATH} not found: the HIP library is not built. Run "
-                "`python -m onnx_image_processing_amd.build` (there is no CPU fallback)."
-            )
-        lib = ctypes.CDLL(LIB_PATH)
-        for name, argtypes in {**SIGNATURES, **DEBUG_SIGNATURES}.items():
-            fn = getattr(lib, name)            # AttributeError if the ABI and the binding diverge
-            fn.argtypes = argtypes
-            fn.restype = _RESTYPE.get(name, c_int)
-        _lib = lib
+        if _product is None:
+            _product = _open(LIB_PATH, SIGNATURES)
+        _lib = _product
     return _lib
+
+
+class debug_library:
+    """with debug_library() as lib: ... -- tests / tools only.  Inside the block every call of this package goes through
+    lib/libmi355x_match_debug.so (same sources, -DMI_DEBUG_HOOKS), whose mi_debug_* hooks select between equivalent
+    kernel implementations; on exit the hooks are back at their defaults and the product library is in use again."""
+
+    def __enter__(self) -> ctypes.CDLL:
+        global _lib, _debug
+        load()
+        if _debug is None:
+            _debug = _open(DEBUG_LIB_PATH, {**SIGNATURES, **DEBUG_SIGNATURES})
+        self._outer = _lib
+        _lib = _debug
+        return _debug
+
+    def __exit__(self, *exc) -> None:
+        global _lib
+        _debug.mi_debug_set(0, 0)                  # key 0: every selector back to the product's value, probes off
+        _lib = self._outer
+
+
+def use_debug_library() -> ctypes.CDLL:
+    """tools/ only: switch this process to the debug library for good (debug_library() without the exit)."""
+    return debug_library().__enter__()
 
 
 def check(code: int, what: str) -> None:

@@ -2,9 +2,10 @@
 
     python -m onnx_image_processing_amd.build [--force]
 
-hipcc cross-compiles without a GPU.  Output: onnx_image_processing_amd/lib/libmi355x_match.so
-(git-ignored; it travels to the GPU box with the working tree).  Objects are rebuilt only when
-a source or header is newer.
+hipcc cross-compiles without a GPU.  Output: onnx_image_processing_amd/lib/libmi355x_match.so -- the product: exports
+exactly include/mi355x_match.h -- and lib/libmi355x_match_debug.so (the same ABI plus the kernel-variant test hooks of
+include/mi355x_match_debug.h; tests/ and tools/ only).  Both are git-ignored and travel to the GPU box with the working
+tree.  Objects are rebuilt only when a source or header is newer.
 """
 from __future__ import annotations
 
@@ -19,16 +20,28 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libmi355x_match.so")
+# the same sources with -DMI_DEBUG_HOOKS: exports include/mi355x_match_debug.h as well; loaded by tests/ and tools/ only
+DEBUG_LIB = os.path.join(LIBDIR, "libmi355x_match_debug.so")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 
 SOURCES = ["corner.hip", "nms.hip", "topk.hip", "bad.hip", "bad_oriented.hip", "bad_dense.hip", "orient.hip", "cost.hip", "sinkhorn.hip", "sinkhorn_dots.hip", "mnn.hip", "akaze.hip", "essential.hip", "detectors.hip", "match_pairs.hip"]
+# sources that read a hook of csrc/hooks.h: compiled a second time for the debug library; every other object is shared
+HOOKED = ["corner.hip", "topk.hip", "sinkhorn.hip", "sinkhorn_dots.hip"]
+DEBUG_ONLY = ["hooks.hip"]
 # -ffp-contract=off: the corner response must not fuse a*b+c (bit parity with the reference's
 # op-by-op fp32); IEEE sqrt/div are hipcc's defaults and are relied upon.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
+# -fvisibility=hidden: only the MI_API declarations of include/*.h are exported (no C++-mangled internals).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall",
          "-Wno-unused-function", f"-I{INCLUDE}"]
 # per-file extras.  corner.hip: SLP packs the stencil's fp32 adds/muls into v_pk_* ops, which issue
 # at half rate on gfx950 and need extra moves to pair operands (+18 % VALU slots measured).
-EXTRA_FLAGS = {"corner.hip": ["-fno-slp-vectorize"]}
+# -save-temps=obj keeps corner's gfx950 assembly next to its object: tests/test_k1_isa.py lints the hand-scheduled
+# region of the ticket kernel in it (CPU only).
+EXTRA_FLAGS = {"corner.hip": ["-fno-slp-vectorize", "-save-temps=obj"]}
+# -Bsymbolic: calls between the library's own entry points bind inside the library (two builds of the same ABI can be
+# loaded into one process -- product and debug -- without one's calls landing in the other)
+LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic",
+              f"-Wl,--version-script={os.path.join(CSRC, 'exports.map')}"]
 
 
 def _hipcc() -> str:
@@ -46,34 +59,46 @@ def _newer(target: str, deps: list[str]) -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Build both libraries (objects are rebuilt only when a source or header is newer); returns the product library."""
     os.makedirs(OBJDIR, exist_ok=True)
     headers = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))) + [os.path.abspath(__file__)]
+    link_deps = [os.path.join(CSRC, "exports.map")]
     hipcc = _hipcc()
     # development hook for on-box parameter sweeps: MI_BUILD_DEFINES="-DAS_WAVES=16 ..." (forces a full rebuild)
     extra_defines = os.environ.get("MI_BUILD_DEFINES", "").split()
     force = force or bool(extra_defines)
     jobs = []
-    objs = []
-    for src in SOURCES:
+    objs, debug_objs = [], []
+
+    def want(src: str, suffix: str, defines: list[str]) -> str:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        objs.append(o)
+        o = os.path.join(OBJDIR, src.replace(".hip", suffix + ".o"))
         if force or _newer(o, [s] + headers):
-            jobs.append([hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), *extra_defines, "-c", s, "-o", o])
+            extra = [f for f in EXTRA_FLAGS.get(src, []) if not (defines and f.startswith("-save-temps"))]   # temps: product only
+            jobs.append([hipcc, *FLAGS, *extra, *defines, *extra_defines, "-c", s, "-o", o])
+        return o
+
+    for src in SOURCES:
+        o = want(src, "", [])
+        objs.append(o)
+        debug_objs.append(want(src, ".dbg", ["-DMI_DEBUG_HOOKS"]) if src in HOOKED else o)
+    for src in DEBUG_ONLY:
+        debug_objs.append(want(src, ".dbg", ["-DMI_DEBUG_HOOKS"]))
 
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=OBJDIR)
         if r.returncode != 0:
             raise RuntimeError(f"build failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _newer(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+    for lib, members in ((LIB, objs), (DEBUG_LIB, debug_objs)):
+        if jobs or force or _newer(lib, members + link_deps):
+            run([hipcc, *LINK_FLAGS, *members, "-o", lib])
     return LIB
 
 

@@ -469,9 +469,9 @@ extern "C" size_t mi_bad_plan_bytes(int num_pairs) {
          (size_t)(num_pairs / 64) * (num_pairs / 64) * sizeof(uint64_t);
 }
 
-// development aid (include/mi355x_match_debug.h): the LDS passes per keypoint of the gather schedule for a HOST copy
-// of a pair table, as the table stands and as scheduled -- no GPU involved
-extern "C" int mi_debug_bad_plan_passes(const uint32_t *pair_geom_host, int num_pairs, int *canonical, int *scheduled) {
+// development aid (mi_debug_bad_plan_passes of the debug library, csrc/hooks.hip): the LDS passes per keypoint of the
+// gather schedule for a HOST copy of a pair table, as the table stands and as scheduled -- no GPU involved
+int mi_bad_plan_passes_host(const uint32_t *pair_geom_host, int num_pairs, int *canonical, int *scheduled) {
   if (!pair_geom_host || !canonical || !scheduled) return MI_E_NULL;
   if (num_pairs <= 0 || num_pairs % 64 != 0 || num_pairs > 1024) return MI_E_PARAM;
   const auto hp = host_plan_for(std::vector<uint32_t>(pair_geom_host, pair_geom_host + num_pairs));

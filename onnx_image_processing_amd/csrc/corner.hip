@@ -13,20 +13,11 @@
 
 #pragma clang fp contract(off)
 
-#include <atomic>
 #include <type_traits>
 
-#include "../../include/mi355x_match_debug.h"
-
-extern std::atomic<int> mi_g_sinkhorn_log_partials;   // defined in sinkhorn.hip
-extern std::atomic<int> mi_g_sinkhorn_split;          // defined in sinkhorn_dots.hip
-extern std::atomic<int> mi_g_topk_select;             // defined in topk.hip
-extern std::atomic<int> mi_g_sinkhorn_persist;        // defined in sinkhorn_dots.hip
-extern std::atomic<int> mi_g_sinkhorn_stamps;
+#include "hooks.h"
 
 namespace {
-
-std::atomic<unsigned long long *> g_corner_clk{nullptr};   // mi_debug_clock_probe (development aid)
 
 constexpr int TW = 128;  // tile width: 32 threads x 4 pixels
 #ifndef MI_K1_POOLS
@@ -705,39 +696,21 @@ int launch_stream(MiSets image, int n, int h, int w, float *score, unsigned *til
 #endif
   const int resident = 256 * PER_CU;
   const int grid = total < resident ? (int)total : resident;
-  // dynamic schedule only when a workgroup owns more than two tiles
+  // dynamic schedule only when a workgroup owns more than two tiles.  The counter block is cleared HERE, on the
+  // stream, ahead of every launch that draws from it: a block left dirty by a launch that died between its first
+  // draw and its last workgroup's reset would otherwise start this launch's tickets mid-range (tiles skipped, score
+  // rows never written, rc 0).  The kernel still leaves the block zero; nothing relies on that any more.
   unsigned *ctr = total > 2LL * grid ? tile_ctr : nullptr;
+  if (ctr && hipMemsetAsync(ctr, 0, MI_TILE_COUNTER_BYTES, s) != hipSuccess) {
+    const int e = mi_launch_status();
+    return e != MI_OK ? e : MI_E_PARAM;
+  }
   hipLaunchKernelGGL((corner_stream_kernel<BS, R, std::is_same<PIX, uint8_t>::value>), dim3(grid), dim3(256), 0,
-                     s, image, score, h, w, tiles_x, tiles_y, (int)total, ctr, g_corner_clk.load(std::memory_order_relaxed));
+                     s, image, score, h, w, tiles_x, tiles_y, (int)total, ctr, MI_HOOK(corner_clk, (unsigned long long *)nullptr));
   return mi_launch_status();
 }
 
-std::atomic<int> g_corner_impl{0};   // 0 = streaming (LDS-DMA) kernel, 1 = register-staged tile kernel
-std::atomic<int> g_corner_rows{4};   // rows per thread of the streaming kernel (tile height = 8 * rows)
-std::atomic<int> g_corner_rows_u8_default{1};   // 1 until mi_debug_set(2, .) is called: the uint8 kernel then uses 5 rows
-
 }  // namespace
-
-// Development/test hook (include/mi355x_match_debug.h, not part of the product ABI): select between equivalent
-// kernel implementations (results identical).  Process-wide atomics: a value set here is seen by every later call.
-// development aid (include/mi355x_match_debug.h): every workgroup of the streaming corner kernel writes
-// {s_memtime, 100 MHz clock} at entry and exit into `buffer` (4 x uint64 per workgroup of the persistent grid,
-// <= 2048 workgroups; device memory); NULL = off
-extern "C" int mi_debug_clock_probe(void *buffer) {
-  g_corner_clk = reinterpret_cast<unsigned long long *>(buffer);
-  return MI_OK;
-}
-
-extern "C" int mi_debug_set(int key, int value) {
-  if (key == 1) { g_corner_impl = value; return MI_OK; }
-  if (key == 4) { mi_g_sinkhorn_log_partials = value; return MI_OK; }
-  if (key == 6) { mi_g_sinkhorn_split = value; return MI_OK; }
-  if (key == 9) { mi_g_topk_select = value; return MI_OK; }
-  if (key == 7) { mi_g_sinkhorn_persist = value; return MI_OK; }
-  if (key == 8) { mi_g_sinkhorn_stamps = value; return MI_OK; }
-  if (key == 2 && (value == 4 || value == 5 || value == 8)) { g_corner_rows = value; g_corner_rows_u8_default = 0; return MI_OK; }
-  return MI_E_PARAM;
-}
 
 // The shared launcher: `images` names one batch or two (MiSets), n = the total number of images.
 int mi_corner_response_sets(MiSets images, int pix_u8, int n, int h, int w, int block_size, float *score,
@@ -747,7 +720,7 @@ int mi_corner_response_sets(MiSets images, int pix_u8, int n, int h, int w, int 
   if (block_size <= 0 || (block_size & 1) == 0) return MI_E_PARAM;
   hipStream_t s = (hipStream_t)stream;
   const uintptr_t bases = (uintptr_t)images.a | (uintptr_t)images.b;
-  const int rows = g_corner_rows.load(std::memory_order_relaxed);
+  const int rows = MI_HOOK(corner_rows, 4);            // rows per thread of the streaming kernel (tile height = 8 * rows)
   const size_t total = (size_t)n * h * w;
   const size_t blocks = (total + 255) / 256;
   if (pix_u8) {
@@ -757,7 +730,7 @@ int mi_corner_response_sets(MiSets images, int pix_u8, int n, int h, int w, int 
       // 5 rows per thread unless the test hook asks otherwise (measured per 448 images: 217 us at 5 rows, 221 at 8,
       // 259 at 4 -- the fp32 kernel's best -- with 6 workgroups per CU)
       if (rows == 8) return launch_stream<3, 8, uint8_t>(images, n, h, w, score, tile_ctr, s);
-      if (rows == 4 && g_corner_rows_u8_default.load(std::memory_order_relaxed) == 0) return launch_stream<3, 4, uint8_t>(images, n, h, w, score, tile_ctr, s);
+      if (rows == 4 && MI_HOOK(corner_rows_u8_default, 1) == 0) return launch_stream<3, 4, uint8_t>(images, n, h, w, score, tile_ctr, s);
       return launch_stream<3, 5, uint8_t>(images, n, h, w, score, tile_ctr, s);
     }
     if (blocks > 0x7fffffffULL) return MI_E_SHAPE;
@@ -767,7 +740,7 @@ int mi_corner_response_sets(MiSets images, int pix_u8, int n, int h, int w, int 
   }
   const bool aligned = (w % 4 == 0) && ((bases | (uintptr_t)score) % 16 == 0);
   if (aligned && h >= 4 && w >= 8) {
-    if (block_size == 3 && g_corner_impl.load(std::memory_order_relaxed) == 0) {
+    if (block_size == 3 && MI_HOOK(corner_impl, 0) == 0) {   // 0 = streaming (LDS-DMA) kernel, 1 = register-staged tile kernel
       if (rows == 4) return launch_stream<3, 4, float>(images, n, h, w, score, tile_ctr, s);
       if (rows == 5) return launch_stream<3, 5, float>(images, n, h, w, score, tile_ctr, s);
       return launch_stream<3, 8, float>(images, n, h, w, score, tile_ctr, s);
@@ -796,10 +769,10 @@ extern "C" int mi_corner_response_u8(const uint8_t *image, int n, int h, int w, 
   return mi_corner_response_sets(mi_one_set(image, n), 1, n, h, w, block_size, score, nullptr, stream);
 }
 
-// The same two calls with a tile counter: 8 bytes of device memory (two uint32, 4-byte aligned) that are ZERO when the
-// call is issued and that the kernel leaves zero, owned by one stream at a time.  With it, large batches hand the
-// tiles of the streaming kernel out dynamically (see the schedule note at corner_stream_kernel): same scores, the
-// launch ends when the work does instead of when the youngest workgroup's fixed share does.
+// The same two calls with a tile counter: MI_TILE_COUNTER_BYTES of device memory (4-byte aligned, any content: cleared
+// by a memset node ahead of the kernel), owned by one stream at a time.  With it, large batches hand the tiles of the
+// streaming kernel out dynamically (see the schedule note at corner_stream_kernel): same scores, the launch ends
+// when the work does instead of when the youngest workgroup's fixed share does.
 extern "C" int mi_corner_response_balanced(const void *image, int pixels_are_u8, int n, int h, int w, int block_size,
                                            float *score, uint32_t *tile_counter, mi_stream_t stream) {
   MI_ENTER();

@@ -1,0 +1,28 @@
+// Kernel-variant selectors and development probes.
+//
+// Product build (libmi355x_match.so): every selector is a compile-time constant -- the library has no process-wide
+// switch that could change which kernel runs -- and the probes are off.
+// -DMI_DEBUG_HOOKS (libmi355x_match_debug.so, loaded by tests/ and tools/ only): the same selectors are process-wide
+// atomics set through include/mi355x_match_debug.h (mi_debug_set and friends, defined in hooks.hip).
+#pragma once
+
+#ifdef MI_DEBUG_HOOKS
+#include <atomic>
+struct MiHooks {
+  std::atomic<int> corner_impl{0};             // key 1: 0 = streaming (LDS-DMA) corner kernel, 1 = register-staged tile kernel
+  std::atomic<int> corner_rows{4};             // key 2: rows per thread of the streaming kernel (4, 5, 8)
+  std::atomic<int> corner_rows_u8_default{1};  // 1 until key 2 is set: the uint8 kernel then uses its own best (5 rows)
+  std::atomic<int> sinkhorn_log_partials{0};   // key 4: band kernel form of mi_sinkhorn
+  std::atomic<int> sinkhorn_split{2};          // key 6: batch parts of mi_sinkhorn_dots on separate streams
+  std::atomic<int> sinkhorn_persist{1};        // key 7: single-launch form for <= 8 pairs
+  std::atomic<int> sinkhorn_stamps{0};         // key 8: phase time stamps of the single-launch kernel
+  std::atomic<int> topk_select{1};             // key 9: radix select + sort k instead of sorting every candidate
+  std::atomic<int> topk_split{-1};             // key 10: workgroups per image of the top-k histogram pass (-1 = automatic)
+  std::atomic<unsigned long long *> corner_clk{nullptr};   // mi_debug_clock_probe
+  std::atomic<unsigned long long *> topk_prof{nullptr};    // mi_debug_topk_stamps
+};
+extern MiHooks mi_hooks;   // hooks.hip
+#define MI_HOOK(field, product_value) (mi_hooks.field.load(std::memory_order_relaxed))
+#else
+#define MI_HOOK(field, product_value) (product_value)
+#endif

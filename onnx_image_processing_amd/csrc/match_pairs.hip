@@ -89,6 +89,7 @@ int check_params(const mi_match_params *p) {
   if (p->block_size <= 0 || p->block_size % 2 == 0 || p->nms_radius < 0 || p->max_keypoints <= 0) return MI_E_PARAM;
   if (p->num_pairs <= 0 || p->num_pairs % 64 != 0 || p->num_pairs > 1024) return MI_E_PARAM;
   if (p->sinkhorn_iterations <= 0 || !(p->epsilon >= MI_DOTS_MIN_EPSILON) || p->max_matches <= 0) return MI_E_PARAM;
+  if ((p->flags & ~MI_SOLVER_MULTI_LAUNCH) != 0) return MI_E_PARAM;
   return MI_OK;
 }
 
@@ -148,8 +149,7 @@ int match_pairs_impl(const PIX *image1, const PIX *image2, int batch, int h, int
                                 params->bad_plan ? L.status : nullptr, stream)) != MI_OK)
       return e;
   } else {
-    // one image side per launch; K1 hands its tiles out dynamically (counter cleared here, left zero by the kernel)
-    if (hipMemsetAsync(L.tile_ctr, 0, MI_TILE_COUNTER_BYTES, (hipStream_t)stream) != hipSuccess) return mi_launch_status() ? mi_launch_status() : MI_E_PARAM;
+    // one image side per launch; K1 hands its tiles out dynamically (mi_corner_response_balanced clears the counter block)
     const PIX *images[2] = {image1, image2};
     float *kpts[2] = {keypoints1, keypoints2};
     uint32_t *bits[2] = {L.bits1, L.bits2};
@@ -169,19 +169,20 @@ int match_pairs_impl(const PIX *image1, const PIX *image2, int batch, int h, int
   // matching/sinkhorn.py:79-208 in the packed (uint16 dot product) form; P is never written
   // (the cost kernel also clears the hand-off area of the single-launch Sinkhorn: one graph node less per call)
   void *handoff = nullptr;
-  const size_t handoff_bytes = mi_sinkhorn_dots_handoff_region(L.sk_ws, batch, k, k, &handoff);
+  const size_t handoff_bytes = mi_sinkhorn_dots_handoff_region(L.sk_ws, batch, k, k, params->flags, &handoff);
   if ((e = mi_cost_dots_bits_zeroing(L.bits1, L.bits2, batch, k, k, pbits, params->normalize_descriptors, L.dots, L.pitch,
                                      L.row_info, L.col_info, handoff, handoff_bytes, stream)) != MI_OK)
     return e;
   const double sqnorm_bound = params->normalize_descriptors ? 1.0 : (double)pbits;
   if ((e = mi_sinkhorn_dots_impl(L.dots, L.row_info, L.col_info, batch, k, k, L.pitch, params->epsilon,
                                  params->unused_score, sqnorm_bound, params->sinkhorn_iterations, L.u, L.v, nullptr, L.sk_ws,
-                                 L.sk_bytes, handoff_bytes > 0, stream)) != MI_OK)
+                                 L.sk_bytes, params->flags, handoff_bytes > 0, stream)) != MI_OK)
     return e;
   // matching/match_extraction.py:46-184 straight from the duals
   return mi_mnn_from_duals_dots(L.dots, L.row_info, L.col_info, batch, k, k, L.pitch, params->epsilon, L.u, L.v,
                                 keypoints1, keypoints2, params->max_matches, params->match_threshold, L.mnn_ws,
-                                L.mnn_bytes, matched1, matched2, match_scores, match_valid, match_ij, stream);
+                                L.mnn_bytes, mi_sinkhorn_dots_status_word(L.sk_ws, batch, k, k), matched1, matched2,
+                                match_scores, match_valid, match_ij, stream);
 }
 }  // namespace
 

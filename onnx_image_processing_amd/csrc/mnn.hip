@@ -69,9 +69,12 @@ __global__ __launch_bounds__(MX_THREADS) void mnn_select_kernel(
     int n, int m, const uint64_t *__restrict__ row_best, const uint64_t *__restrict__ col_best,
     const uint64_t *__restrict__ col_part, int nb,
     const float *__restrict__ kpts1, const float *__restrict__ kpts2, int max_matches, float threshold,
+    const uint32_t *__restrict__ solver_status,
     float *__restrict__ mk1, float *__restrict__ mk2, float *__restrict__ scores,
     uint8_t *__restrict__ valid, int32_t *__restrict__ match_ij) {
   __shared__ uint64_t keys[MX_MAX];
+  // the Sinkhorn call that produced the duals timed out (mi_sinkhorn_dots_status_word): no match of this call is valid
+  const bool dead = solver_status && *solver_status != 0u;
   __shared__ uint64_t cmerged[1024];
   const int t = threadIdx.x, b = blockIdx.x;
   const uint64_t *rb = row_best + (size_t)b * n;
@@ -101,11 +104,15 @@ __global__ __launch_bounds__(MX_THREADS) void mnn_select_kernel(
   for (int i = t; i < npad; i += MX_THREADS) {
     uint64_t key = 0ull;
     if (i < n) {
+      // r == 0: the row has no winner (every probability NaN -- poisoned duals, or NaN in a caller's P): no match,
+      // and no column to look up
       const uint64_t r = rb[i];
-      const uint32_t j = 0xFFFFFFFFu - (uint32_t)(r & 0xFFFFFFFFull);
+      const uint32_t jw = 0xFFFFFFFFu - (uint32_t)(r & 0xFFFFFFFFull);
+      const bool has = r != 0ull && jw < (uint32_t)m;
+      const uint32_t j = has ? jw : 0u;
       const float val = __uint_as_float((uint32_t)(r >> 32));
       const uint32_t ib = 0xFFFFFFFFu - (uint32_t)(cb[j] & 0xFFFFFFFFull);
-      const bool ok = (ib == (uint32_t)i) && (val >= threshold);
+      const bool ok = has && !dead && (ib == (uint32_t)i) && (val >= threshold);
       // high word: 0 for non-matches, bits(score)+1 for matches (keeps score 0.0 above them);
       // low word: inverted row index -> lower row first among equal scores.  +1 so that a real
       // row never collides with the all-zero padding key.
@@ -138,7 +145,8 @@ __global__ __launch_bounds__(MX_THREADS) void mnn_select_kernel(
       matched = hi != 0u;
       sc = matched ? __uint_as_float(hi - 1u) : -1.0f;
     }
-    const uint32_t j = 0xFFFFFFFFu - (uint32_t)(rb[i] & 0xFFFFFFFFull);
+    const uint32_t jw = 0xFFFFFFFFu - (uint32_t)(rb[i] & 0xFFFFFFFFull);
+    const uint32_t j = jw < (uint32_t)m ? jw : 0u;
     const size_t o = (size_t)b * max_matches + s;
     mk1[o * 2 + 0] = kpts1[((size_t)b * n + i) * 2 + 0];
     mk1[o * 2 + 1] = kpts1[((size_t)b * n + i) * 2 + 1];
@@ -357,8 +365,8 @@ DualsWork duals_carve(void *workspace, int batch, int n, int m) {
 template <typename SRC>
 int mnn_from_source(SRC src, const float2 *col_info, int batch, int n, int m, const float *u, const float *v,
                     const float *kpts1, const float *kpts2, int max_matches, float threshold, void *workspace,
-                    size_t workspace_bytes, float *mk1, float *mk2, float *scores, uint8_t *valid, int32_t *match_ij,
-                    hipStream_t s) {
+                    size_t workspace_bytes, const uint32_t *solver_status, float *mk1, float *mk2, float *scores,
+                    uint8_t *valid, int32_t *match_ij, hipStream_t s) {
   if (!u || !v || !kpts1 || !kpts2 || !workspace || !mk1 || !mk2 || !scores || !valid) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
   if (n > MX_MAX || m > 1024 || max_matches <= 0) return MI_E_PARAM;
@@ -376,14 +384,15 @@ int mnn_from_source(SRC src, const float2 *col_info, int batch, int n, int m, co
   if (batch <= 32) {
     // few pairs: the select kernel merges the bands' column winners itself (one launch less on the latency path)
     hipLaunchKernelGGL(mnn_select_kernel, dim3(batch), dim3(MX_THREADS), 0, s, n, m, w.row_best, w.col_best,
-                       (const uint64_t *)w.col_part, nb, kpts1, kpts2, max_matches, threshold, mk1, mk2, scores, valid,
-                       match_ij);
+                       (const uint64_t *)w.col_part, nb, kpts1, kpts2, max_matches, threshold, solver_status, mk1, mk2,
+                       scores, valid, match_ij);
     return mi_launch_status();
   }
   hipLaunchKernelGGL(mnn_colmerge_kernel, dim3(ceil_div(m, 256), batch), dim3(256), 0, s, w.col_part, nb, m,
                      w.col_best);
   hipLaunchKernelGGL(mnn_select_kernel, dim3(batch), dim3(MX_THREADS), 0, s, n, m, w.row_best, w.col_best,
-                     (const uint64_t *)nullptr, 0, kpts1, kpts2, max_matches, threshold, mk1, mk2, scores, valid, match_ij);
+                     (const uint64_t *)nullptr, 0, kpts1, kpts2, max_matches, threshold, solver_status, mk1, mk2, scores,
+                     valid, match_ij);
   return mi_launch_status();
 }
 
@@ -405,14 +414,15 @@ extern "C" int mi_mnn_from_duals(const float *z, int batch, int n, int m, int pi
   src.z = z;
   src.pitch = pitch;
   return mnn_from_source(src, nullptr, batch, n, m, u, v, kpts1, kpts2, max_matches, threshold, workspace,
-                         workspace_bytes, mk1, mk2, scores, valid, match_ij, (hipStream_t)stream);
+                         workspace_bytes, nullptr, mk1, mk2, scores, valid, match_ij, (hipStream_t)stream);
 }
 
 extern "C" int mi_mnn_from_duals_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch,
                                       int n, int m, int pitch, double epsilon, const float *u, const float *v,
                                       const float *kpts1, const float *kpts2, int max_matches, float threshold,
-                                      void *workspace, size_t workspace_bytes, float *mk1, float *mk2,
-                                      float *scores, uint8_t *valid, int32_t *match_ij, mi_stream_t stream) {
+                                      void *workspace, size_t workspace_bytes, const uint32_t *solver_status,
+                                      float *mk1, float *mk2, float *scores, uint8_t *valid, int32_t *match_ij,
+                                      mi_stream_t stream) {
   MI_ENTER();
   if (!dots || !row_info || !col_info) return MI_E_NULL;
   if (pitch < m || pitch % 8 != 0 || ((uintptr_t)dots % 16) != 0) return MI_E_ALIGN;
@@ -424,8 +434,9 @@ extern "C" int mi_mnn_from_duals_dots(const uint16_t *dots, const float *row_inf
   src.col_info = reinterpret_cast<const float2 *>(col_info);
   src.neg_inv_eps = (float)(-1.0 / epsilon);
   src.ri = make_float2(0.f, 0.f);
+  if (solver_status && ((uintptr_t)solver_status % 4) != 0) return MI_E_ALIGN;
   return mnn_from_source(src, src.col_info, batch, n, m, u, v, kpts1, kpts2, max_matches, threshold, workspace,
-                         workspace_bytes, mk1, mk2, scores, valid, match_ij, (hipStream_t)stream);
+                         workspace_bytes, solver_status, mk1, mk2, scores, valid, match_ij, (hipStream_t)stream);
 }
 
 extern "C" int mi_mnn_extract(const float *p, int batch, int n, int m, const float *kpts1, const float *kpts2,
@@ -440,7 +451,8 @@ extern "C" int mi_mnn_extract(const float *p, int batch, int n, int m, const flo
   hipLaunchKernelGGL(mnn_row_kernel, dim3(ceil_div(n, 4), batch), dim3(256), 0, s, p, n, m, row_best);
   hipLaunchKernelGGL(mnn_col_kernel, dim3(ceil_div(m, 64), batch), dim3(256), 0, s, p, n, m, col_best);
   hipLaunchKernelGGL(mnn_select_kernel, dim3(batch), dim3(MX_THREADS), 0, s, n, m, row_best, col_best,
-                     (const uint64_t *)nullptr, 0, kpts1, kpts2, max_matches, threshold, mk1, mk2, scores, valid, match_ij);
+                     (const uint64_t *)nullptr, 0, kpts1, kpts2, max_matches, threshold, (const uint32_t *)nullptr, mk1,
+                     mk2, scores, valid, match_ij);
   return mi_launch_status();
 }
 
@@ -549,7 +561,7 @@ extern "C" int mi_core_maxima(const float *p, int batch, int n, int m, float *ro
   return mi_launch_status();
 }
 
-extern "C" int mi_abi_version(void) { return 1; }
+extern "C" int mi_abi_version(void) { return 2; }
 
 extern "C" const char *mi_error_string(int code) {
   switch (code) {

@@ -15,11 +15,10 @@
 
 #include <math.h>
 
-#include <atomic>
+#include "hooks.h"
 
 // test hook (mi_debug_set key 4, include/mi355x_match_debug.h): 0 = probability-form band kernel, lean instruction stream (default);
 // 2 = the first probability-form kernel; 1 = log-domain (max, sum) band partials, two exps per element
-std::atomic<int> mi_g_sinkhorn_log_partials{0};
 
 namespace {
 
@@ -737,7 +736,7 @@ void launch_fused(const float *z, int batch, int n, int m, int pitch, float dust
   constexpr int NC = 256 * E4;
   for (int it = 0; it < iterations; ++it) {
     const int vz = it == 0 ? 1 : 0;
-    const int band_form = mi_g_sinkhorn_log_partials.load(std::memory_order_relaxed);
+    const int band_form = MI_HOOK(sinkhorn_log_partials, 0);
     if (band_form == 0) {
       float *pf = reinterpret_cast<float *>(part);
       hipLaunchKernelGGL((sk_band_p2_kernel<E4, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, z, n, m, pitch,

@@ -17,13 +17,12 @@
 
 #include <atomic>
 
-// test hook (mi_debug_set key 7): 1 = batches of <= SKP_MAX_BATCH pairs (n, m <= 512) run the single-launch form
-// (default), 0 = always the multi-launch form.  Same duals bit for bit.
-std::atomic<int> mi_g_sinkhorn_persist{1};
-std::atomic<int> mi_g_sinkhorn_stamps{0};      // key 8: 1 = the single-launch kernel records phase time stamps
-// test hook (mi_debug_set key 6, include/mi355x_match_debug.h): number of batch parts run on separate
-// streams (1 = one stream).  Whole bench step: 1.88 / 1.82 / 1.92 ms with 1 / 2 / 3 parts of 256 pairs.
-std::atomic<int> mi_g_sinkhorn_split{2};
+#include "hooks.h"
+// test hooks (include/mi355x_match_debug.h, debug library only; csrc/hooks.h):
+//   key 7: 1 = batches of <= SKP_MAX_BATCH pairs (n, m <= 512) run the single-launch form (default), 0 = always the
+//          multi-launch form.  Same duals bit for bit.   key 8: 1 = the single-launch kernel records phase time stamps.
+//   key 6: number of batch parts run on separate streams (1 = one stream).  Whole bench step: 1.88 / 1.82 / 1.92 ms
+//          with 1 / 2 / 3 parts of 256 pairs.
 
 namespace {
 
@@ -342,9 +341,11 @@ __global__ __launch_bounds__(256) void sk_vcombine_dots_kernel(const float *__re
 // first-iteration column data: tp = column scale, wp = nie * squared norm (v = 0); padding 0 / -inf
 __global__ __launch_bounds__(256) void sk_dots_init_kernel(const float2 *__restrict__ col_info, int m, int cpitch,
                                                            float neg_inv_eps, float *__restrict__ wp,
-                                                           float *__restrict__ tp, float *__restrict__ aux) {
+                                                           float *__restrict__ tp, float *__restrict__ aux,
+                                                           unsigned *__restrict__ status) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;      // the grid covers cpitch exactly (a multiple of 256)
+  if (b == 0 && j == 0) *status = 0u;                // the multi-launch form cannot time out: the call's status word is 0
   const float2 c = (j < m) ? col_info[(size_t)b * m + j] : make_float2(0.0f, 0.0f);
   const float w = (j < m) ? c.y * neg_inv_eps : -INFINITY;
   tp[(size_t)b * cpitch + j] = c.x;
@@ -389,8 +390,10 @@ __global__ __launch_bounds__(256) void sk_exp_dots_kernel(const uint16_t *__rest
 // overwritten.  The arithmetic (operation order included) is that of sk_band_dots_kernel / sk_vcombine_dots_kernel,
 // so the duals equal the multi-launch form's bit for bit (asserted in tests/test_gpu_parity.py).
 // Requirements: n, m <= 512 and all batch * nb workgroups resident at once (batch <= SKP_MAX_BATCH: 128 workgroups
-// of 512 threads on 256 CUs); granule tags are zeroed by a memset node ahead of the launch; every spin is bounded
-// (SKP_SPIN_LIMIT polls, then the `fail` word is set and the workgroup leaves: garbage, never a hang).
+// of 512 threads; the host checks that the grid fits the device, persist_capacity); granule tags are zeroed by a memset
+// node ahead of the launch; every spin is bounded (SKP_SPIN_LIMIT polls of >= ~2 us each: about a second) and a
+// time-out is LOUD: the call's status word is set and the workgroup writes NaN into its pair's duals before it leaves
+// (P, scores and `valid` downstream are then visibly dead; mi_mnn_from_duals_dots also reads the status word).
 constexpr int SKP_MAX_BATCH = 8;
 constexpr int SKP_COLS = 520;                    // granules per band row: columns 0..m (<= 513), padded
 constexpr unsigned SKP_SPIN_LIMIT = 1u << 19;
@@ -500,6 +503,17 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
     for (int w = 1; w < NW; ++w) sum += s_part[1][w][0];
     sum += expf((dust + vd) - mx);
     un = log_m - (logf(sum) + mx);
+  };
+  // time-out exit: NaN into every dual of this pair this workgroup can name (its rows' u, every v, the dustbin u) -- all
+  // bands of the pair end up here once one of them has stopped publishing, and NaN from any of them is final
+  auto poison = [&]() {
+    const float qnan = __builtin_nanf("");
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+      if (lane == 0 && live[r]) u[(size_t)b * (n + 1) + row0 + r] = qnan;
+    if (own0) v[(size_t)b * (m + 1) + t] = qnan;
+    if (own1) v[(size_t)b * (m + 1) + m] = qnan;
+    if (t == 0) u[(size_t)b * (n + 1) + n] = qnan;
   };
   reduce_wmax();
 
@@ -657,7 +671,7 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
     SKP_STAMP(2);
     if (it == iterations - 1) {
       lds_barrier();
-      if (s_fail) return;
+      if (s_fail) { poison(); return; }
       if (band == 0) {
         if (own0) v[(size_t)b * (m + 1) + t] = v0;
         if (own1) v[(size_t)b * (m + 1) + m] = v1;
@@ -666,7 +680,7 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
       return;
     }
     reduce_wmax();                                             // (its barrier publishes s_w / s_vd / s_fail)
-    if (s_fail) return;                                        // uniform: every thread reads it after a barrier
+    if (s_fail) { poison(); return; }                          // uniform: every thread reads it after a barrier
     SKP_STAMP(3);
   }
 #undef SKP_STAMP
@@ -717,17 +731,17 @@ ForkJoin *fork_join_for(hipStream_t s) {
 template <int E8, int RW, int NW, bool FAST>
 int launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int batch, int n, int m, int pitch,
                  ZParams zp, int iterations, float *u, float *v, float *part, float *wp, float *tp, float *aux,
-                 float log_m, float log_n, hipStream_t s) {
+                 float log_m, float log_n, unsigned *statusw, hipStream_t s) {
   const int nb = ceil_div(n, NW * RW);
   constexpr int CP = 512 * E8;    // padded column count of wp / tp
   hipLaunchKernelGGL(sk_dots_init_kernel, dim3(CP / 256, batch), dim3(256), 0, s, ci, m, CP, zp.neg_inv_eps, wp, tp,
-                     aux);
+                     aux, statusw);
   // An iteration is a big row kernel and a tiny column kernel that depend on each other, so between them
   // the GPU drains and refills (about 5 us per iteration).  With enough pairs the batch is cut into parts
   // on separate streams: while one part is in its column kernel / launch gap another part's row kernel
   // keeps the CUs busy.  The parts are independent problems, so results do not change.
   MI_CHECK_LAUNCH();
-  int parts = mi_g_sinkhorn_split.load(std::memory_order_relaxed);
+  int parts = MI_HOOK(sinkhorn_split, 2);
   if (parts > SK_MAX_PARTS) parts = SK_MAX_PARTS;
   if (parts < 1 || batch < 32 * parts) parts = 1;
   ForkJoin *fj = parts > 1 ? fork_join_for(s) : nullptr;
@@ -776,8 +790,27 @@ size_t dots_partials_bytes(int batch, int n, int m, int band) {
 }
 int dots_cpitch(int m) { return m <= 512 ? 512 : 1024; }
 
-// single-launch form: two granule buffers of nb band rows per pair, then the fail word (16 bytes reserved)
+// single-launch form: two granule buffers of nb band rows per pair (then the status word, which every shape has)
 bool persist_shape(int batch, int n, int m) { return batch <= SKP_MAX_BATCH && n <= 512 && m <= 512; }
+int persist_grid(int batch, int n) { return 8 * ceil_div(n, 32) * ceil_div(batch, 8); }
+// Workgroups of the single-launch kernel the current device can hold at once: occupancy per compute unit x compute
+// units, the smaller of the two row-pass variants, asked once per device (0 when the query fails: multi-launch form).
+// A CU-masked or partitioned device reports what it really has, which is the point.
+int persist_capacity() {
+  static std::atomic<int> cache[64];
+  int device = -1;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) { (void)hipGetLastError(); return 0; }
+  int cap = cache[device].load(std::memory_order_relaxed);
+  if (cap != 0) return cap > 0 ? cap : 0;
+  int cus = 0, a = 0, c = 0;
+  const bool ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
+                  hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, sk_persist_kernel<true, 4>, 512, 0) == hipSuccess &&
+                  hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, sk_persist_kernel<false, 4>, 512, 0) == hipSuccess;
+  if (!ok) (void)hipGetLastError();
+  cap = ok ? (a < c ? a : c) * cus : 0;
+  cache[device].store(cap > 0 ? cap : -1, std::memory_order_relaxed);
+  return cap;
+}
 // Rows per wave of the single-launch kernel.  4 = the multi-launch kernel's banding, which its column sums must share
 // to come out bit-identical (a band's column sum is an fma chain over its rows: 16-row bands -- twice the workgroups,
 // half the row pass -- were measured 0.5 us per iteration faster but round differently).
@@ -790,13 +823,34 @@ size_t dots_base_bytes(int batch, int n, int m) {
                    (2 * (size_t)batch * dots_cpitch(m) + (size_t)batch * SKD_AUX) * sizeof(float);
   return (b + 15) & ~(size_t)15;
 }
+// workspace: [multi-launch arrays | granules (single-launch shapes only) | status word, 16 bytes | stamps (ditto)]
+size_t dots_status_offset(int batch, int n, int m) {
+  return dots_base_bytes(batch, n, m) + (persist_shape(batch, n, m) ? persist_granule_bytes(batch, n) : 0);
+}
 
 }  // namespace
+
+// The form mi_sinkhorn_dots takes: a pure function of the extents, the caller's flags and what the device can hold
+// (mi_debug_sinkhorn_dots_form of the debug library exposes it to the CPU tests).
+int mi_sinkhorn_dots_form_host(int batch, int n, int m, int flags, int blocks_per_cu, int cus) {
+  if (!persist_shape(batch, n, m) || (flags & MI_SOLVER_MULTI_LAUNCH) != 0) return 0;
+  if (MI_HOOK(sinkhorn_persist, 1) == 0) return 0;
+  return (long long)blocks_per_cu * cus >= persist_grid(batch, n) ? 1 : 0;
+}
+static bool use_single_launch(int batch, int n, int m, int flags) {
+  if (mi_sinkhorn_dots_form_host(batch, n, m, flags, 1, 1 << 20) == 0) return false;      // shape / flags / hook say no
+  return mi_sinkhorn_dots_form_host(batch, n, m, flags, persist_capacity(), 1) != 0;
+}
 
 extern "C" size_t mi_sinkhorn_dots_workspace_bytes(int batch, int n, int m) {
   const int band = dots_rows_per_band(m);
   if (batch <= 0 || n <= 0 || m <= 0 || band == 0) return 0;
-  return dots_base_bytes(batch, n, m) + (persist_shape(batch, n, m) ? persist_granule_bytes(batch, n) + 16 + SKP_PROF_BYTES : 0);
+  return dots_status_offset(batch, n, m) + 16 + (persist_shape(batch, n, m) ? SKP_PROF_BYTES : 0);
+}
+
+extern "C" const uint32_t *mi_sinkhorn_dots_status_word(const void *workspace, int batch, int n, int m) {
+  if (!workspace || mi_sinkhorn_dots_workspace_bytes(batch, n, m) == 0) return nullptr;
+  return reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(workspace) + dots_status_offset(batch, n, m));
 }
 
 // see include/mi355x_match.h: a caller that destroys a stream it passed to mi_sinkhorn_dots / mi_match_pairs
@@ -808,8 +862,8 @@ extern "C" int mi_release_stream_resources(mi_stream_t stream) {
   return MI_OK;
 }
 
-size_t mi_sinkhorn_dots_handoff_region(void *workspace, int batch, int n, int m, void **region) {
-  if (!persist_shape(batch, n, m) || mi_g_sinkhorn_persist.load(std::memory_order_relaxed) == 0) return 0;
+size_t mi_sinkhorn_dots_handoff_region(void *workspace, int batch, int n, int m, int flags, void **region) {
+  if (!use_single_launch(batch, n, m, flags)) return 0;
   *region = reinterpret_cast<char *>(workspace) + dots_base_bytes(batch, n, m);
   return persist_granule_bytes(batch, n) + 16;
 }
@@ -817,19 +871,21 @@ size_t mi_sinkhorn_dots_handoff_region(void *workspace, int batch, int n, int m,
 extern "C" int mi_sinkhorn_dots(const uint16_t *dots, const float *row_info, const float *col_info, int batch,
                                 int n, int m, int pitch, double epsilon, double unused_score, double sqnorm_bound,
                                 int iterations, float *u, float *v, float *p, void *workspace, size_t workspace_bytes,
-                                mi_stream_t stream) {
+                                int flags, mi_stream_t stream) {
   MI_ENTER();
   return mi_sinkhorn_dots_impl(dots, row_info, col_info, batch, n, m, pitch, epsilon, unused_score, sqnorm_bound,
-                               iterations, u, v, p, workspace, workspace_bytes, 0, stream);
+                               iterations, u, v, p, workspace, workspace_bytes, flags, 0, stream);
 }
 
 int mi_sinkhorn_dots_impl(const uint16_t *dots, const float *row_info, const float *col_info, int batch, int n, int m,
                           int pitch, double epsilon, double unused_score, double sqnorm_bound, int iterations, float *u,
-                          float *v, float *p, void *workspace, size_t workspace_bytes, int prezeroed, mi_stream_t stream) {
+                          float *v, float *p, void *workspace, size_t workspace_bytes, int flags, int prezeroed,
+                          mi_stream_t stream) {
   if (!dots || !row_info || !col_info || !u || !v || !workspace) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
   if (pitch < m || pitch % 8 != 0 || ((uintptr_t)dots % 16) != 0 || ((uintptr_t)workspace % 16) != 0) return MI_E_ALIGN;
   if (iterations <= 0 || !(epsilon >= MI_DOTS_MIN_EPSILON)) return MI_E_PARAM;   // below it: the fp32-Z form (clamped cost)
+  if ((flags & ~MI_SOLVER_MULTI_LAUNCH) != 0) return MI_E_PARAM;
   const size_t need = mi_sinkhorn_dots_workspace_bytes(batch, n, m);
   if (need == 0) return MI_E_PARAM;                 // m > 1024: use the fp32 form
   if (workspace_bytes < need) return MI_E_CAPACITY;
@@ -849,8 +905,9 @@ int mi_sinkhorn_dots_impl(const uint16_t *dots, const float *row_info, const flo
   zp.g_bound = (float)(2.0 / epsilon * sqnorm_bound);
   zp.d_bound = (float)(sqnorm_bound / epsilon);
   const bool fast = sqnorm_bound > 0.0 && (double)zp.g_bound * 1.4426950408889634 < (double)SKD_FAST_LIMIT;
-  if (persist_shape(batch, n, m) && mi_g_sinkhorn_persist.load(std::memory_order_relaxed) != 0) {
-    // single-launch form: zero the granule tags and the fail word (one memset node), then one kernel
+  unsigned *statusw = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(workspace) + dots_status_offset(batch, n, m));
+  if (use_single_launch(batch, n, m, flags)) {
+    // single-launch form: zero the granule tags and the status word (one memset node), then one kernel
     char *gbase = reinterpret_cast<char *>(workspace) + dots_base_bytes(batch, n, m);
     const size_t gbytes = persist_granule_bytes(batch, n);
     if (!prezeroed) {
@@ -858,11 +915,11 @@ int mi_sinkhorn_dots_impl(const uint16_t *dots, const float *row_info, const flo
       if (me != hipSuccess) return (int)me;
     }
     unsigned long long *gran = reinterpret_cast<unsigned long long *>(gbase);
-    unsigned *failw = reinterpret_cast<unsigned *>(gbase + gbytes);
-    unsigned long long *prof = mi_g_sinkhorn_stamps.load(std::memory_order_relaxed) && iterations * 64 <= (int)SKP_PROF_BYTES
+    unsigned *failw = statusw;                       // == gbase + gbytes
+    unsigned long long *prof = MI_HOOK(sinkhorn_stamps, 0) && iterations * 64 <= (int)SKP_PROF_BYTES
                                    ? reinterpret_cast<unsigned long long *>(gbase + gbytes + 16) : nullptr;
     const int rw = persist_rows_per_wave(batch);
-    const dim3 grid(8 * ceil_div(n, 8 * rw) * ceil_div(batch, 8));
+    const dim3 grid(persist_grid(batch, n));
 #define SKP_LAUNCH(FAST, RW) hipLaunchKernelGGL((sk_persist_kernel<FAST, RW>), grid, dim3(512), 0, s, dots, n, m, pitch, ri, ci, zp, iterations, u, v, gran, failw, log_m, log_n, prof, batch)
     if (fast) { if (rw == 2) SKP_LAUNCH(true, 2); else SKP_LAUNCH(true, 4); }
     else { if (rw == 2) SKP_LAUNCH(false, 2); else SKP_LAUNCH(false, 4); }
@@ -873,7 +930,7 @@ int mi_sinkhorn_dots_impl(const uint16_t *dots, const float *row_info, const flo
                          zp, u, v, p);
     return mi_launch_status();
   }
-#define SKD_LAUNCH(E8, RW, FAST) launch_dots<E8, RW, 8, FAST>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, wp, tp, aux, log_m, log_n, s)
+#define SKD_LAUNCH(E8, RW, FAST) launch_dots<E8, RW, 8, FAST>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, wp, tp, aux, log_m, log_n, statusw, s)
   int e;
   if (m <= 512) e = fast ? SKD_LAUNCH(1, 4, true) : SKD_LAUNCH(1, 4, false);
   else e = fast ? SKD_LAUNCH(2, 2, true) : SKD_LAUNCH(2, 2, false);

@@ -12,11 +12,9 @@
 // for the k-th largest key straight from global memory, then sort only the k survivors.
 #include "common.h"
 
-#include <atomic>
-
-// test hook (mi_debug_set key 9, include/mi355x_match_debug.h): 1 = radix-select the k-th key and sort only
-// the k selected keys whenever n > k
-std::atomic<int> mi_g_topk_select{1};
+#include "hooks.h"
+// test hook (mi_debug_set key 9, debug library only): 1 = radix-select the k-th key and sort only the k selected keys
+// whenever n > k (default), 0 = always sort every candidate
 
 namespace {
 
@@ -448,10 +446,6 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
 #undef TK_STAMP
 }
 
-// development aid (mi_debug_set key 10 = address of a device buffer's low 32 bits is not expressible; instead the
-// stamps go to a buffer registered through mi_debug_topk_stamps)
-unsigned long long *g_topk_prof = nullptr;
-
 }  // namespace
 
 int mi_topk_keypoints_sets(const uint64_t *cand, const uint32_t *count, int segments, int segment_capacity, int n, int w,
@@ -461,16 +455,9 @@ int mi_topk_keypoints_sets(const uint64_t *cand, const uint32_t *count, int segm
   if (k <= 0 || k > TK_MAX) return MI_E_PARAM;
   if (segment_capacity <= 0) return MI_E_CAPACITY;
   hipLaunchKernelGGL(topk_kernel, dim3(n), dim3(TK_THREADS), 0, (hipStream_t)stream, cand, count, segments,
-                     (uint32_t)segment_capacity, w, k, keypoints, kscores, mi_g_topk_select.load(std::memory_order_relaxed),
-                     g_topk_prof);
+                     (uint32_t)segment_capacity, w, k, keypoints, kscores, MI_HOOK(topk_select, 1),
+                     MI_HOOK(topk_prof, (unsigned long long *)nullptr));
   return mi_launch_status();
-}
-
-// development aid (include/mi355x_match_debug.h): phase time stamps of workgroup 0 go to `buffer` (8 x u64, device
-// memory) on every later launch; NULL switches them off
-extern "C" int mi_debug_topk_stamps(void *buffer) {
-  g_topk_prof = reinterpret_cast<unsigned long long *>(buffer);
-  return MI_OK;
 }
 
 extern "C" int mi_topk_keypoints(const uint64_t *cand, const uint32_t *count, int segments,

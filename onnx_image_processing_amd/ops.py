@@ -37,17 +37,19 @@ def _images(image: torch.Tensor, what: str, keep_u8: bool = False) -> torch.Tens
 
 
 TILE_COUNTER_BYTES = 16640          # include/mi355x_match.h MI_TILE_COUNTER_BYTES
-_tile_counters: dict = {}
+
+# Sinkhorn solver flags handed to mi_sinkhorn_dots / mi_match_pairs (include/mi355x_match.h, "co-residency"):
+# 0 = MI_SOLVER_DEFAULT; MI_SOLVER_MULTI_LAUNCH for a process that shares its GPU with long-running foreign kernels.
+# A preference of this Python layer (the C library has no process-wide switch); results are identical either way.
+MI_SOLVER_DEFAULT, MI_SOLVER_MULTI_LAUNCH = 0, 1
+_solver_flags = MI_SOLVER_DEFAULT
 
 
-def _tile_counter(device: torch.device) -> torch.Tensor:
-    """K1's tile counter (mi_corner_response_balanced): MI_TILE_COUNTER_BYTES zero bytes per (device, stream); the kernel leaves them zero."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    ctr = _tile_counters.get(key)
-    if ctr is None:
-        ctr = torch.zeros(TILE_COUNTER_BYTES // 4, dtype=torch.int32, device=device)
-        _tile_counters[key] = ctr
-    return ctr
+def set_solver_flags(flags: int) -> None:
+    global _solver_flags
+    if flags not in (MI_SOLVER_DEFAULT, MI_SOLVER_MULTI_LAUNCH):
+        raise ValueError(f"solver flags must be MI_SOLVER_DEFAULT (0) or MI_SOLVER_MULTI_LAUNCH (1), got {flags}")
+    _solver_flags = int(flags)
 
 
 def corner_response(image: torch.Tensor, block_size: int) -> torch.Tensor:
@@ -55,8 +57,11 @@ def corner_response(image: torch.Tensor, block_size: int) -> torch.Tensor:
     n, _, h, w = img.shape
     out = torch.empty(img.shape, dtype=F32, device=img.device)
     u8 = img.dtype == U8
+    # K1's ticket counters: a fresh block per call from the caching allocator (stream-ordered: no sharing between
+    # streams, nothing cached per stream); the library clears it on the stream before the kernel draws from it
+    ctr = torch.empty(TILE_COUNTER_BYTES // 4, dtype=torch.int32, device=img.device)
     N.call("mi_corner_response_balanced", N.dev(img, U8 if u8 else F32, "image"), int(u8), n, h, w, int(block_size),
-           N.dev(out, F32, "score"), _tile_counter(img.device).data_ptr(), N.stream_ptr())
+           N.dev(out, F32, "score"), ctr.data_ptr(), N.stream_ptr())
     return out
 
 
@@ -297,7 +302,8 @@ def sinkhorn_bits(bits1: torch.Tensor, bits2: torch.Tensor, normalized: bool, ep
                   iterations: int, return_duals: bool = False, want_p: bool = True, return_state: bool = False):
     """Cost + Sinkhorn for packed hard-bit descriptors (B,N,D/32),(B,M,D/32) int32 -> P (B,N+1,M+1),
     uint16 dot-product form (M <= 1024; half the bytes per iteration).  return_state: also the
-    (dots, row_info, col_info, pitch) the duals refer to (for mnn_from_duals_dots)."""
+    (dots, row_info, col_info, pitch, (workspace, status word address)) the duals refer to (for mnn_from_duals_dots;
+    the workspace is kept alive because the call's status word lives in it)."""
     b, n, words = bits1.shape
     m = bits2.shape[1]
     dev = bits1.device
@@ -321,9 +327,11 @@ def sinkhorn_bits(bits1: torch.Tensor, bits2: torch.Tensor, normalized: bool, ep
     work = torch.empty(((wbytes + 7) // 8,), dtype=torch.int64, device=dev)
     N.call("mi_sinkhorn_dots", dots.data_ptr(), row_info.data_ptr(), col_info.data_ptr(), b, n, m, pitch,
            float(epsilon), float(unused_score), 1.0 if normalized else float(words * 32), int(iterations),
-           u.data_ptr(), v.data_ptr(), p.data_ptr() if p is not None else None, work.data_ptr(), wbytes, N.stream_ptr())
+           u.data_ptr(), v.data_ptr(), p.data_ptr() if p is not None else None, work.data_ptr(), wbytes, _solver_flags,
+           N.stream_ptr())
     if return_state:
-        return p, u, v, (dots, row_info, col_info, pitch)
+        status = N.load().mi_sinkhorn_dots_status_word(work.data_ptr(), b, n, m)
+        return p, u, v, (dots, row_info, col_info, pitch, (work, status))
     return (p, u, v) if (return_duals or not want_p) else p
 
 
@@ -401,7 +409,8 @@ def mnn_from_duals(z: torch.Tensor, m: int, pitch: int, u: torch.Tensor, v: torc
 
 def mnn_from_duals_dots(state, m: int, epsilon: float, u: torch.Tensor, v: torch.Tensor, kpts1: torch.Tensor,
                         kpts2: torch.Tensor, max_matches: int, threshold: float, return_indices: bool = False):
-    dots, row_info, col_info, pitch = state
+    dots, row_info, col_info, pitch = state[:4]
+    status = state[4][1] if len(state) > 4 else None          # the producing Sinkhorn call's status word (device address)
     b, n, _ = dots.shape
     k1, k2 = kpts1.float().contiguous(), kpts2.float().contiguous()
     wbytes = int(N.load().mi_mnn_duals_workspace_bytes(b, n, m))
@@ -411,8 +420,8 @@ def mnn_from_duals_dots(state, m: int, epsilon: float, u: torch.Tensor, v: torch
     mk1, mk2, sc, valid, ij = _mnn_outputs(b, max_matches, dots.device)
     N.call("mi_mnn_from_duals_dots", dots.data_ptr(), row_info.data_ptr(), col_info.data_ptr(), b, n, m, pitch,
            float(epsilon), N.dev(u, F32, "u"), N.dev(v, F32, "v"), N.dev(k1, F32, "keypoints1"),
-           N.dev(k2, F32, "keypoints2"), int(max_matches), float(threshold), work.data_ptr(), wbytes, mk1.data_ptr(),
-           mk2.data_ptr(), sc.data_ptr(), valid.data_ptr(), ij.data_ptr(), N.stream_ptr())
+           N.dev(k2, F32, "keypoints2"), int(max_matches), float(threshold), work.data_ptr(), wbytes, status,
+           mk1.data_ptr(), mk2.data_ptr(), sc.data_ptr(), valid.data_ptr(), ij.data_ptr(), N.stream_ptr())
     out = (mk1, mk2, sc, valid)
     return out + (ij,) if return_indices else out
 
@@ -569,7 +578,8 @@ def match_pairs(image1: torch.Tensor, image2: torch.Tensor, *, block_size: int, 
     prm = N.MatchParams(int(block_size), int(nms_radius), int(max_keypoints), float(score_threshold), int(border_margin),
                         int(pair_geom.numel()), N.dev(pair_geom, torch.int32, "pair_geom"), N.dev(pair_thr, F32, "pair_thr"),
                         plan.data_ptr() if plan is not None else None, int(bool(normalize_descriptors)), float(epsilon),
-                        float(unused_score), int(sinkhorn_iterations), int(max_matches), float(match_threshold))
+                        float(unused_score), int(sinkhorn_iterations), int(max_matches), float(match_threshold),
+                        _solver_flags)
     import ctypes
     wbytes = int(N.load().mi_match_pairs_workspace_bytes(n, h, w, ctypes.byref(prm)))
     if wbytes == 0:

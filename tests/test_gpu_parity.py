@@ -19,6 +19,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def _status_word(state) -> int:
+    """The status word of the mi_sinkhorn_dots call behind `state` (ops.sinkhorn_bits(..., return_state=True)): it lives
+    inside the call's workspace; 0 = solved."""
+    work, addr = state[4]
+    torch.cuda.synchronize()
+    return int(work.view(torch.int32)[(addr - work.data_ptr()) // 4].item())
+
+
 def gpu(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
@@ -141,16 +149,19 @@ def test_topk_select_path_equals_full_sort(mods):
     sc = ops.corner_response(gpu(a), 3).squeeze(1)
     g = load_golden("nms_topk")
     plateau = gpu(np.tile(g["plateau_scores"], (1, 4, 4))[:, :150, :200].copy())
-    try:
+    with N.debug_library() as lib:                 # the kernel-variant hooks exist only in the debug build of the library
         for scores, r, ks in ((sc, 5, (512, 100, 7)), (plateau, 1, (512, 64))):
             for k in ks:
-                N.load().mi_debug_set(9, 0)
+                assert lib.mi_debug_set(9, 0) == 0
                 kp0, s0 = ops.nms_topk(scores, r, k, 0.0, 0)
-                N.load().mi_debug_set(9, 1)
+                assert lib.mi_debug_set(9, 1) == 0
                 kp1, s1 = ops.nms_topk(scores, r, k, 0.0, 0)
                 assert torch.equal(kp0, kp1) and torch.equal(s0, s1), (r, k)
-    finally:
-        N.load().mi_debug_set(9, 1)
+    for scores, r, k in ((sc, 5, 512), (plateau, 1, 64)):       # and the product library gives the same again
+        with N.debug_library():
+            kp1, s1 = ops.nms_topk(scores, r, k, 0.0, 0)
+        kp2, s2 = ops.nms_topk(scores, r, k, 0.0, 0)
+        assert torch.equal(kp1, kp2) and torch.equal(s1, s2)
 
 
 def test_topk_errors_and_empty(mods):
@@ -286,14 +297,14 @@ def test_sinkhorn_dots_bounded_shift_vs_row_maximum(mods, eps, unused):
     ok, worst = p_close(p_fast.cpu().numpy(), ref)
     assert ok, worst
     # the same call with the bound withheld: per-row maxima
-    _, _, _, (dots, ri, ci, pitch) = ops.sinkhorn_bits(t1, t2, True, eps, unused, 20, return_state=True)
+    _, _, _, (dots, ri, ci, pitch, _) = ops.sinkhorn_bits(t1, t2, True, eps, unused, 20, return_state=True)
     wbytes = int(N.load().mi_sinkhorn_dots_workspace_bytes(2, n, m))
     work = torch.empty((wbytes + 7) // 8, dtype=torch.int64, device=DEV)
     u = torch.empty((2, n + 1), device=DEV)
     v = torch.empty((2, m + 1), device=DEV)
     p_slow = torch.empty((2, n + 1, m + 1), device=DEV)
     N.call("mi_sinkhorn_dots", dots.data_ptr(), ri.data_ptr(), ci.data_ptr(), 2, n, m, pitch, float(eps), float(unused),
-           0.0, 20, u.data_ptr(), v.data_ptr(), p_slow.data_ptr(), work.data_ptr(), wbytes, N.stream_ptr())
+           0.0, 20, u.data_ptr(), v.data_ptr(), p_slow.data_ptr(), work.data_ptr(), wbytes, 0, N.stream_ptr())
     ok, worst = p_close(p_slow.cpu().numpy(), ref)
     assert ok, worst
     assert float(((p_fast - p_slow).abs() / p_slow.abs().clamp(min=1.0)).max()) < 2e-5      # relative on the dustbin entries
@@ -315,17 +326,17 @@ def test_sinkhorn_single_launch_equals_multi_launch(mods, batch, n, m, normalize
     b2[:, :k] = b1[:, :k]                                        # true matches
     t1, t2 = gpu(b1.view(np.int32)), gpu(b2.view(np.int32))
     eps, unused = (0.05, 1.0) if normalized else (24.0, 300.0)
-    lib = N.load()
-    try:
-        assert lib.mi_debug_set(7, 0) == 0
+    try:                                                         # the caller's flag selects the form (product library)
+        ops.set_solver_flags(ops.MI_SOLVER_MULTI_LAUNCH)
         want = [t.clone() for t in ops.sinkhorn_bits(t1, t2, normalized, eps, unused, iters, return_duals=True)]
-        assert lib.mi_debug_set(7, 1) == 0
+        ops.set_solver_flags(ops.MI_SOLVER_DEFAULT)
         for _ in range(3):                                       # the same shapes again: allocator reuse, stale granules
-            got = ops.sinkhorn_bits(t1, t2, normalized, eps, unused, iters, return_duals=True)
+            *got, state = ops.sinkhorn_bits(t1, t2, normalized, eps, unused, iters, return_state=True)
             for x, y in zip(got, want):
                 assert torch.equal(x, y)
+            assert _status_word(state) == 0
     finally:
-        lib.mi_debug_set(7, 1)
+        ops.set_solver_flags(ops.MI_SOLVER_DEFAULT)
     ref = O.sinkhorn_match(*[unpack_bits(b, 512).astype(np.float64) / (np.sqrt(unpack_bits(b, 512).sum(-1, keepdims=True)) if normalized else 1.0)
                              for b in (b1, b2)], iters, eps, unused, "l2", dtype=np.float64)
     ok, worst = p_close(got[0].cpu().numpy(), ref)
@@ -1194,6 +1205,123 @@ def test_corner_ticket_schedule_equals_static(mods):
             assert torch.equal(got, want)
             assert int(ctr.abs().sum()) == 0
     assert np.array_equal(want[:6].cpu().numpy(), O.shi_tomasi_score(base.astype(np.float32), 3))
+    # the bench's own batch (448 frames, where round 2's fault appeared): ONE extra launch per pixel type
+    n = 448
+    img8 = gpu(np.tile(base, (n // 6 + 1, 1, 1, 1))[:n])
+    for x, u8, static in ((img8.float(), 0, "mi_corner_response"), (img8, 1, "mi_corner_response_u8")):
+        want = torch.empty((n, 1, h, w), dtype=torch.float32, device=DEV)
+        N.call(static, x.data_ptr(), n, h, w, 3, want.data_ptr(), N.stream_ptr())
+        got = torch.full((n, 1, h, w), -1.0, dtype=torch.float32, device=DEV)
+        N.call("mi_corner_response_balanced", x.data_ptr(), u8, n, h, w, 3, got.data_ptr(), ctr.data_ptr(), N.stream_ptr())
+        assert torch.equal(got, want)
+        del want, got
+
+
+def test_corner_dirty_tile_counter_is_harmless(mods):
+    """A counter block left dirty (a launch that died between its first draw and the last workgroup's reset) must not
+    make later calls skip tiles: the launcher clears the block on the stream ahead of the kernel.
+    Garbage of three kinds -- mid-range tickets, huge tickets, a wrong `done` count -- still gives the static map."""
+    from onnx_image_processing_amd import _native as N, ops
+    n, h, w = 120, 480, 640
+    base = np.stack([synth_image(910 + i, h, w) for i in range(6)])[:, None]
+    img8 = gpu(np.tile(base, (n // 6, 1, 1, 1)))
+    words = ops.TILE_COUNTER_BYTES // 4
+    for x, u8, static in ((img8.float(), 0, "mi_corner_response"), (img8, 1, "mi_corner_response_u8")):
+        want = torch.empty((n, 1, h, w), dtype=torch.float32, device=DEV)
+        N.call(static, x.data_ptr(), n, h, w, 3, want.data_ptr(), N.stream_ptr())
+        for fill in (37, 0x7FFFFFF0, -1):
+            ctr = torch.full((words,), fill, dtype=torch.int32, device=DEV)
+            got = torch.full((n, 1, h, w), -1.0, dtype=torch.float32, device=DEV)
+            N.call("mi_corner_response_balanced", x.data_ptr(), u8, n, h, w, 3, got.data_ptr(), ctr.data_ptr(), N.stream_ptr())
+            assert torch.equal(got, want), fill
+            assert int(ctr.abs().sum()) == 0
+    # the module path allocates its block per call (uninitialised memory): same map
+    assert torch.equal(ops.corner_response(img8, 3), want)
+
+
+def _poison_setup(batch=2, n=96, m=80):
+    from onnx_image_processing_amd import ops
+    rng = np.random.default_rng(4242)
+    b1 = rng.integers(0, 2 ** 32, size=(batch, n, 8), dtype=np.uint64).astype(np.uint32)
+    b2 = rng.integers(0, 2 ** 32, size=(batch, m, 8), dtype=np.uint64).astype(np.uint32)
+    b2[:, :40] = b1[:, :40]
+    k1 = gpu(rng.integers(0, 200, size=(batch, n, 2)).astype(np.float32))
+    k2 = gpu(rng.integers(0, 200, size=(batch, m, 2)).astype(np.float32))
+    p, u, v, state = ops.sinkhorn_bits(gpu(b1.view(np.int32)), gpu(b2.view(np.int32)), True, 0.05, 1.0, 10,
+                                       return_state=True, want_p=False)
+    return u, v, state, k1, k2, m
+
+
+def test_timed_out_solver_is_loud_not_garbage(mods):
+    """What a hand-off time-out of the single-launch Sinkhorn leaves behind (status word != 0, NaN duals) must come out
+    as "no matches", never as plausible wrong ones and never as an out-of-bounds read:
+    (a) a healthy call: status word 0, matches found; (b) the status word alone forces valid = 0 for every match of
+    the call; (c) NaN duals alone (no status word handed over) give no winner anywhere: valid = 0, indices -1;
+    (d) a NaN row inside an otherwise healthy P through mi_mnn_extract loses only that row."""
+    from onnx_image_processing_amd import ops
+    u, v, state, k1, k2, m = _poison_setup()
+    assert _status_word(state) == 0
+    good = ops.mnn_from_duals_dots(state, m, 0.05, u, v, k1, k2, 30, 0.1, return_indices=True)
+    assert int(good[3].sum()) >= 2 * 20
+    work, addr = state[4]
+    word = work.view(torch.int32)[(addr - work.data_ptr()) // 4:(addr - work.data_ptr()) // 4 + 1]
+    word.fill_(1)                                                # (b)
+    mk1, mk2, sc, valid, ij = ops.mnn_from_duals_dots(state, m, 0.05, u, v, k1, k2, 30, 0.1, return_indices=True)
+    assert int(valid.sum()) == 0 and bool((ij == -1).all()) and bool((sc <= 0).all())
+    word.fill_(0)
+    again = ops.mnn_from_duals_dots(state, m, 0.05, u, v, k1, k2, 30, 0.1, return_indices=True)
+    for x, y in zip(again, good):
+        assert torch.equal(x, y)
+    un, vn = u.clone(), v.clone()                                # (c): pair 0 poisoned, pair 1 healthy
+    un[0].fill_(float("nan"))
+    vn[0].fill_(float("nan"))
+    mk1, mk2, sc, valid, ij = ops.mnn_from_duals_dots(state[:4], m, 0.05, un, vn, k1, k2, 30, 0.1, return_indices=True)
+    assert int(valid[0].sum()) == 0 and bool((ij[0] == -1).all())
+    assert torch.equal(valid[1], good[3][1]) and torch.equal(ij[1], good[4][1]) and torch.equal(sc[1], good[2][1])
+
+
+def test_small_call_on_one_stream_while_another_stream_runs_the_batched_step(mods):
+    """The header's contract: calls on different streams may run concurrently.  A one-pair and an eight-pair call (the
+    single-launch Sinkhorn, whose bands hand column sums to each other inside the launch) are issued on stream A while
+    stream B is busy with 448-pair steps; A's results must be the single-stream results and its solver status 0
+    (VERDICT r2 next #2).  One process, one run."""
+    from onnx_image_processing_amd import ops
+    from onnx_image_processing_amd.synth import synth_batch_u8
+    cfg = dict(block_size=3, num_pairs=512, binarize=True, soft_binarize=False, sinkhorn_iterations=20, epsilon=0.05,
+               nms_radius=5)
+    model = mods["MatchExtractionWrapper"](mods["ShiTomasiSparseBADSinkhornMatcher"](max_keypoints=512, **cfg),
+                                           max_matches=100, match_threshold=0.1).to(DEV)
+    a8, b8 = synth_batch_u8(2000, 448, 480, 640)
+    big1, big2 = gpu(a8), gpu(b8)
+    small = [(big1[:1].clone(), big2[:1].clone()), (big1[8:16].clone(), big2[8:16].clone())]
+    want_small = [[t.clone() for t in model.forward_single_call(x, y)] for x, y in small]
+    want_mod = [[t.clone() for t in model(x, y)] for x, y in small]
+    want_big = [t.clone() for t in model(big1, big2)]
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    got_small, got_mod = [], []
+    with torch.cuda.stream(sb):
+        for _ in range(6):
+            got_big = model(big1, big2)
+    with torch.cuda.stream(sa):
+        for _ in range(3):
+            for x, y in small:
+                got_small.append(model.forward_single_call(x, y))
+                got_mod.append(model(x, y))
+        bits = [gpu(np.random.default_rng(3).integers(0, 2 ** 32, size=(8, 512, 16), dtype=np.uint64).astype(np.uint32).view(np.int32))] * 2
+        state = ops.sinkhorn_bits(*bits, True, 0.05, 1.0, 20, return_state=True, want_p=False)[3]
+    with torch.cuda.stream(sb):
+        for _ in range(2):
+            got_big = model(big1, big2)
+    torch.cuda.synchronize()
+    for i, (g, gm) in enumerate(zip(got_small, got_mod)):
+        for x, y in zip(g, want_small[i % 2]):
+            assert torch.equal(x, y)
+        for x, y in zip(gm, want_mod[i % 2]):
+            assert torch.equal(x, y)
+    for x, y in zip(got_big, want_big):
+        assert torch.equal(x, y)
+    assert _status_word(state) == 0
 
 
 def test_u8_pipeline_equals_f32_on_the_c2_fixture(mods):

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     assert len(names) >= 18
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/mi355x_match.h but not exported"
-    assert lib.mi_abi_version() == 1
+    assert lib.mi_abi_version() == 2
     lib.mi_error_string.restype = ctypes.c_char_p
     assert lib.mi_error_string(0) == b"ok" and b"NULL" in lib.mi_error_string(-1)
 
@@ -40,8 +40,62 @@ def test_library_exports_every_declared_symbol(lib_path):
 def test_binding_covers_the_header(lib_path):
     from onnx_image_processing_amd import _native
     assert sorted(_native.SIGNATURES) == header_functions()
-    assert sorted(_native.DEBUG_SIGNATURES) == header_functions(DEBUG_HEADER) == ["mi_debug_bad_plan_passes", "mi_debug_clock_probe", "mi_debug_set", "mi_debug_topk_stamps"]
+    assert sorted(_native.DEBUG_SIGNATURES) == header_functions(DEBUG_HEADER) == [
+        "mi_debug_bad_plan_passes", "mi_debug_clock_probe", "mi_debug_set", "mi_debug_sinkhorn_dots_form", "mi_debug_topk_stamps"]
     _native.load()
+    with _native.debug_library() as dbg:                     # the debug build exports both headers
+        assert dbg.mi_abi_version() == 2
+
+
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+
+
+def test_product_library_exports_the_header_and_nothing_else(lib_path):
+    """-fvisibility=hidden + the version script: the product library's dynamic symbols are exactly the MI_API
+    declarations of include/mi355x_match.h -- no C++-mangled internals, no libstdc++ instantiations, and none of the
+    process-wide kernel selectors (mi_debug_*), which live in the separate debug library (VERDICT r2 next #10)."""
+    from onnx_image_processing_amd.build import DEBUG_LIB
+    assert _exported(lib_path) == header_functions()
+    assert _exported(DEBUG_LIB) == sorted(header_functions() + header_functions(DEBUG_HEADER))
+    import subprocess
+    syms = subprocess.run(["nm", lib_path], capture_output=True, text=True).stdout
+    assert "mi_hooks" not in syms and "mi_debug" not in syms                 # not even as local symbols
+
+
+def test_sinkhorn_form_decision_is_a_host_check(lib_path):
+    """Which Sinkhorn form runs is decided on the host from (extents, caller flags, what the device can hold): the
+    single-launch form only when its whole grid -- 16 workgroups of 512 threads per pair, pairs rounded up to 8 -- fits
+    occupancy x compute units; a CU-masked / partitioned device or MI_SOLVER_MULTI_LAUNCH takes the multi-launch form
+    (ADVICE r2 medium #1).  Pure function, no GPU."""
+    from onnx_image_processing_amd import _native
+    with _native.debug_library() as dbg:
+        form = dbg.mi_debug_sinkhorn_dots_form
+        assert form(1, 512, 512, 0, 4, 256) == 1 and form(8, 512, 512, 0, 4, 256) == 1      # a whole MI355X
+        assert form(8, 512, 512, 0, 1, 128) == 1 and form(8, 512, 512, 0, 1, 127) == 0        # 128 workgroups needed
+        assert form(1, 512, 512, 0, 3, 42) == 0 and form(1, 512, 512, 0, 4, 32) == 1          # one pair still launches 128
+        assert form(8, 512, 512, 0, 0, 256) == 0                                              # occupancy query failed
+        assert form(8, 512, 512, 1, 4, 256) == 0                                              # the caller's flag
+        assert form(9, 512, 512, 0, 4, 256) == 0 and form(8, 513, 512, 0, 4, 256) == 0        # not a single-launch shape
+        assert form(8, 512, 600, 0, 4, 256) == 0
+        assert form(2, 100, 100, 0, 1, 32) == 1 and form(2, 100, 100, 0, 1, 31) == 0          # 4 bands x 8 slots
+        assert dbg.mi_debug_set(7, 0) == 0 and form(1, 512, 512, 0, 4, 256) == 0              # the test hook
+    with _native.debug_library() as dbg:                      # leaving the block reset the hook
+        assert dbg.mi_debug_sinkhorn_dots_form(1, 512, 512, 0, 4, 256) == 1
+    lib = _native.load()
+    ptr = ctypes.cast(ctypes.create_string_buffer(64), ctypes.c_void_p)
+    assert lib.mi_sinkhorn_dots(ptr, ptr, ptr, 1, 8, 8, 8, 0.05, 1.0, 1.0, 5, ptr, ptr, None, ptr, 1 << 20, 2, None) == -3   # unknown flag
+    base = ctypes.create_string_buffer(1 << 16)
+    addr = ctypes.addressof(base)
+    assert lib.mi_sinkhorn_dots_status_word(None, 1, 8, 8) is None
+    assert lib.mi_sinkhorn_dots_status_word(addr, 1, 8, 2000) is None                        # not a dots shape
+    lib.mi_sinkhorn_dots_workspace_bytes.restype = ctypes.c_size_t
+    for shape in ((1, 8, 8), (8, 512, 512), (9, 512, 512), (64, 512, 1024)):
+        w = lib.mi_sinkhorn_dots_status_word(addr, *shape)
+        total = lib.mi_sinkhorn_dots_workspace_bytes(*shape)
+        assert addr < w and w % 4 == 0 and w + 16 <= addr + total, shape                     # inside the workspace
 
 
 def test_no_environment_variable_changes_which_kernels_run(lib_path):
@@ -226,8 +280,9 @@ def test_match_pairs_host_side_checks(lib_path):
     assert lib.mi_match_pairs_workspace_bytes(8, 480, 640, ctypes.byref(prm)) >= 8 * (per_pair - 32768)   # fixed part: alignment + K1 ticket counters
     big = lib.mi_match_pairs_workspace_bytes(64, 480, 640, ctypes.byref(prm))     # one image side at a time
     assert 64 * 4_000_000 < big < 64 * 6_000_000
+    assert prm.flags == 0
     for field, bad in (("max_keypoints", 2000), ("num_pairs", 100), ("block_size", 4), ("sinkhorn_iterations", 0),
-                       ("epsilon", 0.0), ("max_matches", 0)):
+                       ("epsilon", 0.0), ("max_matches", 0), ("flags", 2)):
         good = getattr(prm, field)
         setattr(prm, field, bad)
         assert lib.mi_match_pairs_workspace_bytes(1, 480, 640, ctypes.byref(prm)) == 0, field
@@ -260,7 +315,7 @@ def test_dots_form_refuses_small_epsilon(lib_path):
     lib = N.load()
     fake = ctypes.create_string_buffer(4096)
     ptr = ctypes.cast(fake, ctypes.c_void_p).value
-    assert lib.mi_sinkhorn_dots(ptr, ptr, ptr, 1, 8, 8, 8, 0.004, 1.0, 1.0, 5, ptr, ptr, None, ptr, 1 << 20, None) == -3
+    assert lib.mi_sinkhorn_dots(ptr, ptr, ptr, 1, 8, 8, 8, 0.004, 1.0, 1.0, 5, ptr, ptr, None, ptr, 1 << 20, 0, None) == -3
     prm = N.MatchParams(3, 5, 512, 0.0, 7, 512, ptr, ptr, None, 1, 0.004, 1.0, 20, 100, 0.1)
     assert lib.mi_match_pairs_workspace_bytes(1, 480, 640, ctypes.byref(prm)) == 0
     prm.epsilon = 0.005
@@ -334,7 +389,11 @@ def test_bad_gather_schedule_is_lane_local_and_cuts_bank_conflicts(lib_path):
     is a deterministic function of the table."""
     from onnx_image_processing_amd import _native as N
     from onnx_image_processing_amd.pytorch_model.descriptor.bad import SparseBAD
-    lib = N.load()
+    with N.debug_library() as lib:                # mi_debug_* live in the debug build only
+        _gather_schedule_checks(lib, SparseBAD)
+
+
+def _gather_schedule_checks(lib, SparseBAD):
     for pairs, bound in ((512, 200), (256, 110)):
         geom = np.ascontiguousarray(SparseBAD(num_pairs=pairs).pair_geom.numpy().astype(np.uint32))
         got = []

@@ -15,7 +15,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 448
 base = np.stack([synth_image(1000 + i) for i in range(8)])[:, None]
 img8 = torch.from_numpy(np.tile(base, (n // 8, 1, 1, 1))).cuda()
 img32 = img8.float()
-lib = N.load()
+lib = N.use_debug_library()          # the mi_debug_* hooks live in lib/libmi355x_match_debug.so
 for rows in (4, 5, 8):
     lib.mi_debug_set(2, rows)
     for name, x, bpp in (("u8", img8, 5.0), ("f32", img32, 8.0)):

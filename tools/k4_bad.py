@@ -22,7 +22,7 @@ for pairs in (512, 256):
     bad = SparseBAD(num_pairs=pairs, binarize=True, soft_binarize=False).cuda()
     geom = np.ascontiguousarray(bad.pair_geom.cpu().numpy().astype(np.uint32))
     a, b = ctypes.c_int(0), ctypes.c_int(0)
-    N.load().mi_debug_bad_plan_passes(geom.ctypes.data, pairs, ctypes.byref(a), ctypes.byref(b))
+    N.use_debug_library().mi_debug_bad_plan_passes(geom.ctypes.data, pairs, ctypes.byref(a), ctypes.byref(b))
     for name, x in (("f32", img32), ("u8", img8)):
         ref = bad.forward_bits(x, kp)
         torch.cuda.synchronize()

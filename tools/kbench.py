@@ -53,8 +53,8 @@ def main():
     if "corner" in args.which:
         for impl, rows, name in ((1, 8, "corner(tile)"), (0, 8, "corner(stream R=8)"), (0, 5, "corner(stream R=5)"),
                                  (0, 4, "corner(stream R=4)")):
-            N.load().mi_debug_set(1, impl)
-            N.load().mi_debug_set(2, rows)
+            N.use_debug_library().mi_debug_set(1, impl)
+            N.use_debug_library().mi_debug_set(2, rows)
             alt = ops.corner_response(img, 3)
             assert torch.equal(alt, score), name
             ms = timeit(lambda: ops.corner_response(img, 3), args.iters)
@@ -96,20 +96,20 @@ def main():
     if "sinkhorn" in args.which:
         for mode, name in ((1, "sinkhorn_fused log-partials"), (2, "sinkhorn_fused prob-partials v1"),
                            (0, "sinkhorn_fused prob-partials lean")):
-            N.load().mi_debug_set(4, mode)
+            N.use_debug_library().mi_debug_set(4, mode)
             ms = timeit(lambda: ops.sinkhorn(z, K, pitch, -20.0, 20), args.iters)
             res[name] = (ms, (21.0 * 4 * n * K * K + 4.0 * n * (K + 1) ** 2) / ms / 1e6)
         ms = timeit(lambda: ops.sinkhorn(z, K, pitch, -20.0, 20, use_workspace=False), args.iters)
         res["sinkhorn_2pass(20 it)"] = (ms, (41.0 * 4 * n * K * K + 4.0 * n * (K + 1) ** 2) / ms / 1e6)
         ref_p = None
         for mode, name in ((1, "one stream"), (2, "2 parts"), (3, "3 parts"), (4, "4 parts")):
-            N.load().mi_debug_set(6, mode)
+            N.use_debug_library().mi_debug_set(6, mode)
             pp_ = ops.sinkhorn_bits(bits, b2, True, 0.05, 1.0, 20)
             assert os.environ.get("KBENCH_NOCHECK") or ref_p is None or torch.equal(pp_, ref_p), name
             ref_p = pp_
             ms = timeit(lambda: ops.sinkhorn_bits(bits, b2, True, 0.05, 1.0, 20), args.iters)
             res[f"cost+sinkhorn dots(20 it, {name})"] = (ms, (20.0 * 2 * n * K * K + 4.0 * n * (K + 1) ** 2) / ms / 1e6)
-        N.load().mi_debug_set(6, 2)
+        N.use_debug_library().mi_debug_set(6, 2)
     p = ops.sinkhorn(z, K, pitch, -20.0, 20)
     if "mnn" in args.which:
         ms = timeit(lambda: ops.mnn_extract(p, kp, torch.roll(kp, 1, 0), 100, 0.1), args.iters)

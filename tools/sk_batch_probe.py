@@ -15,7 +15,7 @@ from onnx_image_processing_amd.pytorch_model.matching.sinkhorn import SinkhornMa
 K = 512
 rng = np.random.default_rng(5)
 m = SinkhornMatcher(iterations=20, epsilon=0.05)
-lib = N.load()
+lib = N.use_debug_library()          # the mi_debug_* hooks live in lib/libmi355x_match_debug.so
 for parts in (1, 2):
     lib.mi_debug_set(6, parts)
     for B in (16, 32, 64, 128, 224, 448, 896):

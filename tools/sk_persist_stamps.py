@@ -12,7 +12,7 @@ import torch  # noqa: E402
 
 from onnx_image_processing_amd import _native as N  # noqa: E402
 
-lib = N.load()
+lib = N.use_debug_library()          # the mi_debug_* hooks live in lib/libmi355x_match_debug.so
 lib.mi_debug_set(8, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 n = m = 512
@@ -30,7 +30,7 @@ u = torch.empty((batch, n + 1), device="cuda")
 v = torch.empty((batch, m + 1), device="cuda")
 for _ in range(5):
     N.call("mi_sinkhorn_dots", dots.data_ptr(), ri.data_ptr(), ci.data_ptr(), batch, n, m, pitch, 0.05, 1.0, 1.0, 20, u.data_ptr(),
-           v.data_ptr(), None, work.data_ptr(), wbytes, N.stream_ptr())
+           v.data_ptr(), None, work.data_ptr(), wbytes, 0, N.stream_ptr())
     torch.cuda.synchronize()
 w = work.cpu().numpy()
 prof = w[-(4096 // 8):][:160].reshape(20, 8).astype(np.int64)

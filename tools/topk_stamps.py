@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from onnx_image_processing_amd import _native as N, ops  # noqa: E402
 from onnx_image_processing_amd.synth import synth_batch  # noqa: E402
 
-lib = N.load()
+lib = N.use_debug_library()          # the mi_debug_* hooks live in lib/libmi355x_match_debug.so
 a, _ = synth_batch(1000, 2, 480, 640)
 img = torch.from_numpy(a).cuda()
 score = ops.corner_response(img, 3).squeeze(1)
