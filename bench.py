@@ -131,13 +131,87 @@ def k1_roofline(ms_per_launch: float, bytes_per_px: float, images: int, kernel: 
 
 
 # ----------------------------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(parity_pairs: int, gpu_records=None) -> dict:
+def compare_match_sets(got: dict, want: dict, max_matches: int, mutual: dict | None = None, tol: float = 1e-4) -> int:
+    """0 = same set and scores within tol; 1 = the sets differ only by a tie at the max_matches cut (both full, every
+    match in one set but not the other scores within tol of the cut score, and -- when the reference's complete mutual
+    set is given -- the match only `got` has is one of them with the same score); 2 = anything else."""
+    if any(abs(got[k] - want[k]) > tol for k in set(got) & set(want)):
+        return 2
+    if set(got) == set(want):
+        return 0
+    if len(got) != max_matches or len(want) != max_matches:
+        return 2
+    cut = min(min(got.values()), min(want.values()))
+    both = {**want, **got}
+    if any(both[k] > cut + tol for k in set(got) ^ set(want)):
+        return 2
+    if mutual is not None and any(k not in mutual or abs(mutual[k] - got[k]) > tol for k in set(got) - set(want)):
+        return 2
+    return 1
+
+
+def physical_cores() -> int:
+    """Physical cores of this host (unique (package, core) pairs of /proc/cpuinfo; os.cpu_count() // 2 if unreadable)."""
+    try:
+        seen, pkg = set(), None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pkg = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                seen.add((pkg, ln.split(":")[1].strip()))
+        if seen:
+            return len(seen)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def host_parallel(workers: int, pairs_per_worker: int) -> dict:
+    """W one-thread processes of the reference CPU path, one pair per call each (oracle/cpu_worker.py): pairs are
+    independent, so this is what the host's cores can do together.  The workers are fresh CPU-only child processes;
+    all of them warm up, then time the same wall-clock window (released together)."""
+    import subprocess
+    worker = os.path.join(ROOT, "oracle", "cpu_worker.py")
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    procs = [subprocess.Popen([sys.executable, worker, str(5000 + 10 * i), str(pairs_per_worker), str(H), str(W), str(K)],
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env) for i in range(workers)]
+    try:
+        for pr in procs:
+            if pr.stdout.readline().strip() != "ready":
+                raise RuntimeError("a cpu_baseline worker failed to start")
+        t0 = time.perf_counter()
+        for pr in procs:
+            pr.stdin.write("go\n")
+            pr.stdin.flush()
+        rows = [json.loads(pr.stdout.readline()) for pr in procs]
+        wall = time.perf_counter() - t0
+    finally:
+        for pr in procs:
+            try:
+                pr.stdin.close()
+            except Exception:
+                pass
+            pr.wait(timeout=60)
+    total = sum(r["pairs"] for r in rows)
+    slowest = max(r["seconds"] for r in rows)
+    return {"workers": workers, "threads_per_worker": 1, "pairs_per_worker": pairs_per_worker,
+            "pairs_per_sec": total / slowest, "slowest_worker_s": slowest, "fastest_worker_s": min(r["seconds"] for r in rows),
+            "wall_s_incl_release": wall, "mean_valid_matches_per_pair": sum(r["valid_matches"] for r in rows) / total,
+            "what": "W single-thread processes of oracle/torch_cpu.py, one pair per call each, released together; "
+                    "total pairs / slowest worker's time"}
+
+
+def cpu_baseline(parity_pairs: int, gpu_records=None, parallel: bool = True) -> dict:
     """The reference CPU path on this host's cores: oracle/torch_cpu.py -- the same ATen CPU
-    kernels in the reference's order, pinned to the reference's recorded outputs by tests/test_oracle_golden.py -- with
-    the reference harness's protocol (5 warm-up + 10 timed calls, mean; sample/image_matching.py:313-328) for one pair
-    per call, for a batch of 8 pairs per call, and for one pair with one thread.  `value` is the best of the
-    multi-thread figures.  gpu_records: the (pairs, max_matches, 6) match records the GPU path produced for the same
-    pairs; the numpy oracle's match sets for the first `parity_pairs` of them are compared after the clocks stop."""
+    kernels in the reference's order, pinned to the reference's recorded outputs by tests/test_oracle_golden.py.
+      sweep          torch intra-op threads in {1, 8, 16, 32, 64, physical cores} for one pair per call, {8, 32, physical}
+                     for eight pairs per call, short protocol (1 warm-up + 3 timed calls) -- the reference relies on
+                     torch's intra-op threads (SURVEY.md section 8b), and how many is the host's choice;
+      value          the BEST single-process configuration of the sweep, re-timed with the reference harness's full
+                     protocol (5 warm-up + 10 timed calls, mean; sample/image_matching.py:313-328); `cores` = its threads;
+      host_parallel  W = physical cores one-thread worker processes, one pair per call each (pairs are independent).
+    gpu_records: the (pairs, max_matches, 6) match records the GPU path produced for the same pairs; the numpy oracle's
+    match sets for the first `parity_pairs` of them are compared after the clocks stop."""
     from onnx_image_processing_amd.synth import synth_batch
     from oracle import numpy_oracle as O
     from oracle.torch_cpu import TorchCpuPath, time_protocol
@@ -146,54 +220,77 @@ def cpu_baseline(parity_pairs: int, gpu_records=None) -> dict:
     path = TorchCpuPath(t["box_512"], t["thr_512"], K, **kw)
     a, b = synth_batch(1000, max(8, parity_pairs), H, W)
     ta, tb = torch.from_numpy(a), torch.from_numpy(b)
-    threads = torch.get_num_threads()
-    one = time_protocol(lambda: path.match(ta[:1], tb[:1], **MNN))
-    batched = time_protocol(lambda: path.match(ta[:8], tb[:8], **MNN), warmup=2, timed=5)
-    torch.set_num_threads(1)
-    single = time_protocol(lambda: path.match(ta[:1], tb[:1], **MNN), warmup=1, timed=3)
-    torch.set_num_threads(threads)
+    default_threads = torch.get_num_threads()
+    cores = physical_cores()
     try:
         model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
     except Exception:
         model = "unknown"
-    best = max(1.0 / one, 8.0 / batched)
-    out = {"value": best, "unit": "image-pairs/sec", "cores": int(threads), "kind": "port",
+    sweep = []
+    for pairs_per_call, counts in ((1, (1, 8, 16, 32, 64, cores)), (8, (8, 32, cores))):
+        for th in sorted({c for c in counts if 1 <= c <= max(cores, 1)}):
+            torch.set_num_threads(th)
+            sec = time_protocol(lambda: path.match(ta[:pairs_per_call], tb[:pairs_per_call], **MNN), warmup=1, timed=3)
+            sweep.append({"pairs_per_call": pairs_per_call, "threads": th, "ms_per_call": sec * 1e3,
+                          "pairs_per_sec": pairs_per_call / sec})
+    best = max(sweep, key=lambda r: r["pairs_per_sec"])
+    torch.set_num_threads(best["threads"])
+    n = best["pairs_per_call"]
+    full = time_protocol(lambda: path.match(ta[:n], tb[:n], **MNN))          # 5 + 10, the reference harness's protocol
+    torch.set_num_threads(default_threads)
+    out = {"value": n / full, "unit": "image-pairs/sec", "cores": int(best["threads"]), "kind": "port",
            "sample": f"oracle/torch_cpu.py (torch-CPU restatement of the reference path, pinned to the reference's recorded "
-                     f"outputs), 640x480 K=512 pairs seeds 1000.., protocol of sample/image_matching.py:313-328: one pair per "
-                     f"call 5+10 runs, 8 pairs per call 2+5 runs, one pair on 1 thread 1+3 runs",
-           "one_pair_per_call": {"ms_per_call": one * 1e3, "pairs_per_sec": 1.0 / one, "threads": int(threads)},
-           "eight_pairs_per_call": {"ms_per_call": batched * 1e3, "pairs_per_sec": 8.0 / batched, "threads": int(threads)},
-           "one_thread": {"ms_per_call": single * 1e3, "pairs_per_sec": 1.0 / single, "threads": 1},
-           "host": {"cpu": model, "logical_cpus": os.cpu_count(), "torch": torch.__version__}}
+                     f"outputs), 640x480 K=512 pairs seeds 1000..: best single-process configuration of the thread sweep "
+                     f"({n} pair(s) per call on {best['threads']} thread(s)), protocol of sample/image_matching.py:313-328 "
+                     f"(5 warm-up + 10 timed calls, mean); the sweep itself uses 1 + 3 calls per configuration",
+           "best_configuration": {"pairs_per_call": n, "threads": int(best["threads"]), "ms_per_call": full * 1e3},
+           "sweep": sweep,
+           "host": {"cpu": model, "logical_cpus": os.cpu_count(), "physical_cores": cores,
+                    "torch_default_threads": int(default_threads), "torch": torch.__version__}}
+    if parallel:
+        out["host_parallel"] = host_parallel(cores, 2)
     if gpu_records is not None and parity_pairs > 0:
-        # match-set parity of the GPU's own output for these very pairs: same matched coordinates, same validity, scores
-        # within 1e-4.  A pair with more than max_matches mutual matches keeps the max_matches best: two scores closer than
-        # the 1e-4 bound that straddle that cut may legitimately swap ("cut ties"); anything else is a real difference.
+        # match-set parity of the GPU's own output for these very pairs, against (a) the numpy oracle run here and (b) what
+        # the REFERENCE produced for the same seeds (tests/golden/bench_seeds_matches.npz, recorded by make_golden.py
+        # --round3-only from the imported reference): same matched coordinates, same validity, scores within 1e-4.  A
+        # pair with more than max_matches mutual matches keeps the max_matches best: two scores closer than the 1e-4
+        # bound that straddle that cut may legitimately swap ("cut ties", checked match by match); anything else is a
+        # real difference.
         okw = {k: v for k, v in CFG.items() if k not in ("num_pairs", "sampling_mode")}
-        same, cut, other, worst, nmatch = 0, 0, 0, 0.0, 0
+        fixture = None
+        fpath = os.path.join(ROOT, "tests", "golden", "bench_seeds_matches.npz")
+        if os.path.exists(fpath):
+            fixture = np.load(fpath)
+            if int(fixture["first_seed"]) != 1000 or (int(fixture["h"]), int(fixture["w"]), int(fixture["k"])) != (H, W, K):
+                fixture = None
+        tally = {"oracle": [0, 0, 0], "reference": [0, 0, 0]}
+        worst, nmatch = 0.0, 0
         for i in range(parity_pairs):
+            g = gpu_records[i]
+            got = {tuple(map(float, g[j, 0:4])): float(g[j, 4]) for j in np.nonzero(g[:, 5] > 0.5)[0]}
             k1, k2, p = O.match_pair(a[i:i + 1], b[i:i + 1], t["box_512"], t["thr_512"], K, **okw)
             mk1, mk2, sc, valid, _ = O.mnn_extract(p, k1, k2, **MNN)
-            g = gpu_records[i]
-            gv = g[:, 5] > 0.5
-            want = {(*mk1[0, j], *mk2[0, j]): float(sc[0, j]) for j in np.nonzero(valid[0])[0]}
-            got = {tuple(g[j, 0:4]): float(g[j, 4]) for j in np.nonzero(gv)[0]}
+            want = {(*map(float, mk1[0, j]), *map(float, mk2[0, j])): float(sc[0, j]) for j in np.nonzero(valid[0])[0]}
             nmatch += len(want)
             worst = max([worst] + [abs(want[k] - got[k]) for k in set(want) & set(got)])
-            if set(want) == set(got):
-                same += 1
-                continue
-            full = len(want) == MNN["max_matches"] and len(got) == MNN["max_matches"]
-            lo = min(min(want.values()), min(got.values()))
-            odd = [k for k in set(want) ^ set(got) if abs({**want, **got}[k] - lo) > 1e-4]
-            if full and not odd:
-                cut += 1
-            else:
-                other += 1
+            tally["oracle"][compare_match_sets(got, want, MNN["max_matches"])] += 1
+            if fixture is not None and i < int(fixture["pairs"]):
+                fv = fixture["mvalid"][i]
+                ref = {(*map(float, fixture["mk1"][i, j]), *map(float, fixture["mk2"][i, j])): float(fixture["mscores"][i, j])
+                       for j in np.nonzero(fv)[0]}
+                mutual = {tuple(map(float, r[:4])): float(r[4]) for r in fixture["mutual"][i][:int(fixture["n_mutual"][i])]}
+                tally["reference"][compare_match_sets(got, ref, MNN["max_matches"], mutual)] += 1
         out["parity"] = {"checker": "oracle/numpy_oracle.py", "pairs_checked": parity_pairs,
-                         "pairs_with_identical_match_set": same,
-                         "pairs_differing_only_by_ties_at_the_max_matches_cut": cut, "pairs_differing_otherwise": other,
+                         "pairs_with_identical_match_set": tally["oracle"][0],
+                         "pairs_differing_only_by_ties_at_the_max_matches_cut": tally["oracle"][1],
+                         "pairs_differing_otherwise": tally["oracle"][2],
                          "matches_checked": nmatch, "max_abs_score_diff": worst, "bound": 1e-4}
+        if fixture is not None:
+            out["parity"]["vs_reference_fixture"] = {
+                "fixture": "tests/golden/bench_seeds_matches.npz (the imported reference's match sets for seeds 1000..1063)",
+                "pairs_checked": sum(tally["reference"]), "pairs_with_identical_match_set": tally["reference"][0],
+                "pairs_differing_only_by_ties_at_the_max_matches_cut": tally["reference"][1],
+                "pairs_differing_otherwise": tally["reference"][2]}
     return out
 
 
@@ -348,6 +445,18 @@ def side_workload(args, rank, world, dev) -> None:
         h, w, k = 1080, 1920, 1024
         base = ShiTomasiSparseBADSinkhornMatcher(max_keypoints=k, **CFG)
         what = "Shi-Tomasi sparse pipeline, 1920x1080, K=1024 (BASELINE configs[2])"
+        roof = ("mi_corner_response_balanced", "corner_stream_kernel<3,4> (mi_corner_response_balanced)", 8.0, 1)
+    elif args.workload == "c3dense":
+        # BASELINE configs[2] in its "dense BAD cost matrix" reading: the reference's ShiTomasiBADSinkhornMatcher
+        # (feature_detection/shi_tomasi_bad_sinkhorn.py:162-219) -- NMS / top-k WITHOUT border margin, descriptors = the dense
+        # response map sampled at the keypoints (evaluated there exactly; the 4.2 GB map is never built), K x K cost on
+        # the int8 MFMA path.  Pinned to the reference at 640x480 by tests/golden/dense_c3_480x640_k512.npz.
+        from onnx_image_processing_amd.pytorch_model.feature_detection import ShiTomasiBADSinkhornMatcher
+        h, w, k = 1080, 1920, 1024
+        dcfg = {kk: v for kk, v in CFG.items() if kk != "sampling_mode"}
+        base = ShiTomasiBADSinkhornMatcher(max_keypoints=k, **dcfg)
+        what = ("ShiTomasiBADSinkhornMatcher (dense-BAD variant: no border margin, responses at the keypoints), 1920x1080, "
+                "K=1024, P=512 hard bits (BASELINE configs[2], dense reading)")
         roof = ("mi_corner_response_balanced", "corner_stream_kernel<3,4> (mi_corner_response_balanced)", 8.0, 1)
     else:
         h, w, k = H, W, K
@@ -510,6 +619,8 @@ def main() -> None:
                     help="pairs resident per GPU and processed per step (448: the Sinkhorn row kernel's workgroups of "
                          "each half-batch fill whole rounds of the 256 CUs, and top-k runs two workgroups per CU)")
     ap.add_argument("--cpu-pairs", type=int, default=64, help="pairs of the live match-set parity check (0 = skip cpu_baseline)")
+    ap.add_argument("--no-host-parallel", action="store_true",
+                    help="cpu_baseline without the W one-thread worker processes (W = physical cores)")
     ap.add_argument("--no-extras", action="store_true", help="skip u8_ingest / streamed / latency (N = 1 extras)")
     ap.add_argument("--single-call", action="store_true",
                     help="run the step as ONE C-ABI call (mi_match_pairs); informational: no per-stage timers, so the "
@@ -519,8 +630,9 @@ def main() -> None:
     ap.add_argument("--frames", choices=["f32", "u8"], default="f32",
                     help="pixel type of the frames resident in HBM for the main line (f32 = the reference's input form; "
                          "u8 is the line `u8_ingest` reports, selectable here so that profilers can be pointed at it)")
-    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
-                    help="c2 (default, the metric's configuration); c3 = 1080x1920 K=1024; c4 = AKAZE front end")
+    ap.add_argument("--workload", choices=["c2", "c3", "c3dense", "c4"], default="c2",
+                    help="c2 (default, the metric's configuration); c3 = 1080x1920 K=1024 sparse pipeline; c3dense = the same "
+                         "size through the dense-BAD matcher; c4 = AKAZE front end")
     ap.add_argument("--dry-run", action="store_true",
                     help="control flow only: stubbed compute on CPU over gloo (tests the N > 1 launcher; not a measurement)")
     args = ap.parse_args()
@@ -658,7 +770,7 @@ def main() -> None:
                 line["latency"] = measure_latency(model, img1, img2, a8, b8)
             if args.cpu_pairs > 0:
                 stage("cpu_baseline")
-                line["cpu_baseline"] = cpu_baseline(min(args.cpu_pairs, B), records)
+                line["cpu_baseline"] = cpu_baseline(min(args.cpu_pairs, B), records, parallel=not args.no_host_parallel)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -34,8 +34,16 @@ class ShiTomasiBADSinkhornMatcher(nn.Module):
         self.matcher = SinkhornMatcher(iterations=sinkhorn_iterations, epsilon=epsilon, unused_score=unused_score,
                                        distance_type=distance_type)
 
-    @torch.no_grad()
-    def forward(self, image1: torch.Tensor, image2: torch.Tensor):
+    def _plan(self, bad):
+        """The fast-path plan of the descriptor's pair table (hard bits only), built once per device."""
+        if bad.mode != N.MI_BAD_HARD:
+            return None
+        plan = getattr(self, "_bad_plan", None)
+        if plan is None or plan.device != bad.pair_geom.device:
+            plan = self._bad_plan = ops.bad_plan(bad.pair_geom, bad.pair_thr)
+        return plan
+
+    def _detect_describe(self, image1: torch.Tensor, image2: torch.Tensor):
         if image1.shape != image2.shape:
             raise RuntimeError(f"image shapes differ: {tuple(image1.shape)} vs {tuple(image2.shape)}")
         bad = self.detector.descriptor
@@ -47,10 +55,27 @@ class ShiTomasiBADSinkhornMatcher(nn.Module):
             del scores
             kpts.append(kp)
             d, bits = ops.sparse_bad(image, kp, bad.pair_geom, bad.pair_thr, bad.mode, bad.temperature,
-                                     self.normalize_descriptors, want_desc=not packed, want_bits=packed)
+                                     self.normalize_descriptors, want_desc=not packed, want_bits=packed,
+                                     plan=self._plan(bad))
             descs.append(bits if packed else d)
+        return kpts, descs, packed
+
+    @torch.no_grad()
+    def forward(self, image1: torch.Tensor, image2: torch.Tensor):
+        kpts, descs, packed = self._detect_describe(image1, image2)
         if packed:
             probs = self.matcher.forward_bits(descs[0], descs[1], self.normalize_descriptors)
         else:
             probs = self.matcher(descs[0], descs[1])
         return kpts[0], kpts[1], probs
+
+    @torch.no_grad()
+    def match_solution(self, image1: torch.Tensor, image2: torch.Tensor):
+        """forward() up to the Sinkhorn duals (extension, as on the sparse matcher): MatchExtractionWrapper takes the
+        mutual matches straight from them, P is never written."""
+        kpts, descs, packed = self._detect_describe(image1, image2)
+        if packed:
+            sol = self.matcher.solve_bits(descs[0], descs[1], self.normalize_descriptors)
+        else:
+            sol = self.matcher.solve(descs[0], descs[1])
+        return kpts[0], kpts[1], sol

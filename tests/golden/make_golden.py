@@ -476,8 +476,90 @@ def round2():
     save("akaze_c4_480x640_k512", **out)
 
 
+def round3():
+    """Round 3.
+    (1) bench_seeds_matches: the reference's own match sets for the 64 pairs bench.py checks live (seeds 1000..1063,
+        640x480, K=512, export-CLI values, MNN 100 / 0.1): the kept matches AND every mutual match above the threshold
+        with its score, so that a checker can tell a tie at the max_matches cut from a wrong match.
+    (2) dense_c3_480x640_k512: ShiTomasiBADSinkhornMatcher (the dense-descriptor variant, BASELINE configs[2] reading
+        "dense BAD") at 640x480, K=512, P=512 hard bits: keypoints, the reference's descriptor bits at the keypoints,
+        its raw (un-binarised) responses where they are near zero (its fp32 integral image is inexact above 2^24, so
+        those are the bits that may legitimately differ from exact arithmetic), P by row/column maxima, dustbins,
+        marginals, eight full rows, and the MNN matches."""
+    from pytorch_model.feature_detection.shi_tomasi_bad_sinkhorn import ShiTomasiBADSinkhornMatcher
+    from pytorch_model.descriptor.bad import BADDescriptor
+    mnn = dict(max_matches=100, threshold=0.1)
+    # ---- (1)
+    n, h, w, k = 64, 480, 640, 512
+    model = ShiTomasiSparseBADSinkhornMatcher(max_keypoints=k, **EXPORT_CFG).eval()
+    extract = MutualNearestNeighborMatcher(**mnn)
+    rows = dict(mk1=[], mk2=[], mscores=[], mvalid=[], mutual=[], n_mutual=[], kpts_sha=[])
+    with torch.no_grad():
+        for i in range(n):
+            a, b = synth_batch(1000 + i, 1, h, w)
+            k1, k2, p = model(torch.from_numpy(a), torch.from_numpy(b))
+            mk1, mk2, sc, valid = extract(p, k1, k2)
+            core = p[0, :k, :k]
+            rmax, rarg = core.max(1)
+            carg = core.max(0)[1]
+            ii = torch.arange(k)
+            mutual = (carg[rarg] == ii) & (rmax >= mnn["threshold"])
+            idx = ii[mutual]
+            order = torch.argsort(rmax[idx], descending=True, stable=True)
+            idx = idx[order]
+            m = torch.full((k, 5), -1.0)
+            m[:len(idx), 0:2] = k1[0, idx]
+            m[:len(idx), 2:4] = k2[0, rarg[idx]]
+            m[:len(idx), 4] = rmax[idx]
+            rows["mk1"].append(mk1[0].numpy()); rows["mk2"].append(mk2[0].numpy())
+            rows["mscores"].append(sc[0].numpy()); rows["mvalid"].append(valid[0].numpy())
+            rows["mutual"].append(m.numpy()); rows["n_mutual"].append(len(idx))
+            rows["kpts_sha"].append(sha(np.concatenate([k1.numpy(), k2.numpy()])))
+            print(f"  pair {i}: {len(idx)} mutual matches", flush=True)
+    save("bench_seeds_matches", first_seed=1000, pairs=n, h=h, w=w, k=k, cfg=np.array(repr(EXPORT_CFG)),
+         mnn_cfg=np.array(repr(mnn)), mk1=np.stack(rows["mk1"]), mk2=np.stack(rows["mk2"]),
+         mscores=np.stack(rows["mscores"]), mvalid=np.stack(rows["mvalid"]), mutual=np.stack(rows["mutual"]),
+         n_mutual=np.array(rows["n_mutual"], np.int32), kpts_sha=np.array(rows["kpts_sha"]))
+    # ---- (2)
+    seed, pairs = 4300, 512
+    cfg = dict(max_keypoints=k, block_size=3, num_pairs=pairs, binarize=True, soft_binarize=False, sinkhorn_iterations=20,
+               epsilon=0.05, unused_score=1.0, distance_type="l2", nms_radius=5, score_threshold=0.0,
+               normalize_descriptors=True)
+    a, b = synth_batch(seed, 1, h, w)
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    mm = ShiTomasiBADSinkhornMatcher(**cfg).eval()
+    with torch.no_grad():
+        k1, k2, p = mm(ta, tb)
+        out = dict(seed=seed, h=h, w=w, k=k, cfg=np.array(repr(cfg)), k1=k1.numpy(), k2=k2.numpy())
+        raw = BADDescriptor(num_pairs=pairs, binarize=False).eval()
+        for tag, im, kp in (("1", ta, k1), ("2", tb, k2)):
+            _, dmap = mm.detector(im)
+            d = mm._extract_descriptors_at_keypoints_batched(dmap, kp)
+            del dmap
+            out["bits" + tag] = pack(d.numpy() > 0.5)
+            out["bits_exactly_01" + tag] = bool(((d == 0) | (d == 1)).all())
+            rmap = raw(im)
+            r = mm._extract_descriptors_at_keypoints_batched(rmap, kp).numpy().astype(np.float32)
+            del rmap
+            near = np.argwhere(np.abs(r) < 4.0)
+            out["near_idx" + tag] = near.astype(np.int32)
+            out["near_val" + tag] = r[tuple(near.T)]
+        core = p[:, :k, :k]
+        rmax, rarg = core.max(2)
+        cmax, carg = core.max(1)
+        out.update(P_sha=np.array(sha(p.numpy())), P_rowsum=p.sum(-1).numpy(), P_colsum=p.sum(-2).numpy(),
+                   P_rowmax=rmax.numpy(), P_rowarg=rarg.numpy().astype(np.int32), P_colmax=cmax.numpy(),
+                   P_colarg=carg.numpy().astype(np.int32), P_dustcol=p[:, :, k].numpy(), P_dustrow=p[:, k, :].numpy(),
+                   P_rows_0_8=p[:, :8].numpy())
+        mk1, mk2, sc, valid = MutualNearestNeighborMatcher(**mnn)(p, k1, k2)
+        out.update(mnn_cfg=np.array(repr(mnn)), mk1=mk1.numpy(), mk2=mk2.numpy(), mscores=sc.numpy(), mvalid=valid.numpy())
+    save("dense_c3_480x640_k512", **out)
+
+
 if __name__ == "__main__":
-    if "--round2-only" in sys.argv:
+    if "--round3-only" in sys.argv:
+        round3()
+    elif "--round2-only" in sys.argv:
         round2()
     elif "--dense-only" in sys.argv:
         dense()

@@ -89,3 +89,31 @@ ALLOW = _Allow({
     "gpu_bilinear_int_vs_oracle": 0, "gpu_bilinear_int_vs_reference": 0, "gpu_bilinear_frac_vs_oracle": 0,
     "gpu_bilinear_frac_vs_reference": 0, "gpu_bilinear_ori_vs_oracle": 0, "gpu_bilinear_ori_vs_reference": 0,
 })
+
+
+def match_dict(mk1, mk2, scores, valid) -> dict:
+    """{(y1, x1, y2, x2): score} of the valid matches of ONE pair."""
+    return {(*map(float, a), *map(float, b)): float(s) for a, b, s, v in zip(mk1, mk2, scores, valid) if v}
+
+
+def check_match_sets(got: dict, want: dict, max_matches: int, tol: float = 1e-4, mutual: dict | None = None) -> str:
+    """Match-set parity of one pair, strictly.  Equal sets with scores within `tol`: "same".
+    Otherwise the ONLY legitimate difference is a tie at the max_matches cut: both sets are full, and every match that
+    is in one set but not the other has a score within `tol` of the cut score (the smallest kept score) -- two scores
+    closer than the parity bound may swap places there.  `mutual`: the reference's complete set of mutual matches
+    above the threshold with their scores; when given, a match only `got` has must be one of them, with the same score
+    to `tol`.  Returns "same" or "cut"; anything else is an AssertionError naming the offending matches."""
+    for k in set(got) & set(want):
+        assert abs(got[k] - want[k]) <= tol, f"score of {k}: {got[k]} vs {want[k]}"
+    if set(got) == set(want):
+        return "same"
+    assert len(got) == max_matches and len(want) == max_matches, \
+        f"sets differ ({sorted(set(got) ^ set(want))}) without both being full: {len(got)} / {len(want)} of {max_matches}"
+    cut = min(min(got.values()), min(want.values()))
+    both = {**want, **got}
+    odd = {k: both[k] for k in set(got) ^ set(want) if both[k] > cut + tol}
+    assert not odd, f"matches differ away from the cut score {cut}: {odd}"
+    if mutual is not None:
+        for k in set(got) - set(want):
+            assert k in mutual and abs(mutual[k] - got[k]) <= tol, f"{k} (score {got[k]}) is not a mutual match of the reference"
+    return "cut"
