@@ -44,6 +44,14 @@ MI_API int mi_debug_bad_plan_passes(const uint32_t *pair_geom_host, int num_pair
  * host decision function the library applies to the occupancy query's answer.  Host only, no GPU. */
 MI_API int mi_debug_sinkhorn_dots_form(int batch, int n, int m, int flags, int blocks_per_cu, int cus);
 
+/* Exhaustive check of the fused AKAZE kernel's exact-rounding helpers (csrc/akaze_math.h) against the IEEE operators:
+ * every float whose bit pattern lies in [lo_bits, hi_bits) is tried; which = 0: sqrt, 1: x / kappa through the
+ * precomputed correctly rounded reciprocal, 2: 1 / x, 3: the general x / kappa sequence.  *mismatches_u64 (device,
+ * zeroed by the caller) receives the number of differing results, *first_bad_u32 (device, preset to 0xFFFFFFFF) the
+ * smallest offending bit pattern. */
+MI_API int mi_debug_akaze_math_check(int which, float kappa, uint32_t lo_bits, uint32_t hi_bits, void *mismatches_u64,
+                                     void *first_bad_u32, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,7 +98,8 @@ SIGNATURES["mi_match_pairs"] = [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.
 # not part of the product ABI; nothing in this package calls them
 DEBUG_SIGNATURES = {"mi_debug_set": [c_int, c_int], "mi_debug_topk_stamps": [c_void_p], "mi_debug_clock_probe": [c_void_p],
                     "mi_debug_bad_plan_passes": [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
-                    "mi_debug_sinkhorn_dots_form": [c_int, c_int, c_int, c_int, c_int, c_int]}
+                    "mi_debug_sinkhorn_dots_form": [c_int, c_int, c_int, c_int, c_int, c_int],
+                    "mi_debug_akaze_math_check": [c_int, c_float, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p]}
 SIGNATURES["mi_match_pairs_u8"] = SIGNATURES["mi_match_pairs"]
 _RESTYPE = {"mi_sinkhorn_dots_status_word": c_void_p, "mi_match_pairs_workspace_bytes": c_size_t, "mi_error_string": c_char_p, "mi_sinkhorn_workspace_bytes": c_size_t, "mi_bad_plan_bytes": c_size_t,
             "mi_sinkhorn_dots_workspace_bytes": c_size_t, "mi_mnn_duals_workspace_bytes": c_size_t}

@@ -37,7 +37,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # at half rate on gfx950 and need extra moves to pair operands (+18 % VALU slots measured).
 # -save-temps=obj keeps corner's gfx950 assembly next to its object: tests/test_k1_isa.py lints the hand-scheduled
 # region of the ticket kernel in it (CPU only).
-EXTRA_FLAGS = {"corner.hip": ["-fno-slp-vectorize", "-save-temps=obj"]}
+EXTRA_FLAGS = {"corner.hip": ["-fno-slp-vectorize", "-save-temps=obj"], "akaze.hip": ["-fno-slp-vectorize"]}
 # -Bsymbolic: calls between the library's own entry points bind inside the library (two builds of the same ABI can be
 # loaded into one process -- product and debug -- without one's calls landing in the other)
 LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic",

@@ -14,6 +14,7 @@
 // of two, so scaling before or after the sum rounds identically.
 // 64x16 tiles through LDS, four pixels per thread; the NMS window maximum is separable (rows, then columns).
 #include "common.h"
+#include "akaze_math.h"
 
 #include <math.h>
 
@@ -236,28 +237,7 @@ __global__ __launch_bounds__(256) void combine_kp_kernel(const float *__restrict
 constexpr int AS_H = MI_AS_H;            // output tile height; its width is 64 - 2 * halo (see the kernel)
 constexpr int AS_WAVES = MI_AS_WAVES;    // waves per workgroup: each phase splits its rows into this many blocks
 
-// Correctly rounded fp32 sqrt and division for the operand ranges of the diffusion step (normal, finite, far from
-// overflow: |g| <= ~255, kappa and 1 + q^2 >= 1e-4), i.e. the compiler's IEEE expansions without their denormal
-// scaling and special-case fix-ups: v_sqrt_f32 / v_rcp_f32 (1 ulp) + exact fma residuals.  Same results as
-// sqrtf() and operator/ on these ranges (asserted against the per-step kernels, which use those, bit for bit).
-__device__ __forceinline__ float ak_sqrt(float x) {
-  const float s = __builtin_amdgcn_sqrtf(x);
-  const float lo = __uint_as_float(__float_as_uint(s) - 1u), hi = __uint_as_float(__float_as_uint(s) + 1u);
-  const float rl = __builtin_fmaf(-lo, s, x), rh = __builtin_fmaf(-hi, s, x);
-  float r = (rl <= 0.0f) ? lo : s;
-  r = (rh > 0.0f) ? hi : r;
-  return r;
-}
-__device__ __forceinline__ float ak_div(float a, float b) {
-  float y = __builtin_amdgcn_rcpf(b);
-  const float e = __builtin_fmaf(-b, y, 1.0f);
-  y = __builtin_fmaf(e, y, y);                       // reciprocal to < 1 ulp
-  float q = a * y;
-  float r = __builtin_fmaf(-b, q, a);                // exact residual
-  q = __builtin_fmaf(r, y, q);
-  r = __builtin_fmaf(-b, q, a);                      // second correction: the compiler's own sequence
-  return __builtin_fmaf(r, y, q);                    // (v_div_fmas without the scaling)
-}
+// (the exact-rounding helpers ak_sqrt / ak_div / ak_div_by / ak_rcp live in akaze_math.h)
 
 template <int ITERS, int NH>
 __global__ __launch_bounds__(64 * AS_WAVES) void akaze_scale_kernel(const float *__restrict__ lin, int h, int w, float kappa,
@@ -278,19 +258,32 @@ __global__ __launch_bounds__(64 * AS_WAVES) void akaze_scale_kernel(const float 
   const int x0 = txi * TW - HALO, y0 = tyi * AS_H - HALO;            // global coordinates of L[0][0]
   const float *src = lin + (size_t)img * h * w;
   // thread = (column tx, row group ty): a wave handles one staged row per instruction, rows ty, ty + 4, ...
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  // (ty is wave-uniform: kept in an SGPR so that every row index, row bound and row predicate below is scalar work)
+  const int tx = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // the image rows / columns the tile covers, in tile coordinates: [ry0, ry1) x [cx0, cx1) lies inside the image
   const int ry0 = max(0, -y0), ry1 = min(LH, h - y0), cx0 = max(0, -x0), cx1 = min(LW, w - x0);
-  for (int r = ty; r < LH; r += AS_WAVES) {
-    const bool rin = r >= ry0 && r < ry1;
-    const float *row = src + (size_t)(y0 + r) * w + x0;
-    L[r][tx] = (rin && tx >= cx0 && tx < cx1) ? row[tx] : 0.0f;
+  // staging: ALL of a lane's rows are requested before the first one is used -- branch-free loads from clamped (always
+  // valid) addresses, the zero padding applied afterwards.  With the load inside the `inside the image` branch every row
+  // was its own round trip to memory: 9 dependent round trips = 10.4 k of a tile's 43.8 k clocks (in-kernel stamps).
+  {
+    constexpr int NST = (LH + AS_WAVES - 1) / AS_WAVES;
+    const float *col = src + clampi(x0 + tx, 0, w - 1);
+    const bool cin = tx >= cx0 && tx < cx1;
+    float v[NST];
+#pragma unroll
+    for (int q = 0; q < NST; ++q) v[q] = col[(size_t)clampi(y0 + ty + q * AS_WAVES, 0, h - 1) * w];
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {
+      const int r = ty + q * AS_WAVES;
+      if (r < LH) L[r][tx] = (cin && r >= ry0 && r < ry1) ? v[q] : 0.0f;
+    }
   }
   __syncthreads();
   // Row blocks: every phase hands each of the 4 waves a contiguous block of rows and walks down it with the rows
   // above and below in registers (3 new LDS reads per flux value instead of 8, 5 + 1 per update instead of 12 + 1),
   // the next row's loads issued before the current row's arithmetic.
   const int c = tx;
+  const float rkappa = 1.0f / kappa;                  // IEEE division: the correctly rounded reciprocal (ak_div_by)
 #pragma unroll
   for (int s = 0; s < ITERS; ++s) {
     // flux on rows / columns [2s+1, L? - 2s - 1): needs L one ring further out
@@ -300,26 +293,26 @@ __global__ __launch_bounds__(64 * AS_WAVES) void akaze_scale_kernel(const float 
       if (c >= f0 && c < LW - f0 && rbeg < rend) {
         const bool cin = c >= cx0 && c < cx1;
         float t0 = L[rbeg - 1][c - 1], t1 = L[rbeg - 1][c], t2 = L[rbeg - 1][c + 1];
-        float m0 = L[rbeg][c - 1], m2 = L[rbeg][c + 1];
+        float m0 = L[rbeg][c - 1], m1 = L[rbeg][c], m2 = L[rbeg][c + 1];
         float b0 = L[rbeg + 1][c - 1], b1 = L[rbeg + 1][c], b2 = L[rbeg + 1][c + 1];
+        // straight-line body (no branch per row: the scheduler can overlap one row's square root / reciprocal chain with
+        // the next row's stencil): the row below the next one is always fetched (clamped to the tile), the flux is
+        // computed for every lane and row and zeroed by a select where the pixel lies outside the image
         for (int r = rbeg; r < rend; ++r) {
-          float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
-          if (r + 1 < rend) { n0 = L[r + 2][c - 1]; n1 = L[r + 2][c]; n2 = L[r + 2][c + 1]; }   // next row, early
-          float fx = 0.0f, fy = 0.0f;
-          if (cin && r >= ry0 && r < ry1) {                                // the flux is zero-padded outside the image
-            const float gxv = (((((t2 - t0) - 2.0f * m0) + 2.0f * m2) - b0) + b2) * 0.125f;          // akaze.py:50-63,82
-            const float gyv = ((((((-t0) - 2.0f * t1) - t2) + b0) + 2.0f * b1) + b2) * 0.125f;
-            const float mag = ak_sqrt(gxv * gxv + gyv * gyv + 1e-8f);                             // :116
-            const float q = ak_div(mag, kappa);
-            const float cond = ak_div(1.0f, 1.0f + q * q);                                        // :96
-            fx = cond * gxv;
-            fy = cond * gyv;
-          }
+          const int rn = min(r + 2, LH - 1);
+          const float n0 = L[rn][c - 1], n1 = L[rn][c], n2 = L[rn][c + 1];                          // next row, early
+          const bool inside = cin && r >= ry0 && r < ry1;                   // the flux is zero-padded outside the image
+          const float gxv = (((((t2 - t0) - 2.0f * m0) + 2.0f * m2) - b0) + b2) * 0.125f;          // akaze.py:50-63,82
+          const float gyv = ((((((-t0) - 2.0f * t1) - t2) + b0) + 2.0f * b1) + b2) * 0.125f;
+          const float mag = ak_sqrt_fp<1>(gxv * gxv + gyv * gyv + 1e-8f);                       // :116
+          const float q = ak_div_by(mag, kappa, rkappa);
+          const float cond = ak_rcp(1.0f + q * q);                                              // :96
+          const float fx = inside ? cond * gxv : 0.0f;
+          const float fy = inside ? cond * gyv : 0.0f;
           FX[r][c] = fx;
           FY[r][c] = fy;
-          t0 = m0; t2 = m2;
-          t1 = L[r][c];                                 // (the centre of the row that becomes the top row)
-          m0 = b0; m2 = b2;
+          t0 = m0; t1 = m1; t2 = m2;
+          m0 = b0; m1 = b1; m2 = b2;
           b0 = n0; b1 = n1; b2 = n2;
         }
       }
@@ -355,33 +348,39 @@ __global__ __launch_bounds__(64 * AS_WAVES) void akaze_scale_kernel(const float 
     if (c >= HALO && c < HALO + TW && c < cx1) lout[((size_t)img * h + (y0 + r)) * w + (x0 + c)] = L[r][c];
   }
   constexpr int R0 = 2 * ITERS + 1;
-#pragma unroll 2
-  for (int r = R0 + ty; r < LH - R0; r += AS_WAVES) {
-    const bool rin = r >= ry0 && r < ry1;
-    {
-      const int c = tx;
-      if (c < R0 || c >= LW - R0) continue;
-      float resp = -INFINITY;
-      if (rin && c >= cx0 && c < cx1) {
-        const float a = L[r - 1][c - 1], b = L[r - 1][c], cc = L[r - 1][c + 1], d = L[r][c - 1], e = L[r][c],
-                    f = L[r][c + 1], g = L[r + 1][c - 1], hh = L[r + 1][c], k = L[r + 1][c + 1];
-        const float lxx = ((((((((a - 2.0f * b) + cc) + 2.0f * d) - 4.0f * e) + 2.0f * f) + g) - 2.0f * hh) + k) * 0.0625f;
-        const float lyy = ((((((((a + 2.0f * b) + cc) - 2.0f * d) - 4.0f * e) - 2.0f * f) + g) + 2.0f * hh) + k) * 0.0625f;
-        const float lxy = (((a - cc) - g) + k) * 0.25f;
-        resp = lxx * lyy - lxy * lxy;                                                          // :196
-      }
-      FX[r][c] = resp;
-    }
-  }
-  __syncthreads();
-  // window maximum, separable: along the rows (tile columns only), then down the columns
-  for (int r = R0 + ty; r < LH - R0; r += AS_WAVES) {
-    const int c = tx;
-    if (c < HALO || c >= HALO + TW) continue;
-    float mx = FX[r][c - NH];
+  // Hessian determinant and its row-window maximum in ONE phase: a wave walks a contiguous block of rows with the 3 x 3
+  // window of L sliding through registers (3 new LDS reads per row instead of 9), writes the row of responses to FX and
+  // reads the row's neighbours straight back -- the row was written by this very wave, whose LDS operations execute in
+  // order, so no workgroup barrier is needed; the empty asm keeps the COMPILER from moving the reads above the write
+  // (per thread the addresses differ, so it otherwise may).
+  {
+    constexpr int nrows = LH - 2 * R0, per = (nrows + AS_WAVES - 1) / AS_WAVES;
+    const int rbeg = R0 + ty * per, rend = min(rbeg + per, LH - R0);
+    if (c >= R0 && c < LW - R0 && rbeg < rend) {
+      const bool cin = c >= cx0 && c < cx1;
+      const bool ctile = c >= HALO && c < HALO + TW;
+      float t0 = L[rbeg - 1][c - 1], t1 = L[rbeg - 1][c], t2 = L[rbeg - 1][c + 1];
+      float m0 = L[rbeg][c - 1], m1 = L[rbeg][c], m2 = L[rbeg][c + 1];
+      for (int r = rbeg; r < rend; ++r) {
+        const float b0 = L[r + 1][c - 1], b1 = L[r + 1][c], b2 = L[r + 1][c + 1];
+        const float lxx = ((((((((t0 - 2.0f * t1) + t2) + 2.0f * m0) - 4.0f * m1) + 2.0f * m2) + b0) - 2.0f * b1) + b2) * 0.0625f;
+        const float lyy = ((((((((t0 + 2.0f * t1) + t2) - 2.0f * m0) - 4.0f * m1) - 2.0f * m2) + b0) + 2.0f * b1) + b2) * 0.0625f;
+        const float lxy = (((t0 - t2) - b0) + b2) * 0.25f;
+        const float det = lxx * lyy - lxy * lxy;                                                  // :196
+        const float resp = (cin && r >= ry0 && r < ry1) ? det : -INFINITY;   // -inf outside the image: the pool's padding
+        FX[r][c] = resp;
+        asm volatile("" ::: "memory");
+        if (ctile) {
+          float mx = FX[r][c - NH];
 #pragma unroll
-    for (int d = 1; d <= 2 * NH; ++d) mx = fmaxf(mx, FX[r][c - NH + d]);
-    FY[r][c] = mx;
+          for (int d = 1; d <= 2 * NH; ++d) mx = fmaxf(mx, FX[r][c - NH + d]);
+          FY[r][c] = mx;
+        }
+        asm volatile("" ::: "memory");
+        t0 = m0; t1 = m1; t2 = m2;
+        m0 = b0; m1 = b1; m2 = b2;
+      }
+    }
   }
   __syncthreads();
   for (int r = HALO + ty; r < min(HALO + AS_H, ry1); r += AS_WAVES) {

@@ -50,3 +50,41 @@ MI_API int mi_debug_bad_plan_passes(const uint32_t *pair_geom_host, int num_pair
 MI_API int mi_debug_sinkhorn_dots_form(int batch, int n, int m, int flags, int blocks_per_cu, int cus) {
   return mi_sinkhorn_dots_form_host(batch, n, m, flags, blocks_per_cu, cus);
 }
+
+// ---- exhaustive check of csrc/akaze_math.h against the IEEE operators (tests/test_gpu_parity.py) -----------------
+#include "akaze_math.h"
+namespace {
+// which: 0 = ak_sqrt(x) vs sqrtf(x); 1 = ak_div_by(x, kappa, 1 / kappa) vs x / kappa; 2 = ak_rcp(x) vs 1 / x;
+// 3 = ak_div(x, kappa) vs x / kappa; 4 / 5 = ak_sqrt_fp<1> / <2>(x) vs sqrtf(x).  Every float with bit pattern in [lo_bits, hi_bits) is tried.
+__global__ __launch_bounds__(256) void akaze_math_check_kernel(int which, float kappa, uint32_t lo_bits, uint32_t hi_bits,
+                                                               unsigned long long *mismatches, uint32_t *first_bad) {
+  const float rk = 1.0f / kappa;
+  unsigned long long bad = 0;
+  for (unsigned long long b = (unsigned long long)lo_bits + blockIdx.x * 256ull + threadIdx.x; b < hi_bits;
+       b += (unsigned long long)gridDim.x * 256ull) {
+    const float x = __uint_as_float((uint32_t)b);
+    float got, want;
+    if (which == 0) { got = ak_sqrt(x); want = sqrtf(x); }
+    else if (which == 1) { got = ak_div_by(x, kappa, rk); want = x / kappa; }
+    else if (which == 2) { got = ak_rcp(x); want = 1.0f / x; }
+    else if (which == 3) { got = ak_div(x, kappa); want = x / kappa; }
+    else if (which == 4) { got = ak_sqrt_fp<1>(x); want = sqrtf(x); }
+    else { got = ak_sqrt_fp<2>(x); want = sqrtf(x); }
+    if (__float_as_uint(got) != __float_as_uint(want)) {
+      ++bad;
+      atomicMin(first_bad, (uint32_t)b);
+    }
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+}  // namespace
+
+MI_API int mi_debug_akaze_math_check(int which, float kappa, uint32_t lo_bits, uint32_t hi_bits, void *mismatches_u64,
+                                     void *first_bad_u32, mi_stream_t stream) {
+  MI_ENTER();
+  if (!mismatches_u64 || !first_bad_u32) return MI_E_NULL;
+  if (which < 0 || which > 5 || !(kappa > 0.0f) || lo_bits >= hi_bits) return MI_E_PARAM;
+  hipLaunchKernelGGL(akaze_math_check_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, which, kappa, lo_bits, hi_bits,
+                     reinterpret_cast<unsigned long long *>(mismatches_u64), reinterpret_cast<uint32_t *>(first_bad_u32));
+  return mi_launch_status();
+}

@@ -117,6 +117,16 @@ __device__ __forceinline__ void bitonic_sort_desc_4096(uint64_t *keys, uint64_t 
   __syncthreads();
 }
 
+// BIG = false: 73 KB of LDS, two workgroups per CU -- images whose candidates are expected to fit the LDS key array
+// (640x480: ~3,300).  BIG = true (large images; chosen on the host by the segment count): ONE 128 KB LDS region that
+// first holds the 32-bit SCORES of up to TK_BIG_MAX candidates -- the k-th largest score is then found by a radix
+// select that never leaves LDS, and one more pass over the candidate lists gathers the keys at or above it into the
+// key array (which reuses the region) -- instead of up to eight dependent passes over global memory plus a gather:
+// 1080p, K = 1024, ~22,000 candidates per image: 148 -> ~50 us per 128 images.  Every path returns the k largest keys
+// in descending order; keys are distinct, so the result does not depend on the path.
+constexpr int TK_BIG_MAX = 32768;    // scores the big kernel's LDS region holds (128 KB)
+
+template <bool BIG>
 __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__restrict__ cand,
                                                           const uint32_t *__restrict__ count, int segments,
                                                           uint32_t seg_cap, int w, int k, MiSets kpt_sets,
@@ -124,8 +134,10 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
                                                           unsigned long long *prof) {
 #define TK_STAMP(i) do { if (prof && blockIdx.x == 0 && threadIdx.x == 0) prof[i] = wall_clock64(); } while (0)
   TK_STAMP(0);
-  __shared__ uint64_t keys[TK_MAX];
-  __shared__ uint64_t keys2[TK_MAX];      // second buffer of the register sort's cross-wave stages
+  __shared__ uint64_t raw[BIG ? TK_BIG_MAX / 2 : 2 * TK_MAX];
+  uint64_t *const keys = raw;
+  uint64_t *const keys2 = raw + TK_MAX;   // second buffer of the register sort's cross-wave stages
+  uint32_t *const scores = reinterpret_cast<uint32_t *>(raw);   // BIG: the candidates' scores, before the keys move in
   __shared__ uint32_t seg_cnt[TK_SEGS], seg_base[TK_SEGS];
   __shared__ uint32_t hist[256];
   __shared__ uint32_t wsum[TK_WAVES];
@@ -162,9 +174,118 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
   int nsel;
   TK_STAMP(1);
 
-  if (n <= (uint32_t)TK_MAX && slots) {
+  // ---- BIG: more candidates than the key array holds, but their scores fit the LDS region
+  bool in_lds = false;                    // the keys to choose from are already in keys[0..n)
+  if (BIG && slots && n > (uint32_t)TK_MAX && n <= (uint32_t)TK_BIG_MAX && k <= TK_MAX) {
+    // (a) scores into LDS: a wave takes eight segments at a time, all loads in flight before the first LDS store
+    for (int s0 = wave * 8; s0 < segments; s0 += TK_WAVES * 8) {
+      uint64_t v[8];
+      uint32_t c[8], base[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int sg = s0 + q;
+        c[q] = sg < segments ? seg_cnt[sg] : 0u;
+        base[q] = sg < segments ? seg_base[sg] : 0u;
+        v[q] = 0ull;
+        if ((uint32_t)lane < c[q]) v[q] = list[(size_t)sg * seg_cap + lane];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if ((uint32_t)lane < c[q]) scores[base[q] + lane] = (uint32_t)(v[q] >> 32);
+        for (uint32_t i = 64 + lane; i < c[q]; i += 64) scores[base[q] + i] = (uint32_t)(list[(size_t)(s0 + q) * seg_cap + i] >> 32);
+      }
+    }
+    if (t == 0) { s_prefix = 0ull; s_krem = (uint32_t)k; s_done = 0u; }
+    __syncthreads();
+    // (b) the k-th largest SCORE by MSB radix select over the LDS copy (scores repeat; the keys do not)
+    uint32_t mask32 = 0u;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (t < 256) hist[t] = 0u;
+      __syncthreads();
+      const uint32_t prefix = (uint32_t)s_prefix;
+      for (uint32_t i0 = 0; i0 < n; i0 += TK_THREADS) {
+        const uint32_t i = i0 + t;
+        const uint32_t sc = i < n ? scores[i] : 0u;
+        const bool act = i < n && ((sc & mask32) == prefix);
+        const uint32_t digit = (sc >> shift) & 255u;
+        const unsigned long long am = __ballot(act);
+        if (am) {                                                // wave-level aggregation, as in the key select below
+          const int leader = __ffsll((long long)am) - 1;
+          const uint32_t d0 = __shfl(digit, leader, 64);
+          const unsigned long long same = __ballot(act && digit == d0);
+          if (lane == leader) atomicAdd(&hist[d0], (uint32_t)__popcll(same));
+          if (act && digit != d0) atomicAdd(&hist[digit], 1u);
+        }
+      }
+      __syncthreads();
+      if (t < 64) {
+        const uint32_t krem = s_krem;
+        uint32_t c[4], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { c[q] = hist[255 - 4 * t - q]; tot += c[q]; }
+        uint32_t incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t up = __shfl_up(incl, o, 64);
+          if (t >= o) incl += up;
+        }
+        uint32_t above = incl - tot;
+        if (above < krem && krem <= incl) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (krem <= above + c[q]) {
+              s_prefix = (uint64_t)(prefix | ((uint32_t)(255 - 4 * t - q) << shift));
+              s_krem = krem - above;
+              s_fill = c[q];                                     // keys in the chosen bin
+              if (krem - above == c[q]) s_done = 1u;             // the whole bin is wanted: no further digit needed
+              break;
+            }
+            above += c[q];
+          }
+        }
+      }
+      mask32 |= (0xFFu << shift);
+      __syncthreads();
+      if (s_done) break;                                         // workgroup-uniform
+    }
+    // Every key whose score is >= `floor32` is a candidate for the k places: the k - s_krem keys above the chosen bin
+    // plus the bin's s_fill keys, of which s_krem are wanted (all of them unless scores tie exactly at the k-th place).
+    const uint32_t floor32 = (uint32_t)s_prefix;                 // digits below the last pass are zero
+    const uint32_t n2 = ((uint32_t)k - s_krem) + s_fill;
+    __syncthreads();                                             // everybody has read s_prefix / s_krem / s_fill; scores are dead
+    if (n2 <= (uint32_t)TK_MAX) {
+      // (c) gather those keys from the lists into the key array (which now takes over the region)
+      if (t == 0) s_fill = 0u;
+      __syncthreads();
+      for (int s0 = wave * 8; s0 < segments; s0 += TK_WAVES * 8) {
+        uint64_t v[8];
+        uint32_t c[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int sg = s0 + q;
+          c[q] = sg < segments ? seg_cnt[sg] : 0u;
+          v[q] = 0ull;
+          if ((uint32_t)lane < c[q]) v[q] = list[(size_t)sg * seg_cap + lane];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if ((uint32_t)lane < c[q] && (uint32_t)(v[q] >> 32) >= floor32) keys[atomicAdd(&s_fill, 1u)] = v[q];
+          for (uint32_t i = 64 + lane; i < c[q]; i += 64) {
+            const uint64_t key = list[(size_t)(s0 + q) * seg_cap + i];
+            if ((uint32_t)(key >> 32) >= floor32) keys[atomicAdd(&s_fill, 1u)] = key;
+          }
+        }
+      }
+      __syncthreads();
+      n = s_fill;                                                // == n2: k <= n <= TK_MAX keys to choose from, in keys[]
+      in_lds = true;
+    }
+    __syncthreads();
+  }
+
+  if (in_lds || (n <= (uint32_t)TK_MAX && slots)) {
     // gather: a wave takes four segments at a time, all their loads in flight before the first LDS store
-    for (int s0 = wave * 4; s0 < segments; s0 += TK_WAVES * 4) {
+    for (int s0 = wave * 4; !in_lds && s0 < segments; s0 += TK_WAVES * 4) {
       uint64_t v[4];
       uint32_t c[4], base[4];
 #pragma unroll
@@ -185,7 +306,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
     while (npad < (int)n) npad <<= 1;
     __syncthreads();
     TK_STAMP(2);
-    if (select_mode && n > (uint32_t)k && 4 * k <= TK_MAX) {
+    if ((select_mode || in_lds) && n >= (uint32_t)k && 4 * k <= TK_MAX && (n > (uint32_t)k || in_lds)) {
       // Far fewer keys are wanted than there are candidates (512 of ~3300 at 640x480): find the k-th largest key
       // by MSB radix select on register copies of the LDS keys (at most 8 passes of 8 bits, typically 4: the
       // passes stop as soon as a whole bin is wanted), move the k winners to the second buffer and sort only
@@ -195,7 +316,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
       for (int q = 0; q < 4; ++q) r[q] = (uint32_t)(t + q * TK_THREADS) < n ? keys[t + q * TK_THREADS] : 0ull;
       if (t == 0) { s_prefix = 0ull; s_krem = (uint32_t)k; s_fill = 0u; s_done = 0u; }
       uint64_t mask = 0ull;
-      for (int shift = 56; shift >= 0; shift -= 8) {
+      // n == k (the usual outcome of the big kernel's score select): every key is a winner, nothing to select
+      for (int shift = n == (uint32_t)k ? -8 : 56; shift >= 0; shift -= 8) {
         if (t < 256) hist[t] = 0u;
         __syncthreads();
         const uint64_t prefix = s_prefix;
@@ -244,6 +366,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_kernel(const uint64_t *__rest
         __syncthreads();
         if (s_done) break;                // workgroup-uniform
       }
+      if (n == (uint32_t)k) __syncthreads();   // (no pass ran: thread 0's reset of s_prefix / s_fill must still be seen)
       const uint64_t kth = s_prefix;      // keys are distinct: exactly k keys are >= kth
       TK_STAMP(3);
 #pragma unroll
@@ -454,9 +577,19 @@ int mi_topk_keypoints_sets(const uint64_t *cand, const uint32_t *count, int segm
   if (n <= 0 || w <= 0 || segments <= 0) return MI_E_SHAPE;
   if (k <= 0 || k > TK_MAX) return MI_E_PARAM;
   if (segment_capacity <= 0) return MI_E_CAPACITY;
-  hipLaunchKernelGGL(topk_kernel, dim3(n), dim3(TK_THREADS), 0, (hipStream_t)stream, cand, count, segments,
-                     (uint32_t)segment_capacity, w, k, keypoints, kscores, MI_HOOK(topk_select, 1),
-                     MI_HOOK(topk_prof, (unsigned long long *)nullptr));
+  // the big-LDS kernel for large images (one workgroup per CU; see the kernel's note): more than 150 tiles of 128 x 32
+  // pixels (~0.6 Mpx) are expected to yield more candidates than the small kernel's key array holds.  Either kernel is
+  // correct for any input; the choice is a matter of speed (test hook key 10 forces one of them).
+  const int choice = MI_HOOK(topk_split, -1);
+  const bool big = choice < 0 ? segments > 150 : choice != 0;
+  if (big)
+    hipLaunchKernelGGL(topk_kernel<true>, dim3(n), dim3(TK_THREADS), 0, (hipStream_t)stream, cand, count, segments,
+                       (uint32_t)segment_capacity, w, k, keypoints, kscores, MI_HOOK(topk_select, 1),
+                       MI_HOOK(topk_prof, (unsigned long long *)nullptr));
+  else
+    hipLaunchKernelGGL(topk_kernel<false>, dim3(n), dim3(TK_THREADS), 0, (hipStream_t)stream, cand, count, segments,
+                       (uint32_t)segment_capacity, w, k, keypoints, kscores, MI_HOOK(topk_select, 1),
+                       MI_HOOK(topk_prof, (unsigned long long *)nullptr));
   return mi_launch_status();
 }
 

@@ -142,6 +142,46 @@ def test_topk_plateaus_vs_oracle(mods):
         assert np.array_equal(kp.cpu().numpy(), kp_ref) and np.array_equal(sc.cpu().numpy(), sc_ref)
 
 
+def test_topk_big_kernel_equals_small_kernel_and_oracle(mods):
+    """Large images run top-k with the scores of up to 32,768 candidates resident in LDS (topk_kernel<BIG>: score select in
+    LDS, one gather, merge-rank sort) instead of eight passes over global memory.  Both kernels (test hook key 10) must
+    return the same keypoints and scores, and the oracle's, on: a 1080p corner map (~22 k candidates; k = 1024, 512,
+    100 and 2000 > 1024), a quantised map whose k-th place falls inside a run of EQUAL scores (the tie is broken by the
+    linear index, so the bin's keys go through the key select), a map with more than 4,096 keys tied at the k-th place
+    (falls back to the global-memory select), and a sparse map with fewer candidates than k."""
+    from onnx_image_processing_amd import _native as N, ops
+    a, _ = synth_batch(4100, 2, 1080, 1920)
+    sc = ops.corner_response(gpu(a), 3).squeeze(1)
+    quant = (sc / sc.amax() * 40.0).round()                     # 41 distinct values: long runs of equal scores
+    coarse = (sc > 0).float() * 3.0 + (sc > sc.mean()).float()  # 3 values: tens of thousands tied at the k-th place
+    sparse = torch.zeros_like(sc)
+    sparse[:, 100:900:40, 100:1800:50] = sc[:, 100:900:40, 100:1800:50] + 1.0      # 20 x 34 = 680 candidates per image
+    cases = ((sc, 5, (1024, 512, 100, 2000)), (quant, 5, (1024, 300)), (coarse, 3, (1024,)), (sparse, 5, (1024, 64)))
+    for scores, r, ks in cases:
+        ncand = int((ops.nms_mask(scores, r) * (scores > 0)).sum(dim=(1, 2)).max())
+        for k in ks:
+            with N.debug_library() as lib:
+                assert lib.mi_debug_set(10, 0) == 0
+                kp0, s0 = ops.nms_topk(scores, r, k, 0.0, 7)
+                assert lib.mi_debug_set(10, 1) == 0
+                kp1, s1 = ops.nms_topk(scores, r, k, 0.0, 7)
+            kp2, s2 = ops.nms_topk(scores, r, k, 0.0, 7)        # the product library (big kernel by segment count)
+            assert torch.equal(kp0, kp1) and torch.equal(s0, s1), (ncand, r, k)
+            assert torch.equal(kp1, kp2) and torch.equal(s1, s2), (ncand, r, k)
+        arr = scores[:1].cpu().numpy()
+        kp_ref, sc_ref, _ = O.select_topk_keypoints(arr, O.nms_mask(arr, r), ks[0], 0.0, 7)
+        kp, s_ = ops.nms_topk(scores[:1], r, ks[0], 0.0, 7)
+        assert np.array_equal(kp.cpu().numpy(), kp_ref) and np.array_equal(s_.cpu().numpy(), sc_ref), (ncand, r)
+    # the small images' kernel forced onto the big path's code and vice versa: 640x480 through the big kernel
+    b, _ = synth_batch(3100, 2, 480, 640)
+    sc = ops.corner_response(gpu(b), 3).squeeze(1)
+    with N.debug_library() as lib:
+        lib.mi_debug_set(10, 1)
+        kp1, s1 = ops.nms_topk(sc, 5, 512, 0.0, 7)
+    kp2, s2 = ops.nms_topk(sc, 5, 512, 0.0, 7)
+    assert torch.equal(kp1, kp2) and torch.equal(s1, s2)
+
+
 def test_topk_select_path_equals_full_sort(mods):
     """k << candidates: the radix-select + sort-k path and the full bitonic sort return the same keypoints and
     scores (640x480: ~3300 candidates per image, k = 512 and k = 100; a plateau map with massive ties too)."""
@@ -795,6 +835,30 @@ def test_akaze_fused_scale_equals_step_kernels(mods, shape):
             got_l, got_s = ops.akaze_scale(x, iters, kappa, 0.25, thr, nms)
             assert torch.equal(got_l, want_l) and torch.equal(got_s, want_s), (scale, iters, nms)
             assert int((got_s > 0).sum()) > 0 or scale != 1.0
+
+
+def test_akaze_fast_division_is_exact(mods):
+    """The fused AKAZE kernel's arithmetic helpers (csrc/akaze_math.h) against the IEEE operators, EXHAUSTIVELY over the
+    operand ranges of the diffusion step: ak_sqrt on [1e-8, 2^24] and the fp32-pipe form the kernel uses
+    (ak_sqrt_fp<1>: v_rsq_f32 + one exact-residual correction) on [1e-8, 2^64], x / kappa through the precomputed reciprocal
+    (Markstein's 3-instruction form) for several kappa on [2^-30, 2^24], 1 / d on [1, 2^40), and the general division.
+    ~1.8e9 evaluations; zero differing bit patterns allowed."""
+    import struct
+    from onnx_image_processing_amd import _native as N
+
+    def bits(x):
+        return struct.unpack("<I", struct.pack("<f", x))[0]
+
+    cases = [(0, 0.05, 1e-8, 2.0 ** 24), (4, 0.05, 1e-8, 2.0 ** 64), (2, 0.05, 1.0, 2.0 ** 40)]
+    cases += [(1, kappa, 2.0 ** -30, 2.0 ** 24) for kappa in (0.05, 0.03, 0.1, 0.7, 1.0, 3.0, 1e-3)]
+    cases += [(3, 0.05, 2.0 ** -30, 2.0 ** 24)]
+    with N.debug_library() as lib:
+        for which, kappa, lo, hi in cases:
+            bad = torch.zeros(1, dtype=torch.int64, device=DEV)
+            first = torch.full((1,), -1, dtype=torch.int32, device=DEV)
+            N.check(lib.mi_debug_akaze_math_check(which, kappa, bits(lo), bits(hi), bad.data_ptr(), first.data_ptr(),
+                                                  N.stream_ptr()), "mi_debug_akaze_math_check")
+            assert int(bad.item()) == 0, (which, kappa, int(bad.item()), hex(int(first.item()) & 0xFFFFFFFF))
 
 
 def test_akaze_c4_480x640_k512_golden(mods):

@@ -41,7 +41,8 @@ def test_binding_covers_the_header(lib_path):
     from onnx_image_processing_amd import _native
     assert sorted(_native.SIGNATURES) == header_functions()
     assert sorted(_native.DEBUG_SIGNATURES) == header_functions(DEBUG_HEADER) == [
-        "mi_debug_bad_plan_passes", "mi_debug_clock_probe", "mi_debug_set", "mi_debug_sinkhorn_dots_form", "mi_debug_topk_stamps"]
+        "mi_debug_akaze_math_check", "mi_debug_bad_plan_passes", "mi_debug_clock_probe", "mi_debug_set",
+        "mi_debug_sinkhorn_dots_form", "mi_debug_topk_stamps"]
     _native.load()
     with _native.debug_library() as dbg:                     # the debug build exports both headers
         assert dbg.mi_abi_version() == 2
