@@ -102,12 +102,12 @@ def step_stats(per_step_ms: list[float]) -> dict:
             "mean": statistics.fmean(per_step_ms)}
 
 
-def pmc_traffic(kernel_prefix: str, pairs_per_gpu: int):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*_bench_pmc_traffic.json:
+def pmc_traffic(kernel_prefix: str, pairs_per_gpu: int, workload: str = "bench"):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/*_<workload>_pmc_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this script at the recorded pairs per GPU, reads
     doubled per the gfx950 note).  None when no profile of this batch size exists."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_pmc_traffic.json")))
     for path in reversed(files):
         try:
             prof = json.load(open(path))
@@ -445,7 +445,7 @@ def side_workload(args, rank, world, dev) -> None:
         h, w, k = 1080, 1920, 1024
         base = ShiTomasiSparseBADSinkhornMatcher(max_keypoints=k, **CFG)
         what = "Shi-Tomasi sparse pipeline, 1920x1080, K=1024 (BASELINE configs[2])"
-        roof = ("mi_corner_response_balanced", "corner_stream_kernel<3,4> (mi_corner_response_balanced)", 8.0, 1)
+        roof = ("mi_corner_response_balanced", "corner_stream_kernel<3,4> (mi_corner_response_balanced)", 8.0, 1, "corner_stream_kernel<3,4,false>")
     elif args.workload == "c3dense":
         # BASELINE configs[2] in its "dense BAD cost matrix" reading: the reference's ShiTomasiBADSinkhornMatcher
         # (feature_detection/shi_tomasi_bad_sinkhorn.py:162-219) -- NMS / top-k WITHOUT border margin, descriptors = the dense
@@ -457,7 +457,7 @@ def side_workload(args, rank, world, dev) -> None:
         base = ShiTomasiBADSinkhornMatcher(max_keypoints=k, **dcfg)
         what = ("ShiTomasiBADSinkhornMatcher (dense-BAD variant: no border margin, responses at the keypoints), 1920x1080, "
                 "K=1024, P=512 hard bits (BASELINE configs[2], dense reading)")
-        roof = ("mi_corner_response_balanced", "corner_stream_kernel<3,4> (mi_corner_response_balanced)", 8.0, 1)
+        roof = ("mi_corner_response_balanced", "corner_stream_kernel<3,4> (mi_corner_response_balanced)", 8.0, 1, "corner_stream_kernel<3,4,false>")
     else:
         h, w, k = H, W, K
         # export_akaze_sparse_bad_sinkhorn.py defaults: 256 pairs, no binarisation, NMS radius 3
@@ -468,7 +468,7 @@ def side_workload(args, rank, world, dev) -> None:
         what = ("AKAZE(3 scales x 3 steps) + oriented sparse BAD(256, raw) + Sinkhorn(20, eps 0.05), 640x480, K=512 "
                 "(BASELINE configs[3], AKAZE export-CLI values)")
         # one scale per launch: reads the previous scale's image, writes the diffused image and the scale's score map
-        roof = ("mi_akaze_scale", "akaze_scale_kernel (mi_akaze_scale: 3 diffusion steps + Hessian + NMS per launch)", 12.0, 1)
+        roof = ("mi_akaze_scale", "akaze_scale_kernel (mi_akaze_scale: 3 diffusion steps + Hessian + NMS per launch)", 12.0, 1, "akaze_scale_kernel<3,2>")
     begin, _ = D.shard_range(B * world, rank, world)
     a, b = synth_batch(1000 + begin, B, h, w)
     img1, img2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
@@ -502,10 +502,11 @@ def side_workload(args, rank, world, dev) -> None:
         if timed:
             nbytes = roof[2] * B * h * w * roof[3]
             t_ms = float(np.mean(timed))
+            traffic, tsrc = pmc_traffic(roof[4], B, args.workload)
             line["roofline"] = {"kernel": roof[1], "bound": "hbm", "achieved": nbytes / (t_ms * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "traffic": None, "bytes_per_launch": nbytes, "bytes_per_pixel": roof[2],
-                                "ms_per_launch": t_ms}
+                                "traffic": traffic, "traffic_source": tsrc, "bytes_per_launch": nbytes,
+                                "bytes_per_pixel": roof[2], "ms_per_launch": t_ms}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -29,18 +29,17 @@ static_assert((K1_POOLS * K1_POOL_STRIDE + 1) * 4 <= MI_TILE_COUNTER_BYTES, "inc
 constexpr int LPAD = 4;  // LDS padding each side, one float4 (>= 1 + block/2 for block <= 7)
 constexpr int LW4 = (TW + 2 * LPAD) / 4;
 
-// Correctly rounded fp32 sqrt for normal, finite x (here x >= 1e-10): v_sqrt_f32 is within 1 ulp,
-// so the answer is one of {s-1ulp, s, s+1ulp}; two exact-sign fma residuals pick it.  This is
-// the compiler's own IEEE sqrt expansion without its denormal pre-scaling and class checks.
+// Correctly rounded fp32 sqrt for normal, finite x (here x >= 1e-10) on the fp32 pipe only: y = v_rsq_f32(x), g = x y,
+// h = y / 2, one correction g + (x - g g) h with the residual exact in one fma.  Compared with sqrtf() over EVERY float
+// in [1e-10, 2^126] by the exhaustive GPU test (tests/test_gpu_parity.py::test_akaze_fast_division_is_exact; the helper
+// is csrc/akaze_math.h's ak_sqrt_fp<1>).  The earlier form -- v_sqrt_f32, then {s - 1ulp, s, s + 1ulp} picked by two
+// exact-sign fma residuals: the compiler's IEEE expansion without its denormal scaling -- spends two compares and two
+// selects on the pick, which issue at half the rate of fp32 multiplies and adds on gfx950 (tools/micro/valu_classes.hip).
 __device__ __forceinline__ float sqrt_rn(float x) {
-  const float s = __builtin_amdgcn_sqrtf(x);
-  const float lo = __uint_as_float(__float_as_uint(s) - 1u);
-  const float hi = __uint_as_float(__float_as_uint(s) + 1u);
-  const float rl = __builtin_fmaf(-lo, s, x);
-  const float rh = __builtin_fmaf(-hi, s, x);
-  float r = (rl <= 0.0f) ? lo : s;
-  r = (rh > 0.0f) ? hi : r;
-  return r;
+  const float y = __builtin_amdgcn_rsqf(x);
+  const float g = x * y;
+  const float h = 0.5f * y;
+  return __builtin_fmaf(__builtin_fmaf(-g, g, x), h, g);
 }
 
 __device__ __forceinline__ float lambda_min(float a, float c, float b) {

@@ -840,7 +840,7 @@ def test_akaze_fused_scale_equals_step_kernels(mods, shape):
 def test_akaze_fast_division_is_exact(mods):
     """The fused AKAZE kernel's arithmetic helpers (csrc/akaze_math.h) against the IEEE operators, EXHAUSTIVELY over the
     operand ranges of the diffusion step: ak_sqrt on [1e-8, 2^24] and the fp32-pipe form the kernel uses
-    (ak_sqrt_fp<1>: v_rsq_f32 + one exact-residual correction) on [1e-8, 2^64], x / kappa through the precomputed reciprocal
+    (ak_sqrt_fp<1>: v_rsq_f32 + one exact-residual correction; K1's sqrt_rn is the same sequence) on [1e-10, 2^126], x / kappa through the precomputed reciprocal
     (Markstein's 3-instruction form) for several kappa on [2^-30, 2^24], 1 / d on [1, 2^40), and the general division.
     ~1.8e9 evaluations; zero differing bit patterns allowed."""
     import struct
@@ -849,7 +849,7 @@ def test_akaze_fast_division_is_exact(mods):
     def bits(x):
         return struct.unpack("<I", struct.pack("<f", x))[0]
 
-    cases = [(0, 0.05, 1e-8, 2.0 ** 24), (4, 0.05, 1e-8, 2.0 ** 64), (2, 0.05, 1.0, 2.0 ** 40)]
+    cases = [(0, 0.05, 1e-8, 2.0 ** 24), (4, 0.05, 1e-10, 2.0 ** 126), (2, 0.05, 1.0, 2.0 ** 40)]
     cases += [(1, kappa, 2.0 ** -30, 2.0 ** 24) for kappa in (0.05, 0.03, 0.1, 0.7, 1.0, 3.0, 1e-3)]
     cases += [(3, 0.05, 2.0 ** -30, 2.0 ** 24)]
     with N.debug_library() as lib:

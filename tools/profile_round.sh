@@ -30,11 +30,17 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_W
 echo pmc SQ done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/latency" -o latency -- python3 "$ROOT/tools/latency_trace.py" --single-call --graph --iters 50 > "$OUT/latency.log" 2>&1
 echo latency done
-timeout -k 10 300 python3 "$B" --workload c3 --pairs-per-gpu 128 > "$OUT/c3.json" 2> "$OUT/c3.err"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/c3stats" -o c3 -- python3 "$B" --workload c3 --pairs-per-gpu 128 --steps 5 --warmup 2 > "$OUT/c3stats.log" 2>&1
-timeout -k 10 300 python3 "$B" --workload c4 --pairs-per-gpu 128 > "$OUT/c4.json" 2> "$OUT/c4.err"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/c4stats" -o c4 -- python3 "$B" --workload c4 --pairs-per-gpu 128 --steps 5 --warmup 2 > "$OUT/c4stats.log" 2>&1
+# BASELINE configs[2] (sparse pipeline and dense-BAD matcher) and configs[3]: bench line, kernel statistics and the two
+# HBM-traffic passes each (so that their roofline objects carry a `traffic` figure)
+for wl in c3 c3dense c4; do
+  timeout -k 10 300 python3 "$B" --workload $wl --pairs-per-gpu 128 > "$OUT/$wl.json" 2> "$OUT/$wl.err"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/${wl}stats" -o $wl -- python3 "$B" --workload $wl --pairs-per-gpu 128 --steps 5 --warmup 2 > "$OUT/${wl}stats.log" 2>&1
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_${wl}_$c" -o pmc -- python3 "$B" --workload $wl --pairs-per-gpu 128 --steps 2 --warmup 1 > "$OUT/pmc_${wl}_$c.log" 2>&1
+  done
+  echo $wl done
+done
 # summarise here and drop the databases: gpurun copies at most 64 MiB back
-python3 "$ROOT/tools/profile_summarise.py" "${PROFILE_TAG:-r02}" "$OUT/summary"
+python3 "$ROOT/tools/profile_summarise.py" "${PROFILE_TAG:-r03}" "$OUT/summary"
 find "$OUT" -name '*.db' -delete
 echo profile_round done

@@ -54,7 +54,38 @@ stats_csv("stats", "stats", f"{tag}_bench_kernel_stats.csv",
 stats_csv("latency", "latency", f"{tag}_latency_kernel_stats.csv",
           "# rocprofv3 --kernel-trace --stats -- python3 tools/latency_trace.py --single-call --graph --iters 50   "
           "(ONE 640x480 K=512 pair per call through mi_match_pairs, replayed as a hipGraph; every call synchronised)")
-for wl, pairs in (("c3", 128), ("c4", 128)):
+def side_traffic(wl, pairs):
+    """FETCH_SIZE / WRITE_SIZE passes of a side workload -> {tag}_{wl}_pmc_traffic.json (same corrections as the main one)"""
+    t = collections.defaultdict(dict)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        path = os.path.join(SRC, f"pmc_{wl}_{counter}", "pmc_results.db")
+        if not os.path.exists(path):
+            return
+        cur = sqlite3.connect(path).cursor()
+        cols = [c[0] for c in cur.execute("select * from counters_collection limit 1").description]
+        acc = collections.defaultdict(list)
+        for r in cur.execute("select * from counters_collection"):
+            row = dict(zip(cols, r))
+            if row["counter_name"] == counter:
+                acc[short(row["kernel_name"])].append(row["value"])
+        for k, v in acc.items():
+            t[k][counter + "_KB_raw_per_launch"] = sum(v) / len(v)
+            t[k]["launches"] = len(v)
+    o = {"note": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --workload {wl} --pairs-per-gpu {pairs} "
+                 "--steps 2 --warmup 1`; per-launch averages; counters are KB; reads doubled per the gfx950 note in MI355X_MICROARCH.md",
+         "workload": wl, "pairs_per_gpu": pairs, "kernels": {}}
+    for k, v in sorted(t.items(), key=lambda kv: -kv[1].get("FETCH_SIZE_KB_raw_per_launch", 0)):
+        if k.startswith("at::") or k.startswith("__amd") or "elementwise" in k or "Cat" in k or "reduce_kernel" in k:
+            continue
+        rd = v.get("FETCH_SIZE_KB_raw_per_launch", 0.0) * 1024 * 2 / 1e6
+        wr = v.get("WRITE_SIZE_KB_raw_per_launch", 0.0) * 1024 / 1e6
+        o["kernels"][k] = {**{kk: round(vv, 3) for kk, vv in v.items()}, "read_MB_corrected_x2": round(rd, 1),
+                           "write_MB": round(wr, 1), "total_MB": round(rd + wr, 1)}
+    json.dump(o, open(os.path.join(dst, f"{tag}_{wl}_pmc_traffic.json"), "w"), indent=1)
+
+
+for wl, pairs in (("c3", 128), ("c3dense", 128), ("c4", 128)):
+    side_traffic(wl, pairs)
     stats_csv(wl + "stats", wl, f"{tag}_{wl}_kernel_stats.csv",
               f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --pairs-per-gpu {pairs} --steps 5 --warmup 2")
     src = os.path.join(SRC, wl + ".json")
