@@ -22,10 +22,11 @@ def env_world() -> tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init(backend: str | None = None) -> tuple[int, int, int]:
-    """Join the process group described by the environment; no-op for a single process."""
+def init(backend: str | None = None, force: bool = False) -> tuple[int, int, int]:
+    """Join the process group described by the environment; no-op for a single process (unless `force`: a world of one
+    still forms a group -- what the one-GPU hardware test of the RCCL code path uses)."""
     rank, world, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # the pool's host driver supports only dmabuf IPC: with the legacy mode RCCL's peer-buffer exchange fails in
         # hipIpcGetMemHandle ("invalid argument").  The image exports this already; set here for a bare environment.

@@ -18,6 +18,7 @@ from oracle import numpy_oracle as O
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
 def _status_word(state) -> int:
@@ -1600,3 +1601,49 @@ def test_match_pairs_argument_checks(mods):
     with pytest.raises(RuntimeError):
         mods["MatchExtractionWrapper"](mods["ShiTomasiSparseBADSinkhornMatcher"](max_keypoints=64)).to(DEV) \
             .forward_single_call(img, img)                                               # soft descriptors: not covered
+
+
+def test_rccl_process_group_of_one_runs_the_gather_path(tmp_path):
+    """The N > 1 code of bench.py -- init_process_group(backend "nccl" = RCCL), gather of match records, max-over-ranks
+    reduction, per-rank facts, barriers, teardown -- on real hardware.  A one-GPU box cannot host two RCCL ranks, so the
+    group has ONE rank (distributed.init(force=True)): every collective call, tensor placement and argument the N-rank run
+    makes is exercised, only the peer traffic is missing (that half is covered by the world-2 gloo tests).  Runs in a
+    fresh child process (its own rendezvous port and process group)."""
+    import socket
+    import subprocess
+    import sys as _sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    code = """
+import os, sys, json
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+import bench
+from onnx_image_processing_amd import distributed as D
+rank, world, local = D.init(force=True)
+assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+dev = torch.device("cuda", local)
+rec = torch.rand(5, 100, 6, device=dev)
+out = D.gather_records(rec, dst=0, total=5)
+assert out is not None and torch.equal(out, rec)
+out2 = D.gather_records(rec, dst=0, collective="all_gather")
+assert torch.equal(out2, rec)
+assert D.barrier_max_ms(12.5, dev) == 12.5
+calls = []
+def step():
+    calls.append(1)
+    return D.gather_records(rec * len(calls), dst=0, total=5)
+elapsed, per_step, last, own = bench.run_timed(step, steps=3, warmup=1, world=2, device=dev, sync=torch.cuda.synchronize)
+facts = bench.world_facts(own, 3, dev)
+assert len(per_step) == 3 and torch.equal(last, rec * 4)
+dist.barrier()
+dist.destroy_process_group()
+print(json.dumps(facts))
+""" % ROOT
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json as _json
+    facts = _json.loads(r.stdout.strip().splitlines()[-1])
+    assert facts["ranks_seen"] == 1 and facts["backend"] == "nccl" and len(facts["ms_per_step_per_rank"]) == 1
