@@ -461,6 +461,14 @@ def test_outlier_filters_module(mods):
         assert np.array_equal(dustbin_margin_filter(gpu(full), margin).cpu().numpy(), O.dustbin_margin_filter(full, margin))
     with pytest.raises(RuntimeError):
         probability_ratio_filter(gpu(p[None]), 2.0)
+    # the reference's own call pattern (sample/image_matching.py:49-118): numpy in (float64 too), numpy bool out
+    for core, thr, expect in KNOWN_RATIO:
+        got = probability_ratio_filter(np.asarray(core, dtype=np.float64), thr)
+        assert isinstance(got, np.ndarray) and got.dtype == np.bool_ and got.tolist() == expect
+    for full_, margin, expect in KNOWN_DUSTBIN:
+        got = dustbin_margin_filter(np.asarray(full_), margin)
+        assert isinstance(got, np.ndarray) and got.tolist() == expect
+    assert np.array_equal(dustbin_margin_filter(full, 0.3), O.dustbin_margin_filter(full, 0.3))
 
 
 def test_mnn_vs_oracle(mods):
