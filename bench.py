@@ -70,15 +70,49 @@ class StepClock:
         return [(b - a) * 1e3 for a, b in zip(self.stamps, self.stamps[1:])]
 
 
-def run_timed(step, steps: int, warmup: int, world: int, device, sync) -> tuple[float, list[float], object, float]:
+class PipelinedGather:
+    """The step's result gather with ONE collective in flight: step i issues its gather (gather_records_async) and
+    returns the gathered records of step i - 1; drain() -- called inside the timed region, before its closing
+    synchronise -- completes the last one.  Every step's records are gathered and waited for before the clock stops;
+    what changes is that the slabs of step i travel while step i + 1 computes instead of in front of it.  With one
+    process (no process group) the gather is the identity and nothing is deferred."""
+
+    def __init__(self, total: int | None = None):
+        self.pending = None
+        self.total = total
+        self.last = None
+
+    def __call__(self, rec):
+        from onnx_image_processing_amd import distributed as D
+        handle = D.gather_records_async(rec, dst=0, total=self.total)
+        if not dist.is_initialized():
+            self.last = handle.wait()
+            return self.last
+        if self.pending is not None:
+            self.last = self.pending.wait()
+        self.pending = handle
+        return self.last
+
+    def drain(self):
+        if self.pending is not None:
+            self.last = self.pending.wait()
+            self.pending = None
+        return self.last
+
+
+def run_timed(step, steps: int, warmup: int, world: int, device, sync, drain=None) -> tuple[float, list[float], object, float]:
     """The contract's timed region: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by a barrier + device
     synchronisation on both sides; returns (elapsed ms, MAX over ranks; per-step ms of this rank; last step's output;
-    this rank's own elapsed ms up to its last synchronise, before the closing barrier).
+    this rank's own elapsed ms up to its last synchronise, before the closing barrier).  drain: completes whatever the
+    steps left in flight (PipelinedGather.drain) -- called after the warm-up and, inside the timed region, after the
+    last step; its return value replaces the last step's output.
     `step()` returns what rank 0 needs (the gathered records); `sync()` is torch.cuda.synchronize on a GPU."""
     from onnx_image_processing_amd import distributed as D
     out = None
     for _ in range(warmup):
         out = step()
+    if drain is not None:
+        out = drain()
     sync()
     if world > 1:
         dist.barrier()
@@ -89,6 +123,8 @@ def run_timed(step, steps: int, warmup: int, world: int, device, sync) -> tuple[
     for i in range(steps):
         out = step()
         clock.mark(i + 1)
+    if drain is not None:
+        out = drain()
     sync()
     own_ms = (time.perf_counter() - t0) * 1e3
     if world > 1:
@@ -476,17 +512,20 @@ def side_workload(args, rank, world, dev) -> None:
     model = MatchExtractionWrapper(base, max_matches=MNN["max_matches"], match_threshold=MNN["threshold"]).to(dev)
     model.fuse_extraction = not args.two_step
 
+    gather = PipelinedGather()
+
     def step():
-        return D.gather_records(D.pack_records(*model(img1, img2)), dst=0)
+        return gather(D.pack_records(*model(img1, img2)))
 
     _native.enable_timing(True, only={roof[0]})
-    elapsed_ms, per_step, out, own_ms = run_timed(step, args.steps, args.warmup, world, dev, torch.cuda.synchronize)
+    elapsed_ms, per_step, out, own_ms = run_timed(step, args.steps, args.warmup, world, dev, torch.cuda.synchronize, gather.drain)
     facts = world_facts(own_ms, args.steps, dev)
     timed = _native.timings_ms().get(roof[0], [])
     timed = timed[-len(timed) * args.steps // (args.steps + args.warmup):] if timed else timed     # drop the warm-up calls
     _native.enable_timing(True)
     for _ in range(3):
         step()
+    gather.drain()
     per_call = _native.timings_ms()
     _native.enable_timing(False)
     if rank == 0:
@@ -587,11 +626,13 @@ def dry_run(args, rank: int, world: int) -> None:
     if os.environ.get("MI_BENCH_DRY_RUN_FAIL_RANK") == str(rank):              # test hook of the dry run only: a rank that dies
         raise SystemExit(3)
 
+    gather = PipelinedGather(total=B * world)
+
     def step():
         time.sleep(0.001 * (rank + 1))
-        return D.gather_records(rec, dst=0, total=B * world)
+        return gather(rec)
 
-    elapsed_ms, per_step, out, own_ms = run_timed(step, args.steps, args.warmup, world, "cpu", lambda: None)
+    elapsed_ms, per_step, out, own_ms = run_timed(step, args.steps, args.warmup, world, "cpu", lambda: None, gather.drain)
     facts = world_facts(own_ms, args.steps, "cpu")
     if rank == 0:
         ms = elapsed_ms / args.steps
@@ -681,14 +722,16 @@ def main() -> None:
                                    max_matches=MNN["max_matches"], match_threshold=MNN["threshold"]).to(dev)
     model.fuse_extraction = not args.two_step
 
+    gather = PipelinedGather()          # N > 1: one RCCL gather in flight under the next step's kernels; N = 1: identity
+
     def step():
         rec = D.pack_records(*(model.forward_single_call(img1, img2) if args.single_call else model(img1, img2)))
-        return D.gather_records(rec, dst=0)
+        return gather(rec)
 
     # HIP events around the roofline kernel's calls only (two per step) inside the timed region; the per-stage table
     # below comes from extra steps after it, so its 24 events per step do not sit in the measurement
     _native.enable_timing(True, only=None if args.single_call else {"mi_corner_response_balanced"})
-    elapsed_ms, per_step, out, own_ms = run_timed(step, args.steps, args.warmup, world, dev, torch.cuda.synchronize)
+    elapsed_ms, per_step, out, own_ms = run_timed(step, args.steps, args.warmup, world, dev, torch.cuda.synchronize, gather.drain)
     facts = world_facts(own_ms, args.steps, dev)
     per_call = _native.timings_ms()
     _native.enable_timing(False)
@@ -697,7 +740,8 @@ def main() -> None:
     if not args.single_call:                                     # per-stage times (informational), outside the timed region
         _native.enable_timing(True)
         for _ in range(stage_steps):
-            out = step()
+            step()
+        out = gather.drain()
         stages = _native.timings_ms()
         _native.enable_timing(False)
 
@@ -724,6 +768,9 @@ def main() -> None:
                                    + (", issued as one mi_match_pairs call per step" if args.single_call else ""),
                        "pairs_per_gpu_per_step": B, "global_pairs_per_step": pairs_per_step,
                        "height": H, "width": W, "max_keypoints": K, "parallelism": f"pair-sharded x{world}",
+                       "result_gather": ("none (one process)" if world == 1 else
+                                         "RCCL gather of the match records to rank 0 every step, one collective in flight under "
+                                         "the next step's kernels, all completed inside the timed region"),
                        "input": ("uint8" if u8_main else "float32") + " frames resident in HBM",
                        "mean_valid_matches_per_pair": float(out[..., 5].sum().item()) / pairs_per_step},
             "step_ms": step_stats(per_step),

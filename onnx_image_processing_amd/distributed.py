@@ -110,6 +110,50 @@ def gather_records(rec: torch.Tensor, dst: int = 0, total: int | None = None,
     return torch.cat(out, dim=0)
 
 
+class PendingGather:
+    """Handle of gather_records_async: wait() returns what gather_records would have returned (the concatenated records
+    on `dst`, None elsewhere).  The tensors of the collective are kept alive until then."""
+
+    def __init__(self, work, out, rank, dst, sizes, rec):
+        self._work, self._out, self._rank, self._dst, self._sizes, self._rec = work, out, rank, dst, sizes, rec
+
+    def wait(self) -> torch.Tensor | None:
+        if self._work is not None:
+            self._work.wait()          # RCCL: the current stream waits for the collective; the host does not block
+            self._work = None
+        if self._rank != self._dst:
+            return None
+        out = self._out
+        if self._sizes is not None:
+            out = [slab[:sz] for slab, sz in zip(out, self._sizes)]
+        return out[0] if len(out) == 1 else torch.cat(out, dim=0)
+
+
+def gather_records_async(rec: torch.Tensor, dst: int = 0, total: int | None = None) -> PendingGather:
+    """gather_records(collective="gather") issued WITHOUT waiting for it: the collective runs on the backend's own
+    stream behind the work already enqueued on the current stream (the records), so the next step's kernels can be
+    enqueued -- and run -- while the slabs travel over xGMI.  bench.py keeps one gather in flight: step i waits for the
+    gather of step i - 1.  Same argument checks and padding rules as gather_records."""
+    if not dist.is_initialized():
+        if total is not None and rec.shape[0] != total:
+            raise ValueError(f"single process holds {rec.shape[0]} rows but total={total}")
+        return PendingGather(None, [rec], 0, 0, None, rec)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = None
+    if total is not None:
+        sizes = shard_sizes(total, world)
+        if rec.shape[0] != sizes[rank]:
+            raise ValueError(f"rank {rank} holds {rec.shape[0]} rows, shard_range({total}, {rank}, {world}) says {sizes[rank]}")
+        rows = max(sizes)
+        if rec.shape[0] < rows:
+            pad = torch.zeros((rows - rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
+            rec = torch.cat([rec, pad], dim=0)
+    rec = rec.contiguous()
+    out = [torch.empty_like(rec) for _ in range(world)] if rank == dst else None
+    work = dist.gather(rec, out, dst=dst, async_op=True)
+    return PendingGather(work, out, rank, dst, sizes, rec)
+
+
 def barrier_max_ms(elapsed_ms: float, device: torch.device | str) -> float:
     """Maximum of a per-rank time over all ranks."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -1639,10 +1639,12 @@ out2 = D.gather_records(rec, dst=0, collective="all_gather")
 assert torch.equal(out2, rec)
 assert D.barrier_max_ms(12.5, dev) == 12.5
 calls = []
+gather = bench.PipelinedGather(total=5)                       # the bench's own form: one gather in flight
 def step():
     calls.append(1)
-    return D.gather_records(rec * len(calls), dst=0, total=5)
-elapsed, per_step, last, own = bench.run_timed(step, steps=3, warmup=1, world=2, device=dev, sync=torch.cuda.synchronize)
+    return gather(rec * len(calls))
+elapsed, per_step, last, own = bench.run_timed(step, steps=3, warmup=1, world=2, device=dev, sync=torch.cuda.synchronize,
+                                               drain=gather.drain)
 facts = bench.world_facts(own, 3, dev)
 assert len(per_step) == 3 and torch.equal(last, rec * 4)
 dist.barrier()
