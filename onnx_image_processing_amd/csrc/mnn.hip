@@ -121,16 +121,46 @@ __global__ __launch_bounds__(MX_THREADS) void mnn_select_kernel(
     keys[i] = key;
   }
   __syncthreads();
-  for (int size = 2; size <= npad; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int i = t; i < (npad >> 1); i += MX_THREADS) {
-        const int pos = 2 * i - (i & (stride - 1));
-        const int par = pos + stride;
-        const bool desc = ((pos & size) == 0);
-        const uint64_t a = keys[pos], c = keys[par];
-        if ((a < c) == desc) { keys[pos] = c; keys[par] = a; }
+  const uint64_t *sorted = keys;
+  if (npad >= 128 && npad <= MX_THREADS) {
+    // Counting-rank order of the rows' keys (round 3; the bitonic network below needs 45 barrier-separated stages for
+    // 512 keys): real keys are distinct (their low word is the inverted row index), so a key's place in the descending
+    // order is the number of keys above it.  1024 / npad threads share a key, each counting over its slice; a wave's
+    // lanes hold consecutive keys and the same slice, so every read of the scan is a broadcast.  The upper part of the
+    // key array is free for npad <= 1024: [1024, 2048) takes the ordered keys, [2048, ...) the per-key counters.
+    uint64_t *ordered = keys + MX_THREADS;
+    uint32_t *above_of = reinterpret_cast<uint32_t *>(keys + 2 * MX_THREADS);
+    const int tpk = MX_THREADS / npad, slice = npad / tpk;
+    const int ki = t & (npad - 1), part = t / npad;
+    if (t < npad) { above_of[t] = 0u; ordered[t] = 0ull; }
+    const uint64_t mine = keys[ki];
+    uint32_t above = 0;
+    if (mine != 0ull) {
+      const ulonglong2 *lst = reinterpret_cast<const ulonglong2 *>(keys + part * slice);
+#pragma unroll 8
+      for (int j = 0; j < slice / 2; ++j) {
+        const ulonglong2 two = lst[j];
+        above += (two.x > mine ? 1u : 0u) + (two.y > mine ? 1u : 0u);
       }
-      __syncthreads();
+    }
+    __syncthreads();
+    if (mine != 0ull && above) atomicAdd(&above_of[ki], above);
+    __syncthreads();
+    if (part == 0 && mine != 0ull) ordered[above_of[ki]] = mine;
+    __syncthreads();
+    sorted = ordered;
+  } else {
+    for (int size = 2; size <= npad; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int i = t; i < (npad >> 1); i += MX_THREADS) {
+          const int pos = 2 * i - (i & (stride - 1));
+          const int par = pos + stride;
+          const bool desc = ((pos & size) == 0);
+          const uint64_t a = keys[pos], c = keys[par];
+          if ((a < c) == desc) { keys[pos] = c; keys[par] = a; }
+        }
+        __syncthreads();
+      }
     }
   }
   const int cnt = max_matches < n ? max_matches : n;
@@ -139,7 +169,7 @@ __global__ __launch_bounds__(MX_THREADS) void mnn_select_kernel(
     uint32_t i = 0;
     bool matched = false;
     if (s < cnt) {
-      const uint64_t key = keys[s];
+      const uint64_t key = sorted[s];
       i = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
       const uint32_t hi = (uint32_t)(key >> 32);
       matched = hi != 0u;

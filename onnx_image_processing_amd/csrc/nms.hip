@@ -302,14 +302,19 @@ __global__ __launch_bounds__(NTH) void nms_fast_kernel(const float *__restrict__
     if (i >= LH * (NT_W / 4)) break;
     const int rr = i >> 5, cg = i & 31;
     float v[NV];
-#pragma unroll
-    for (int c = 0; c < NV / 4; ++c) {
+    {
+      // keep the 16-byte reads whole: left alone the compiler fetches only the 4+2r floats it needs with
+      // ds_read2_b32, whose 16-byte lane stride is a 4-way bank conflict; ds_read_b128 has none.  The empty asm that
+      // pins a chunk follows ALL of the item's reads (round 3): pinned one by one, every read was waited for before
+      // the next was issued -- NV / 4 dependent LDS round trips per item (s_waitcnt lgkmcnt(0) after each in the .s).
       typedef float f4v __attribute__((ext_vector_type(4)));
-      f4v q = *reinterpret_cast<const f4v *>(&pa[rr][cg + c]);
-      // keep the 16-byte read whole: left alone the compiler fetches only the 4+2r floats it needs with
-      // ds_read2_b32, whose 16-byte lane stride is a 4-way bank conflict; ds_read_b128 has none
-      asm volatile("" : "+v"(q));
-      v[4 * c] = q.x; v[4 * c + 1] = q.y; v[4 * c + 2] = q.z; v[4 * c + 3] = q.w;
+      f4v q[NV / 4];
+#pragma unroll
+      for (int c = 0; c < NV / 4; ++c) q[c] = *reinterpret_cast<const f4v *>(&pa[rr][cg + c]);
+#pragma unroll
+      for (int c = 0; c < NV / 4; ++c) asm volatile("" : "+v"(q[c]));
+#pragma unroll
+      for (int c = 0; c < NV / 4; ++c) { v[4 * c] = q[c].x; v[4 * c + 1] = q[c].y; v[4 * c + 2] = q[c].z; v[4 * c + 3] = q[c].w; }
     }
     // windows [B0+o-R, B0+o+R], o = 0..3; for R >= 2 they share the core [B0+3-R, B0+R]
     float o[4];

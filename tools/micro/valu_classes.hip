@@ -36,6 +36,9 @@
 #define I_BFE(i) "v_bfe_u32 %" #i ", %" #i ", 3, 8\n"
 #define I_ALIGN(i) "v_alignbit_b32 %" #i ", %" #i ", %8, 8\n"
 #define I_CVTU8(i) "v_cvt_f32_ubyte1 %" #i ", %" #i "\n"
+#define I_MIX(i) "v_fma_mix_f32 %" #i ", %" #i ", %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+#define I_CVTH(i) "v_cvt_f32_f16 %" #i ", %" #i "\n"
+#define I_PKFMA(i) "v_pk_fma_f32 %" #i ", %" #i ", %10, %10\n"
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k(float *out, int iters) {
@@ -50,7 +53,8 @@ __global__ __launch_bounds__(256) void k(float *out, int iters) {
       else if (KIND == 12) REP8(I_EXP); else if (KIND == 13) REP8(I_LOG); else if (KIND == 14) REP8(I_RCP); else if (KIND == 15) REP8(I_RSQ);
       else if (KIND == 16) REP8(I_SQRT); else if (KIND == 17) REP8(I_DPP); else if (KIND == 18) REP8(I_DPPW); else if (KIND == 19) REP8(I_ADDDPP);
       else if (KIND == 20) REP8(I_PERM); else if (KIND == 21) REP8(I_MAX3); else if (KIND == 22) REP8(I_MAD24); else if (KIND == 23) REP8(I_MULLO);
-      else if (KIND == 24) REP8(I_BFE); else if (KIND == 25) REP8(I_ALIGN); else REP8(I_CVTU8);
+      else if (KIND == 24) REP8(I_BFE); else if (KIND == 25) REP8(I_ALIGN); else if (KIND == 26) REP8(I_CVTU8);
+      else if (KIND == 27) REP8(I_MIX); else REP8(I_CVTH);
     }
   }
   out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
@@ -89,6 +93,7 @@ int main() {
   run<23>("v_mul_lo_u32", out); run<7>("v_mov_b32", out); run<8>("v_cndmask_b32", out); run<9>("v_cmp_gt_f32", out);
   run<10>("v_cvt_f32_u32", out); run<11>("v_cvt_f32_u32 sdwa", out); run<26>("v_cvt_f32_ubyte1", out);
   run<12>("v_exp_f32", out); run<13>("v_log_f32", out); run<14>("v_rcp_f32", out); run<15>("v_rsq_f32", out); run<16>("v_sqrt_f32", out);
+  run<27>("v_fma_mix_f32 (f16 src)", out); run<28>("v_cvt_f32_f16", out);
   run<17>("v_mov_dpp quad_perm", out); run<18>("v_mov_dpp wave_shr", out); run<19>("v_add_f32 dpp", out);
   return 0;
 }
