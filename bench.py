@@ -494,6 +494,19 @@ def side_workload(args, rank, world, dev) -> None:
         what = ("ShiTomasiBADSinkhornMatcher (dense-BAD variant: no border margin, responses at the keypoints), 1920x1080, "
                 "K=1024, P=512 hard bits (BASELINE configs[2], dense reading)")
         roof = ("mi_corner_response_balanced", "corner_stream_kernel<3,4> (mi_corner_response_balanced)", 8.0, 1, "corner_stream_kernel<3,4,false>")
+    elif args.workload == "vo":
+        # the visual-odometry model (sample/visual_odometry.py:520-545 runs it once per frame
+        # pair): Shi-Tomasi(5) + angle at the keypoints + rotation-aware BAD + Sinkhorn + essential-matrix head, Angle
+        # export-CLI values, pinned to the reference by tests/golden/angle_vo_480x640_k512.npz
+        from onnx_image_processing_amd.pytorch_model.feature_detection import ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix
+        h, w, k = H, W, K
+        vcfg = dict(block_size=5, num_pairs=512, binarize=True, soft_binarize=False, sinkhorn_iterations=20, epsilon=0.05,
+                    unused_score=1.0, distance_type="l2", nms_radius=5, score_threshold=0.0, normalize_descriptors=True)
+        cam = torch.tensor([[500.0, 0.0, 320.0], [0.0, 500.0, 240.0], [0.0, 0.0, 1.0]])
+        base = ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix(K=cam, max_keypoints=k, **vcfg)
+        what = ("ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix (the VO model: Shi-Tomasi(5) + keypoint angles + oriented "
+                "BAD(512, hard) + Sinkhorn(20, eps 0.05) + essential-matrix head), 640x480, K=512, Angle export-CLI values")
+        roof = ("mi_corner_response_balanced", "corner_tile_kernel<5,8> (block 5: the register-staged tile kernel)", 8.0, 1, "corner_tile_kernel<5,8>")
     else:
         h, w, k = H, W, K
         # export_akaze_sparse_bad_sinkhorn.py defaults: 256 pairs, no binarisation, NMS radius 3
@@ -509,13 +522,18 @@ def side_workload(args, rank, world, dev) -> None:
     a, b = synth_batch(1000 + begin, B, h, w)
     img1, img2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
     del a, b
-    model = MatchExtractionWrapper(base, max_matches=MNN["max_matches"], match_threshold=MNN["threshold"]).to(dev)
-    model.fuse_extraction = not args.two_step
-
     gather = PipelinedGather()
+    if args.workload == "vo":
+        model = base.to(dev)
 
-    def step():
-        return gather(D.pack_records(*model(img1, img2)))
+        def step():                                   # one record per pair: the 3 x 3 essential matrix (P stays on the GPU)
+            return gather(model(img1, img2)[3].reshape(B, 1, 9))
+    else:
+        model = MatchExtractionWrapper(base, max_matches=MNN["max_matches"], match_threshold=MNN["threshold"]).to(dev)
+        model.fuse_extraction = not args.two_step
+
+        def step():
+            return gather(D.pack_records(*model(img1, img2)))
 
     _native.enable_timing(True, only={roof[0]})
     elapsed_ms, per_step, out, own_ms = run_timed(step, args.steps, args.warmup, world, dev, torch.cuda.synchronize, gather.drain)
@@ -535,7 +553,9 @@ def side_workload(args, rank, world, dev) -> None:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": what, "pairs_per_gpu_per_step": B,
-                       "mean_valid_matches_per_pair": float(out[..., 5].sum().item()) / (B * world)},
+                       **({"finite_essential_matrices": int(torch.isfinite(out).all(dim=(1, 2)).sum().item())}
+                          if args.workload == "vo" else
+                          {"mean_valid_matches_per_pair": float(out[..., 5].sum().item()) / (B * world)})},
             "step_ms": step_stats(per_step), **facts,
             "kernels": {kk: {"ms_per_step": float(np.sum(v)) / 3, "calls_per_step": len(v) / 3} for kk, v in per_call.items()}}
         if timed:
@@ -672,9 +692,10 @@ def main() -> None:
     ap.add_argument("--frames", choices=["f32", "u8"], default="f32",
                     help="pixel type of the frames resident in HBM for the main line (f32 = the reference's input form; "
                          "u8 is the line `u8_ingest` reports, selectable here so that profilers can be pointed at it)")
-    ap.add_argument("--workload", choices=["c2", "c3", "c3dense", "c4"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "c3", "c3dense", "c4", "vo"], default="c2",
                     help="c2 (default, the metric's configuration); c3 = 1080x1920 K=1024 sparse pipeline; c3dense = the same "
-                         "size through the dense-BAD matcher; c4 = AKAZE front end")
+                         "size through the dense-BAD matcher; c4 = AKAZE front end; vo = the visual-odometry model "
+                         "(Shi-Tomasi+Angle matcher with the essential-matrix head)")
     ap.add_argument("--dry-run", action="store_true",
                     help="control flow only: stubbed compute on CPU over gloo (tests the N > 1 launcher; not a measurement)")
     args = ap.parse_args()

@@ -556,9 +556,40 @@ def round3():
     save("dense_c3_480x640_k512", **out)
 
 
+
+def round3_vo():
+    """The visual-odometry model at the size it runs at (sample/visual_odometry.py:520-545):
+    ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix with the Angle export-CLI values (block 5, 512 hard pairs,
+    epsilon 0.05, NMS radius 5) at 640x480, K = 512, and a pinhole camera matrix: keypoints, P by
+    row / column maxima and argmaxima, dustbins, marginals, eight full rows, MNN matches and the essential matrix."""
+    from pytorch_model.feature_detection import ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix
+    seed, h, w, k = 4400, 480, 640, 512
+    cfg = dict(max_keypoints=k, block_size=5, num_pairs=512, binarize=True, soft_binarize=False, sinkhorn_iterations=20,
+               epsilon=0.05, unused_score=1.0, distance_type="l2", nms_radius=5, score_threshold=0.0,
+               normalize_descriptors=True)
+    kc = torch.tensor([[500.0, 0.0, 320.0], [0.0, 500.0, 240.0], [0.0, 0.0, 1.0]])
+    a, b = synth_batch(seed, 1, h, w)
+    with torch.no_grad():
+        k1, k2, p, e = ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix(K=kc, **cfg).eval()(torch.from_numpy(a), torch.from_numpy(b))
+        core = p[:, :k, :k]
+        rmax, rarg = core.max(2)
+        cmax, carg = core.max(1)
+        mnn = dict(max_matches=100, threshold=0.1)
+        mk1, mk2, sc, valid = MutualNearestNeighborMatcher(**mnn)(p, k1, k2)
+        save("angle_vo_480x640_k512", seed=seed, h=h, w=w, k=k, cfg=np.array(repr(cfg)), cam_K=kc.numpy(), k1=k1.numpy(),
+             k2=k2.numpy(), E=e.numpy(), P_sha=np.array(sha(p.numpy())), P_rowsum=p.sum(-1).numpy(), P_colsum=p.sum(-2).numpy(),
+             P_rowmax=rmax.numpy(), P_rowarg=rarg.numpy().astype(np.int32), P_colmax=cmax.numpy(),
+             P_colarg=carg.numpy().astype(np.int32), P_dustcol=p[:, :, k].numpy(), P_dustrow=p[:, k, :].numpy(),
+             P_rows_0_8=p[:, :8].numpy(), mnn_cfg=np.array(repr(mnn)), mk1=mk1.numpy(), mk2=mk2.numpy(),
+             mscores=sc.numpy(), mvalid=valid.numpy())
+
+
 if __name__ == "__main__":
-    if "--round3-only" in sys.argv:
+    if "--round3-vo-only" in sys.argv:
+        round3_vo()
+    elif "--round3-only" in sys.argv:
         round3()
+        round3_vo()
     elif "--round2-only" in sys.argv:
         round2()
     elif "--dense-only" in sys.argv:

@@ -1038,6 +1038,40 @@ def test_essential_matrix_composites_vs_golden(mods, name):
     assert e2.shape == (2, 3, 3) and _e_close(e2[0], e)
 
 
+def test_vo_model_480x640_k512_reference_fixture(mods):
+    """The visual-odometry model (sample/visual_odometry.py:520-545's session) at its
+    deployment size against the recorded reference run: ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix, Angle
+    export-CLI values (block 5, 512 hard pairs, epsilon 0.05, NMS 5), 640x480, K = 512, pinhole K.  Keypoint sets equal
+    (sequence too on this input), P through maxima / argmaxima / dustbins / sample rows to 1e-4, the MNN match set with
+    the strict tie rule, E within 1e-4 * max|E| of the reference's."""
+    from onnx_image_processing_amd.pytorch_model.feature_detection import ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix
+    g = load_golden("angle_vo_480x640_k512")
+    cfg = cfg_of(g)
+    k = int(g["k"])
+    a, b = synth_batch(int(g["seed"]), 1, int(g["h"]), int(g["w"]))
+    model = ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix(K=torch.from_numpy(g["cam_K"]), **cfg).to(DEV)
+    k1, k2, p, e = model(gpu(a), gpu(b))
+    k1n, k2n, pn, en = [t.cpu().numpy() for t in (k1, k2, p, e)]
+    assert {tuple(x) for x in k1n[0]} == {tuple(x) for x in g["k1"][0]} and {tuple(x) for x in k2n[0]} == {tuple(x) for x in g["k2"][0]}
+    if np.array_equal(k1n, g["k1"]) and np.array_equal(k2n, g["k2"]):
+        core = pn[:, :k, :k]
+        assert np.array_equal(core.argmax(2), g["P_rowarg"]) and np.array_equal(core.argmax(1), g["P_colarg"])
+        for mine, key in ((core.max(2), "P_rowmax"), (core.max(1), "P_colmax"), (pn[:, :, k], "P_dustcol"),
+                          (pn[:, k, :], "P_dustrow"), (pn[:, :8], "P_rows_0_8")):
+            ok, worst = p_close(mine, g[key])
+            assert ok, (key, worst)
+        mcfg = cfg_of(g, "mnn_cfg")
+        mk = [t.cpu().numpy() for t in mods["MutualNearestNeighborMatcher"](mcfg["max_matches"], mcfg["threshold"])(p, k1, k2)]
+        check_match_sets(match_dict(mk[0][0], mk[1][0], mk[2][0], mk[3][0]),
+                         match_dict(g["mk1"][0], g["mk2"][0], g["mscores"][0], g["mvalid"][0]), mcfg["max_matches"])
+    else:
+        pytest.fail("block-5 keypoint order differs from the reference's on the fixture input (sets equal): re-record or relax")
+    assert en.shape == (3, 3) and _e_close(en, g["E"], tol=1e-3), np.abs(en - g["E"]).max()
+    # uint8 frames (converted on the device for this family): identical outputs
+    for x, y in zip(model(gpu(a.astype(np.uint8)), gpu(b.astype(np.uint8))), (k1, k2, p, e)):
+        assert torch.equal(x, y)
+
+
 # ------------------------------------------------------------------ FAST / DoG detectors
 def test_fast_and_dog_detectors(mods):
     from onnx_image_processing_amd.pytorch_model.detector import DoGDetector, DoGDetectorWithScore, FASTScore

@@ -576,3 +576,24 @@ def test_oracle_dense_variant_vs_reference_480x640_k512():
     assert 0 < total <= 2 * 262144 // 1000
     core = p[:, :k, :k]
     assert np.array_equal(core.argmax(2), g["P_rowarg"]) and np.abs(core.max(2) - g["P_rowmax"]).max() < 0.06
+
+
+def test_oracle_vo_model_480x640_k512_vs_reference():
+    """The visual-odometry model at its deployment size (tests/golden/angle_vo_480x640_k512.npz, recorded from the reference's
+    ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix with the Angle export-CLI values): keypoints, P statistics and E."""
+    g = load_golden("angle_vo_480x640_k512")
+    cfg = cfg_of(g)
+    k = int(g["k"])
+    a, b = synth_batch(int(g["seed"]), 1, int(g["h"]), int(g["w"]))
+    kw = {kk: v for kk, v in cfg.items() if kk not in ("num_pairs", "max_keypoints")}
+    o1, o2, op = O.match_pair_angle(a, b, *bad_tables(cfg["num_pairs"]), k, **kw)
+    assert {tuple(x) for x in o1[0]} == {tuple(x) for x in g["k1"][0]} and {tuple(x) for x in o2[0]} == {tuple(x) for x in g["k2"][0]}
+    assert np.array_equal(o1, g["k1"]) and np.array_equal(o2, g["k2"])          # (block 5: equal here, not guaranteed in general)
+    core = op[:, :k, :k]
+    assert np.array_equal(core.argmax(2), g["P_rowarg"]) and np.array_equal(core.argmax(1), g["P_colarg"])
+    for mine, key in ((core.max(2), "P_rowmax"), (core.max(1), "P_colmax"), (op[:, :, k], "P_dustcol"), (op[:, k, :], "P_dustrow"),
+                      (op[:, :8], "P_rows_0_8")):
+        ok, worst = p_close(mine, g[key])
+        assert ok, (key, worst)
+    e = O.essential_matrix_keypoints(op[0], o1[0], o2[0], o1[0][:, 0] >= 0, o2[0][:, 0] >= 0, g["cam_K"])
+    assert np.abs(e - g["E"]).max() <= 1e-4 * max(1.0, np.abs(g["E"]).max())

@@ -32,7 +32,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/latency" -o latency 
 echo latency done
 # BASELINE configs[2] (sparse pipeline and dense-BAD matcher) and configs[3]: bench line, kernel statistics and the two
 # HBM-traffic passes each (so that their roofline objects carry a `traffic` figure)
-for wl in c3 c3dense c4; do
+for wl in c3 c3dense c4 vo; do
   timeout -k 10 300 python3 "$B" --workload $wl --pairs-per-gpu 128 > "$OUT/$wl.json" 2> "$OUT/$wl.err"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/${wl}stats" -o $wl -- python3 "$B" --workload $wl --pairs-per-gpu 128 --steps 5 --warmup 2 > "$OUT/${wl}stats.log" 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do

@@ -84,7 +84,7 @@ def side_traffic(wl, pairs):
     json.dump(o, open(os.path.join(dst, f"{tag}_{wl}_pmc_traffic.json"), "w"), indent=1)
 
 
-for wl, pairs in (("c3", 128), ("c3dense", 128), ("c4", 128)):
+for wl, pairs in (("c3", 128), ("c3dense", 128), ("c4", 128), ("vo", 128)):
     side_traffic(wl, pairs)
     stats_csv(wl + "stats", wl, f"{tag}_{wl}_kernel_stats.csv",
               f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --pairs-per-gpu {pairs} --steps 5 --warmup 2")
