@@ -350,10 +350,17 @@ MI_API int mi_normalise_keypoints(const float *keypoints, long long count, const
  * sums, Kronecker-factored normal equations, n_iter steps of shifted power iteration for the minimum
  * eigenvector, denormalisation, projection onto singular values (s, s, 0) with n_iter_manifold steps.
  * pts1 (batch, n, 2), pts2 (batch, m, 2): NORMALISED image coordinates (x, y) = K^-1 [px, py, 1].
- * e (batch, 3, 3).  n, m <= 1024, 1 <= top_k <= min(8, n, m).  Deterministic. */
+ * e (batch, 3, 3).  n, m <= 1024, 1 <= top_k <= min(8, n, m).  Deterministic.
+ * workspace (optional): mi_essential_matrix_workspace_bytes(batch, n, m, top_k) bytes, 16-byte aligned (the query returns
+ * 0 for top_k > 4: no banded form).  With it the head runs in two launches -- one pass over the matrix spread over the
+ * chip (bands of 32 rows: row thresholds, the rows' candidate entries, per-band column lists), then one workgroup per
+ * pair on the sparse weights -- instead of one workgroup per pair streaming the matrix four times (~0.6 ms per launch
+ * whatever the batch).  Same definition of every quantity; results agree with the workspace-less form to fp32 rounding
+ * (a row's / column's few weights are added in a different order).  NULL: the single-launch dense form. */
+MI_API size_t mi_essential_matrix_workspace_bytes(int batch, int n, int m, int top_k);
 MI_API int mi_essential_matrix(const float *p, int batch, int n, int m, const float *pts1, const float *pts2,
                         const uint8_t *valid1, const uint8_t *valid2, int top_k, int n_iter,
-                        int n_iter_manifold, float *e, mi_stream_t stream);
+                        int n_iter_manifold, float *e, void *workspace, size_t workspace_bytes, mi_stream_t stream);
 
 /* ---- detector/fast.py:198-239  FASTScore.forward (use_nms = False) ----------------------------------
  * score (n,1,h,w) = 1.0 where 9 contiguous pixels of the radius-3 circle (replicate padding) are all

@@ -67,8 +67,9 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_void_p],
     "mi_core_maxima": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mi_normalise_keypoints": [c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p],
+    "mi_essential_matrix_workspace_bytes": [c_int, c_int, c_int, c_int],
     "mi_essential_matrix": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                            c_void_p, c_void_p],
+                            c_void_p, c_void_p, c_size_t, c_void_p],
     "mi_fast_score": [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
     "mi_dog_responses": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mi_akaze_diffuse": [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p],
@@ -101,7 +102,7 @@ DEBUG_SIGNATURES = {"mi_debug_set": [c_int, c_int], "mi_debug_topk_stamps": [c_v
                     "mi_debug_sinkhorn_dots_form": [c_int, c_int, c_int, c_int, c_int, c_int],
                     "mi_debug_akaze_math_check": [c_int, c_float, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p]}
 SIGNATURES["mi_match_pairs_u8"] = SIGNATURES["mi_match_pairs"]
-_RESTYPE = {"mi_sinkhorn_dots_status_word": c_void_p, "mi_match_pairs_workspace_bytes": c_size_t, "mi_error_string": c_char_p, "mi_sinkhorn_workspace_bytes": c_size_t, "mi_bad_plan_bytes": c_size_t,
+_RESTYPE = {"mi_essential_matrix_workspace_bytes": c_size_t, "mi_sinkhorn_dots_status_word": c_void_p, "mi_match_pairs_workspace_bytes": c_size_t, "mi_error_string": c_char_p, "mi_sinkhorn_workspace_bytes": c_size_t, "mi_bad_plan_bytes": c_size_t,
             "mi_sinkhorn_dots_workspace_bytes": c_size_t, "mi_mnn_duals_workspace_bytes": c_size_t}
 
 MI_BAD_RAW, MI_BAD_SOFT, MI_BAD_HARD = 0, 1, 2

@@ -79,19 +79,24 @@ __device__ __forceinline__ void hartley_wave(const float *__restrict__ pts, cons
   }
 }
 
-__global__ __launch_bounds__(EM_T) void em_estimate_kernel(const float *__restrict__ p, int n, int m,
-                                                           const float *__restrict__ pts1,
-                                                           const float *__restrict__ pts2,
-                                                           const uint8_t *__restrict__ valid1,
-                                                           const uint8_t *__restrict__ valid2, int top_k, int n_iter,
-                                                           int n_iter_manifold, float *__restrict__ e_out) {
-  __shared__ float thr_row[EM_MAXN], thr_col[EM_MAXN], w1[EM_MAXN], w2[EM_MAXN], v1s[EM_MAXN], v2s[EM_MAXN];
-  __shared__ float f2x[EM_MAXN], f2y[EM_MAXN];
-  __shared__ float mpart[EM_W][81];
-  __shared__ float mflat[81];
-  __shared__ float hart[6];        // c1x, c1y, s1, c2x, c2y, s2
+// LDS state shared by the dense front, the sparse front and the solve
+struct EmShared {
+  float thr_row[EM_MAXN], thr_col[EM_MAXN], w1[EM_MAXN], w2[EM_MAXN], v1s[EM_MAXN], v2s[EM_MAXN];
+  float f2x[EM_MAXN], f2y[EM_MAXN];
+  float mpart[EM_W][81];
+  float mflat[81];
+  float hart[6];        // c1x, c1y, s1, c2x, c2y, s2
+};
+
+// Dense front: thresholds, weights, Hartley parameters and the 81 normal-equation sums of pair b, by one 1024-thread
+// workgroup streaming P four times.  Leaves S.mflat / S.hart ready (a barrier has been passed).
+__device__ void em_dense_front(EmShared &S, const float *__restrict__ p, int b, int n, int m,
+                               const float *__restrict__ pts1, const float *__restrict__ pts2,
+                               const uint8_t *__restrict__ valid1, const uint8_t *__restrict__ valid2, int top_k) {
+  float *thr_row = S.thr_row, *thr_col = S.thr_col, *w1 = S.w1, *w2 = S.w2, *v1s = S.v1s, *v2s = S.v2s, *f2x = S.f2x, *f2y = S.f2y;
+  float (*mpart)[81] = S.mpart;
+  float *mflat = S.mflat, *hart = S.hart;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int b = blockIdx.x;
   const float *pb = p + (size_t)b * (n + 1) * (size_t)(m + 1);
   const size_t pitch = (size_t)(m + 1);
   const float *q1 = pts1 + (size_t)b * n * 2, *q2 = pts2 + (size_t)b * m * 2;
@@ -200,7 +205,11 @@ __global__ __launch_bounds__(EM_T) void em_estimate_kernel(const float *__restri
     mflat[t] = s;
   }
   __syncthreads();
-  if (t != 0) return;
+}
+
+// The serial tail (one thread): 9x9 minimum eigenvector, denormalisation, manifold projection -> E of pair b
+__device__ void em_solve(const EmShared &S, int b, int n_iter, int n_iter_manifold, float *__restrict__ e_out) {
+  const float *mflat = S.mflat, *hart = S.hart;
 
   // ---- 9x9 minimum eigenvector by shifted power iteration (:150-173)
   float mm[9][9];
@@ -268,6 +277,291 @@ __global__ __launch_bounds__(EM_T) void em_estimate_kernel(const float *__restri
     for (int c = 0; c < 3; ++c) out[r * 3 + c] = (um[r][0] * s_avg) * vm[c][0] + (um[r][1] * s_avg) * vm[c][1];
 }
 
+__global__ __launch_bounds__(EM_T) void em_estimate_kernel(const float *__restrict__ p, int n, int m,
+                                                           const float *__restrict__ pts1,
+                                                           const float *__restrict__ pts2,
+                                                           const uint8_t *__restrict__ valid1,
+                                                           const uint8_t *__restrict__ valid2, int top_k, int n_iter,
+                                                           int n_iter_manifold, float *__restrict__ e_out) {
+  __shared__ EmShared S;
+  em_dense_front(S, p, (int)blockIdx.x, n, m, pts1, pts2, valid1, valid2, top_k);
+  if (threadIdx.x == 0) em_solve(S, (int)blockIdx.x, n_iter, n_iter_manifold, e_out);
+}
+
+// ---- round 3: the same head spread over the chip --------------------------------------------------------------------
+// The dense kernel above gives one workgroup per pair four passes over a 1 MB matrix: ~0.6 ms per launch whatever the
+// batch (128 pairs: 128 workgroups on 256 CUs, each bound by the latency of its own dependent loads) -- three times
+// the rest of the VO model for one pair per call.  But the weights are SPARSE: an entry counts only if it is among the
+// top_k of its row (and of its column, and > 0.01), i.e. at most top_k + ties entries per row.  So:
+//   em_band_kernel    grid (bands of 32 rows, pairs): ONE pass over the matrix.  Per row: the k-th largest value (wave
+//                     reduction over per-lane sorted insertion, as above) and the row's candidates -- entries >= it and
+//                     > 0.01, at most EM_CAND, else the row is flagged; per column: the band's top_k values (lanes own
+//                     columns, merged over the band's waves in LDS).
+//   em_sparse_kernel  one workgroup per pair: column thresholds from the bands' lists, weights of the candidates, row
+//                     sums, column sums (every column's few contributions ordered by row before they are added:
+//                     deterministic), Hartley parameters, normal equations from per-row moment sums (same wave / row
+//                     partition as the dense kernel), then the same serial solve.  A flagged row or a column with more
+//                     than EM_CAND contributions (massive exact ties) sends the pair through em_dense_front instead.
+// Same definition of every quantity; sums over a row's / column's handful of weights are formed in a different order than
+// the dense kernel's lane-strided sums, so the two agree to fp32 rounding (the tests' tolerance), not bit for bit.
+constexpr int EM_CAND = 8;          // candidates kept per row / contributions kept per column
+constexpr int EB_WAVES = 8, EB_RPW = 4, EB_ROWS = EB_WAVES * EB_RPW;   // band: 8 waves x 4 rows
+
+template <int K, int Q>             // K = top_k (1..4), Q = 64-column groups per row (8: m <= 512, 16: m <= 1024)
+__global__ __launch_bounds__(64 * EB_WAVES) void em_band_kernel(const float *__restrict__ p, int n, int m,
+                                                                const uint8_t *__restrict__ valid1,
+                                                                const uint8_t *__restrict__ valid2,
+                                                                float *__restrict__ thr_row, uint8_t *__restrict__ cand_cnt,
+                                                                int *__restrict__ cand_j, float *__restrict__ cand_x,
+                                                                float *__restrict__ col_part) {
+  __shared__ float ctop_s[EB_WAVES][64 * Q][K];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y, band = blockIdx.x, nb = gridDim.x;
+  const float *pb = p + (size_t)b * (n + 1) * (size_t)(m + 1);
+  const size_t pitch = (size_t)(m + 1);
+  float v2[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int j = lane + 64 * q;
+    v2[q] = j < m ? (valid2 ? (valid2[(size_t)b * m + j] ? 1.0f : 0.0f) : 1.0f) : 0.0f;
+  }
+  float ctop[Q][K];                  // this wave's top K of every column it has seen (descending)
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+#pragma unroll
+    for (int k = 0; k < K; ++k) ctop[q][k] = -INFINITY;
+  for (int r = 0; r < EB_RPW; ++r) {
+    const int i = band * EB_ROWS + wave * EB_RPW + r;
+    if (i >= n) break;                                            // wave-uniform
+    const float v1 = valid1 ? (valid1[(size_t)b * n + i] ? 1.0f : 0.0f) : 1.0f;
+    float x[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int j = lane + 64 * q;
+      x[q] = j < m ? (pb[(size_t)i * pitch + j] * v1) * v2[q] : -INFINITY;      // core (:334-343); -inf past the matrix
+    }
+    float top[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) top[k] = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      float y = x[q];
+#pragma unroll
+      for (int k = 0; k < K; ++k) { const float hi = fmaxf(top[k], y), lo = fminf(top[k], y); top[k] = hi; y = lo; }
+      float z = x[q];
+#pragma unroll
+      for (int k = 0; k < K; ++k) { const float hi = fmaxf(ctop[q][k], z), lo = fminf(ctop[q][k], z); ctop[q][k] = hi; z = lo; }
+    }
+    float kth = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < K; ++s) {                                 // pop the wave-wide maximum K times (multiplicity kept)
+      kth = wave_max_dpp(top[0]);
+      const unsigned long long owners = __ballot(top[0] == kth);
+      if (lane == __ffsll((long long)owners) - 1) {
+#pragma unroll
+        for (int k = 0; k + 1 < K; ++k) top[k] = top[k + 1];
+        top[K - 1] = -INFINITY;
+      }
+    }
+    // candidates of the row: entries >= the k-th largest that can carry weight at all (> 0.01, :345-358)
+    uint32_t cnt = 0;
+    const size_t cbase = ((size_t)b * n + i) * EM_CAND;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const bool c = x[q] >= kth && x[q] > 0.01f;
+      const unsigned long long mk = __ballot(c);
+      if (c) {
+        const uint32_t slot = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+        if (slot < (uint32_t)EM_CAND) { cand_j[cbase + slot] = lane + 64 * q; cand_x[cbase + slot] = x[q]; }
+      }
+      cnt += (uint32_t)__popcll(mk);
+    }
+    if (lane == 0) {
+      thr_row[(size_t)b * n + i] = kth;
+      cand_cnt[(size_t)b * n + i] = cnt > (uint32_t)EM_CAND ? (uint8_t)255 : (uint8_t)cnt;
+    }
+  }
+  // the band's top K per column: merge the waves' lists
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+#pragma unroll
+    for (int k = 0; k < K; ++k) ctop_s[wave][lane + 64 * q][k] = ctop[q][k];
+  __syncthreads();
+  for (int j = threadIdx.x; j < m; j += 64 * EB_WAVES) {
+    float top[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) top[k] = ctop_s[0][j][k];
+    for (int w = 1; w < EB_WAVES; ++w)
+#pragma unroll
+      for (int k2 = 0; k2 < K; ++k2) {
+        float y = ctop_s[w][j][k2];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { const float hi = fmaxf(top[k], y), lo = fminf(top[k], y); top[k] = hi; y = lo; }
+      }
+#pragma unroll
+    for (int k = 0; k < K; ++k) col_part[(((size_t)b * nb + band) * m + j) * K + k] = top[k];
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(EM_T) void em_sparse_kernel(const float *__restrict__ p, int n, int m,
+                                                         const float *__restrict__ pts1, const float *__restrict__ pts2,
+                                                         const uint8_t *__restrict__ valid1,
+                                                         const uint8_t *__restrict__ valid2, int n_iter,
+                                                         int n_iter_manifold, const float *__restrict__ thr_row_g,
+                                                         const uint8_t *__restrict__ cand_cnt,
+                                                         const int *__restrict__ cand_j, const float *__restrict__ cand_x,
+                                                         const float *__restrict__ col_part, int nb,
+                                                         float *__restrict__ e_out) {
+  __shared__ EmShared S;
+  __shared__ float cw[EM_MAXN][EM_CAND];        // a column's contributions: weights ...
+  __shared__ short ci[EM_MAXN][EM_CAND];        // ... and the rows they come from
+  __shared__ int ccount[EM_MAXN];
+  __shared__ float rmom[EM_MAXN][6];            // per row: sum_j w f2x^2, w f2x f2y, w f2x, w f2y^2, w f2y, w
+  __shared__ int s_dense;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int b = blockIdx.x;
+  const float *q1 = pts1 + (size_t)b * n * 2, *q2 = pts2 + (size_t)b * m * 2;
+  if (t == 0) s_dense = 0;
+  for (int j = t; j < m; j += EM_T) ccount[j] = 0;
+  __syncthreads();
+  // column thresholds: the k-th largest of the bands' top-K lists (their union holds the column's top K with multiplicity)
+  for (int j = t; j < m; j += EM_T) {
+    float top[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) top[k] = -INFINITY;
+    for (int band = 0; band < nb; ++band)
+#pragma unroll
+      for (int k2 = 0; k2 < K; ++k2) {
+        float y = col_part[(((size_t)b * nb + band) * m + j) * K + k2];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { const float hi = fmaxf(top[k], y), lo = fminf(top[k], y); top[k] = hi; y = lo; }
+      }
+    S.thr_col[j] = top[K - 1];
+  }
+  for (int i = t; i < n; i += EM_T)
+    if (cand_cnt[(size_t)b * n + i] == 255) s_dense = 1;          // more tied candidates than kept: dense front
+  __syncthreads();
+  // weights of the candidates; a row's sum; every weighted entry filed under its column
+  for (int i = t; i < n; i += EM_T) {
+    const int cnt = cand_cnt[(size_t)b * n + i] == 255 ? 0 : (int)cand_cnt[(size_t)b * n + i];
+    float s = 0.0f;
+    for (int c = 0; c < cnt; ++c) {
+      const int j = cand_j[((size_t)b * n + i) * EM_CAND + c];
+      const float x = cand_x[((size_t)b * n + i) * EM_CAND + c];
+      const float w = x >= S.thr_col[j] ? x : 0.0f;              // (>= thr_row and > 0.01 hold for every candidate)
+      s += w;
+      if (w != 0.0f) {
+        const int slot = atomicAdd(&ccount[j], 1);
+        if (slot < EM_CAND) { cw[j][slot] = w; ci[j][slot] = (short)i; } else s_dense = 1;
+      }
+    }
+    S.w1[i] = s;
+  }
+  __syncthreads();
+  if (s_dense) {                                                  // workgroup-uniform
+    __syncthreads();
+    em_dense_front(S, p, b, n, m, pts1, pts2, valid1, valid2, K);
+  } else {
+    // column sums: a column's contributions arrive in any order; they are ADDED in ascending row order
+    for (int j = t; j < m; j += EM_T) {
+      const int cnt = ccount[j];
+      float wv[EM_CAND];
+      short iv[EM_CAND];
+#pragma unroll
+      for (int c = 0; c < EM_CAND; ++c) { wv[c] = c < cnt ? cw[j][c] : 0.0f; iv[c] = c < cnt ? ci[j][c] : (short)0x7fff; }
+#pragma unroll
+      for (int a2 = 1; a2 < EM_CAND; ++a2)                        // insertion sort by row (<= 8 entries, registers)
+#pragma unroll
+        for (int c = a2; c > 0; --c)
+          if (iv[c] < iv[c - 1]) { const short ti = iv[c]; iv[c] = iv[c - 1]; iv[c - 1] = ti; const float tw = wv[c]; wv[c] = wv[c - 1]; wv[c - 1] = tw; }
+      float s = 0.0f;
+#pragma unroll
+      for (int c = 0; c < EM_CAND; ++c) s += wv[c];
+      S.w2[j] = s;
+    }
+    __syncthreads();
+    if (wave == 0) hartley_wave(q1, S.w1, n, lane, S.hart);
+    if (wave == 1) hartley_wave(q2, S.w2, m, lane, S.hart + 3);
+    __syncthreads();
+    for (int j = t; j < m; j += EM_T) {
+      S.f2x[j] = (q2[2 * j + 0] - S.hart[3]) * S.hart[5];
+      S.f2y[j] = (q2[2 * j + 1] - S.hart[4]) * S.hart[5];
+    }
+    __syncthreads();
+    // per-row moment sums over the row's weighted candidates (:401-414, inner factor W F2)
+    for (int i = t; i < n; i += EM_T) {
+      const int cnt = (int)cand_cnt[(size_t)b * n + i];
+      float sxx = 0.0f, sxy = 0.0f, sx = 0.0f, syy = 0.0f, sy = 0.0f, s1 = 0.0f;
+      for (int c = 0; c < cnt; ++c) {
+        const int j = cand_j[((size_t)b * n + i) * EM_CAND + c];
+        const float xv = cand_x[((size_t)b * n + i) * EM_CAND + c];
+        const float w = xv >= S.thr_col[j] ? xv : 0.0f;
+        const float x = S.f2x[j], y = S.f2y[j];
+        sxx += w * (x * x); sxy += w * (x * y); sx += w * x; syy += w * (y * y); sy += w * y; s1 += w;
+      }
+      rmom[i][0] = sxx; rmom[i][1] = sxy; rmom[i][2] = sx; rmom[i][3] = syy; rmom[i][4] = sy; rmom[i][5] = s1;
+    }
+    __syncthreads();
+    // outer factor F1^T (.): the dense kernel's wave / row partition and accumulation order
+    float acc0 = 0.0f, acc1 = 0.0f;
+    for (int i = wave; i < n; i += EM_W) {
+      const float wf2[9] = {rmom[i][0], rmom[i][1], rmom[i][2], rmom[i][1], rmom[i][3], rmom[i][4], rmom[i][2], rmom[i][4], rmom[i][5]};
+      const float f1[3] = {(q1[2 * i + 0] - S.hart[0]) * S.hart[2], (q1[2 * i + 1] - S.hart[1]) * S.hart[2], 1.0f};
+      {
+        const int e = lane, pr = e / 9, qs = e - pr * 9;
+        float wsel = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) wsel = (qs == c) ? wf2[c] : wsel;
+        acc0 += (f1[pr / 3] * f1[pr % 3]) * wsel;
+      }
+      if (lane < 81 - 64) {
+        const int e = 64 + lane, pr = e / 9, qs = e - pr * 9;
+        float wsel = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) wsel = (qs == c) ? wf2[c] : wsel;
+        acc1 += (f1[pr / 3] * f1[pr % 3]) * wsel;
+      }
+    }
+    S.mpart[wave][lane] = acc0;
+    if (lane < 81 - 64) S.mpart[wave][64 + lane] = acc1;
+    __syncthreads();
+    if (t < 81) {
+      float s = 0.0f;
+#pragma unroll
+      for (int w = 0; w < EM_W; ++w) s += S.mpart[w][t];
+      S.mflat[t] = s;
+    }
+    __syncthreads();
+  }
+  if (t == 0) em_solve(S, b, n_iter, n_iter_manifold, e_out);
+}
+
+// workspace of the banded form, per pair: thr_row (n floats), candidate counts (n bytes, padded), candidates
+// (n x EM_CAND x (int + float)), the bands' column lists (bands x m x K floats)
+struct EmWork {
+  float *thr_row;
+  uint8_t *cand_cnt;
+  int *cand_j;
+  float *cand_x;
+  float *col_part;
+  size_t total;
+};
+EmWork em_carve(void *ws, int batch, int n, int m, int k) {
+  const int nb = ceil_div(n, EB_ROWS);
+  char *base = reinterpret_cast<char *>(ws);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char *q = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return q; };
+  EmWork w;
+  w.thr_row = reinterpret_cast<float *>(take((size_t)batch * n * 4));
+  w.cand_cnt = reinterpret_cast<uint8_t *>(take((size_t)batch * n));
+  w.cand_j = reinterpret_cast<int *>(take((size_t)batch * n * EM_CAND * 4));
+  w.cand_x = reinterpret_cast<float *>(take((size_t)batch * n * EM_CAND * 4));
+  w.col_part = reinterpret_cast<float *>(take((size_t)batch * nb * m * k * 4));
+  w.total = off;
+  return w;
+}
+
 }  // namespace
 
 namespace {
@@ -294,16 +588,44 @@ extern "C" int mi_normalise_keypoints(const float *keypoints, long long count, c
   return mi_launch_status();
 }
 
+extern "C" size_t mi_essential_matrix_workspace_bytes(int batch, int n, int m, int top_k) {
+  if (batch <= 0 || n <= 0 || m <= 0 || n > EM_MAXN || m > EM_MAXN || top_k < 1 || top_k > 4 || batch > 65535) return 0;
+  return em_carve(nullptr, batch, n, m, top_k).total;
+}
+
 extern "C" int mi_essential_matrix(const float *p, int batch, int n, int m, const float *pts1, const float *pts2,
                                    const uint8_t *valid1, const uint8_t *valid2, int top_k, int n_iter,
-                                   int n_iter_manifold, float *e, mi_stream_t stream) {
+                                   int n_iter_manifold, float *e, void *workspace, size_t workspace_bytes,
+                                   mi_stream_t stream) {
   MI_ENTER();
   if (!p || !pts1 || !pts2 || !e) return MI_E_NULL;
   if ((valid1 == nullptr) != (valid2 == nullptr)) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0) return MI_E_SHAPE;
   if (n > EM_MAXN || m > EM_MAXN) return MI_E_PARAM;
   if (top_k <= 0 || top_k > EM_MAXK || top_k > n || top_k > m || n_iter < 0 || n_iter_manifold < 0) return MI_E_PARAM;
-  hipLaunchKernelGGL(em_estimate_kernel, dim3(batch), dim3(EM_T), 0, (hipStream_t)stream, p, n, m, pts1, pts2, valid1,
-                     valid2, top_k, n_iter, n_iter_manifold, e);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t need = mi_essential_matrix_workspace_bytes(batch, n, m, top_k);
+  if (workspace && need > 0) {
+    // banded form: one pass over the matrix spread over the chip, then one workgroup per pair on the sparse weights
+    if (((uintptr_t)workspace % 16) != 0) return MI_E_ALIGN;
+    if (workspace_bytes < need) return MI_E_CAPACITY;
+    const EmWork w = em_carve(workspace, batch, n, m, top_k);
+    const int nb = ceil_div(n, EB_ROWS);
+    const dim3 grid(nb, batch);
+#define EM_BAND(K, Q) hipLaunchKernelGGL((em_band_kernel<K, Q>), grid, dim3(64 * EB_WAVES), 0, s, p, n, m, valid1, valid2, w.thr_row, w.cand_cnt, w.cand_j, w.cand_x, w.col_part)
+#define EM_SPARSE(K) hipLaunchKernelGGL((em_sparse_kernel<K>), dim3(batch), dim3(EM_T), 0, s, p, n, m, pts1, pts2, valid1, valid2, n_iter, n_iter_manifold, w.thr_row, w.cand_cnt, w.cand_j, w.cand_x, w.col_part, nb, e)
+    const bool wide = m > 512;
+    switch (top_k) {
+      case 1: if (wide) EM_BAND(1, 16); else EM_BAND(1, 8); MI_CHECK_LAUNCH(); EM_SPARSE(1); break;
+      case 2: if (wide) EM_BAND(2, 16); else EM_BAND(2, 8); MI_CHECK_LAUNCH(); EM_SPARSE(2); break;
+      case 3: if (wide) EM_BAND(3, 16); else EM_BAND(3, 8); MI_CHECK_LAUNCH(); EM_SPARSE(3); break;
+      default: if (wide) EM_BAND(4, 16); else EM_BAND(4, 8); MI_CHECK_LAUNCH(); EM_SPARSE(4); break;
+    }
+#undef EM_BAND
+#undef EM_SPARSE
+    return mi_launch_status();
+  }
+  hipLaunchKernelGGL(em_estimate_kernel, dim3(batch), dim3(EM_T), 0, s, p, n, m, pts1, pts2, valid1, valid2, top_k, n_iter,
+                     n_iter_manifold, e);
   return mi_launch_status();
 }

@@ -497,8 +497,10 @@ def akaze_orientation_at_keypoints(scale_scores: torch.Tensor, scale_theta: torc
 # ---- essential-matrix head (geometry/essential_matrix_estimator.py) ---------------------------------
 
 def essential_matrix(p: torch.Tensor, pts1_n: torch.Tensor, pts2_n: torch.Tensor, valid1: torch.Tensor | None,
-                     valid2: torch.Tensor | None, top_k: int, n_iter: int, n_iter_manifold: int) -> torch.Tensor:
-    """P (B,N+1,M+1), normalised points (B,N,2)/(B,M,2) as (x,y), optional validity (B,N)/(B,M) -> E (B,3,3)."""
+                     valid2: torch.Tensor | None, top_k: int, n_iter: int, n_iter_manifold: int,
+                     banded: bool = True) -> torch.Tensor:
+    """P (B,N+1,M+1), normalised points (B,N,2)/(B,M,2) as (x,y), optional validity (B,N)/(B,M) -> E (B,3,3).
+    banded: the two-launch form on a workspace (top_k <= 4); False: the single-launch dense form."""
     if p.dim() != 3:
         raise RuntimeError(f"P must have shape (B, N+1, M+1), got {tuple(p.shape)}")
     pp = p.float().contiguous()
@@ -511,10 +513,12 @@ def essential_matrix(p: torch.Tensor, pts1_n: torch.Tensor, pts2_n: torch.Tensor
     v1 = valid1.to(torch.uint8).contiguous() if valid1 is not None else None
     v2 = valid2.to(torch.uint8).contiguous() if valid2 is not None else None
     e = torch.empty((b, 3, 3), dtype=F32, device=pp.device)
+    wbytes = int(N.load().mi_essential_matrix_workspace_bytes(b, n, m, int(top_k))) if banded else 0
+    work = torch.empty(((wbytes + 7) // 8,), dtype=torch.int64, device=pp.device) if wbytes else None
     N.call("mi_essential_matrix", N.dev(pp, F32, "P"), b, n, m, N.dev(q1, F32, "pts1"), N.dev(q2, F32, "pts2"),
            N.dev(v1, torch.uint8, "valid1") if v1 is not None else None,
            N.dev(v2, torch.uint8, "valid2") if v2 is not None else None, int(top_k), int(n_iter), int(n_iter_manifold),
-           e.data_ptr(), N.stream_ptr())
+           e.data_ptr(), work.data_ptr() if work is not None else None, wbytes, N.stream_ptr())
     return e
 
 

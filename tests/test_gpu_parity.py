@@ -1015,6 +1015,56 @@ def test_essential_matrix_estimator_vs_oracle_and_golden(mods):
         EssentialMatrixEstimator(K=kg, image_shape=(32, 32), top_k=9).to(DEV)(gpu(p[0]))
 
 
+def test_essential_matrix_banded_form_equals_dense_form(mods):
+    """mi_essential_matrix with a workspace (one pass over P spread over the chip + one workgroup per pair on the sparse
+    weights) against the single-launch dense form and the oracle: random matrices with a few confident entries per row,
+    top_k 1..4, n != m, m > 512 (two column chunks per lane), validity masks, an all-zero row and column, exact ties inside
+    the top k (six equal values in a row), and massive ties that overflow a row's candidate list and a column's
+    contribution list (the pair then goes through the dense front inside the sparse kernel)."""
+    from onnx_image_processing_amd import ops
+    rng = np.random.default_rng(77)
+
+    def pts(bn, cnt):
+        return gpu((rng.random((bn, cnt, 2)).astype(np.float32) - 0.5) * 1.2)
+
+    def run(pm, top_k, v1=None, v2=None):
+        bn, n1, m1 = pm.shape
+        q1, q2 = pts(bn, n1 - 1), pts(bn, m1 - 1)
+        outs = [ops.essential_matrix(gpu(pm), q1, q2, v1, v2, top_k, 30, 10, banded=f).cpu().numpy() for f in (True, False)]
+        for bi in range(bn):
+            assert _e_close(outs[0][bi], outs[1][bi], tol=2e-4), (pm.shape, top_k, bi, np.abs(outs[0][bi] - outs[1][bi]).max())
+        again = ops.essential_matrix(gpu(pm), q1, q2, v1, v2, top_k, 30, 10, banded=True).cpu().numpy()
+        assert np.array_equal(again, outs[0])                                  # deterministic
+        return outs[0]
+
+    for shape in ((3, 513, 513), (2, 201, 141), (2, 65, 97), (2, 300, 1025), (1, 1025, 1025), (1, 34, 20)):
+        pm = rng.random(shape).astype(np.float32) ** 6
+        for top_k in (1, 2, 3, 4):
+            run(pm, top_k)
+    pm = rng.random((3, 257, 301)).astype(np.float32) ** 4
+    pm[0, 5, :] = 0.0
+    pm[0, :, 7] = 0.0
+    pm[1, 9, 3:9] = 0.5                                                           # six equal values in one row
+    pm[2, 20:40, 11] = 0.75                                                       # twenty equal values in one column
+    run(pm, 3)
+    v1 = gpu(rng.random((3, 256)) > 0.2)
+    v2 = gpu(rng.random((3, 300)) > 0.2)
+    run(pm, 3, v1, v2)
+    ties = np.full((2, 129, 129), 0.3, np.float32)                                # every entry tied: candidate lists overflow
+    ties[1] = rng.random((129, 129)).astype(np.float32) ** 5                      # (pair 1 stays on the sparse path)
+    run(ties, 3)
+    col_over = rng.random((1, 200, 90)).astype(np.float32) * 0.005                # nothing above 0.01 ...
+    col_over[0, :40, 17] = np.linspace(0.5, 0.9, 40, dtype=np.float32)            # ... but one column with 40 row-winners
+    col_over[0, :40, 18] = 0.45
+    run(col_over, 3)
+    # the banded form against the oracle directly (grid form of the estimator)
+    from onnx_image_processing_amd.pytorch_model.geometry import EssentialMatrixEstimator
+    g = load_golden("essential_matrix")
+    est = EssentialMatrixEstimator(K=torch.from_numpy(g["grid_K"]), image_shape=(32, 32)).to(DEV)
+    for i in range(3):
+        assert _e_close(est(gpu(g[f"grid{i}_P"])).cpu().numpy(), O.essential_matrix_grid(g[f"grid{i}_P"], g["grid_K"]))
+
+
 @pytest.mark.parametrize("name", ["st", "st_soft", "ak"])
 def test_essential_matrix_composites_vs_golden(mods, name):
     from onnx_image_processing_amd.pytorch_model.feature_detection import (

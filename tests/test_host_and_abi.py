@@ -240,12 +240,18 @@ def test_argument_validation_of_the_widened_entries(lib_path):
     buf = ctypes.create_string_buffer(256)
     p = ctypes.cast(buf, ctypes.c_void_p)
     vp, ci, cf, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double
-    lib.mi_essential_matrix.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, ci, vp, vp]
-    assert lib.mi_essential_matrix(None, 1, 8, 8, p, p, None, None, 3, 30, 10, p, None) == -1       # NULL P
-    assert lib.mi_essential_matrix(p, 1, 8, 8, p, p, p, None, 3, 30, 10, p, None) == -1             # one validity mask only
-    assert lib.mi_essential_matrix(p, 1, 2000, 8, p, p, None, None, 3, 30, 10, p, None) == -3       # n > 1024
-    assert lib.mi_essential_matrix(p, 1, 8, 8, p, p, None, None, 9, 30, 10, p, None) == -3          # top_k > 8
-    assert lib.mi_essential_matrix(p, 1, 2, 8, p, p, None, None, 3, 30, 10, p, None) == -3          # top_k > n
+    lib.mi_essential_matrix.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, ci, ci, ci, vp, vp, ctypes.c_size_t, vp]
+    assert lib.mi_essential_matrix(None, 1, 8, 8, p, p, None, None, 3, 30, 10, p, None, 0, None) == -1       # NULL P
+    assert lib.mi_essential_matrix(p, 1, 8, 8, p, p, p, None, 3, 30, 10, p, None, 0, None) == -1             # one validity mask only
+    assert lib.mi_essential_matrix(p, 1, 2000, 8, p, p, None, None, 3, 30, 10, p, None, 0, None) == -3       # n > 1024
+    assert lib.mi_essential_matrix(p, 1, 8, 8, p, p, None, None, 9, 30, 10, p, None, 0, None) == -3          # top_k > 8
+    assert lib.mi_essential_matrix(p, 1, 2, 8, p, p, None, None, 3, 30, 10, p, None, 0, None) == -3          # top_k > n
+    lib.mi_essential_matrix_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.mi_essential_matrix_workspace_bytes(1, 512, 512, 5) == 0                                   # banded form: top_k <= 4
+    need = lib.mi_essential_matrix_workspace_bytes(2, 512, 512, 3)
+    assert need >= 2 * (512 * 4 + 512 + 512 * 8 * 8 + 16 * 512 * 3 * 4)
+    assert lib.mi_essential_matrix(p, 2, 512, 512, p, p, None, None, 3, 30, 10, p, p, need - 1, None) == -4  # workspace too small
+    assert lib.mi_essential_matrix(p, 2, 512, 512, p, p, None, None, 3, 30, 10, p, ctypes.c_void_p(p.value + 4), need, None) == -5
     lib.mi_mnn_duals_workspace_bytes.restype = ctypes.c_size_t
     lib.mi_mnn_duals_workspace_bytes.argtypes = [ci, ci, ci]
     assert lib.mi_mnn_duals_workspace_bytes(2, 512, 512) == (2 * 512 + 2 * 512 + 2 * 16 * 512) * 8
