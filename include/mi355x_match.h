@@ -189,12 +189,16 @@ MI_API int mi_angle_at_keypoints(const float *image, int n, int h, int w, const 
  * neighbouring centres interpolated as grid_sample "bilinear" does (bad.py:535-549), response and
  * sign test in fp32.  The non-oriented bilinear case is angle 0 for every keypoint.
  * status (optional): n*k bytes of workspace; when given, keypoints on uint8-valued windows are done
- * with an int32 table (half the LDS, same results) and only the rest with the fp64 one. */
+ * with an int32 table (half the LDS, same results) and only the rest with the fp64 one.
+ * max_reach: an upper bound, in pixels, of |pair offset from the patch centre| + box radius over the pair table, or 0 if
+ * unknown.  0 < max_reach <= 22.5 (both reference tables: 22.22) lets the nearest mode use a 48 x 48 instead of a
+ * 60 x 60 window per keypoint (same results, more keypoints in flight); a bound the table exceeds is a contract
+ * violation (boxes clipped to the window). */
 MI_API int mi_sparse_bad_oriented(const float *image, int n, int h, int w, const float *keypoints, int k,
                            const float *orientation_map, const float *keypoint_angles,
                            const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
-                           float temperature, int normalize, int bilinear, float *desc, uint32_t *bits,
-                           uint8_t *status, mi_stream_t stream);
+                           float temperature, int normalize, int bilinear, float max_reach, float *desc,
+                           uint32_t *bits, uint8_t *status, mi_stream_t stream);
 
 /* ---- matching/sinkhorn.py:79-110,178  cost matrix -> core log-score matrix --------------------
  * z[b, i, j] = -cost(desc1[b,i], desc2[b,j]) / epsilon for i < n, j < m; row pitch `pitch` floats

@@ -43,7 +43,7 @@ SIGNATURES = {
     "mi_angle_map": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mi_angle_at_keypoints": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mi_sparse_bad_oriented": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+                               c_int, c_int, c_float, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "mi_cost_logscores_bits": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p],
     "mi_cost_logscores_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p],
     "mi_sinkhorn_workspace_bytes": [c_int, c_int, c_int],

@@ -17,9 +17,12 @@
 
 namespace {
 
-constexpr int OW = 60;            // window edge
-constexpr int OOFF = 29;          // window origin = floor(k) - OOFF
-constexpr int OSP = OW + 1;       // SAT edge
+// Window edge OW (template argument): 60 covers any table of the 32x32 patch frame (rotated offsets reach
+// sqrt(15^2+15^2) = 21.2 px, radius <= 7, bilinear neighbour + 1); 48 covers tables whose largest |offset| + radius
+// is <= 22.5 px in the nearest mode -- the caller states that bound (max_reach) -- [f-23, f+24] then holds every box:
+// frac(k) + reach + 0.5 (rounding of the centre) < 24.  Both reference tables reach 22.22 px.  A 48-pixel window is
+// 9.6 instead of 14.9 KB of LDS per keypoint and 48 instead of 60 loads per lane: more windows in flight per CU, which
+// is what bounds this kernel.
 
 __device__ __forceinline__ int nearest_centre_o(float pos, float scale, int size) {
   const float g = pos * scale - 1.0f;
@@ -30,7 +33,9 @@ __device__ __forceinline__ int nearest_centre_o(float pos, float scale, int size
 
 // SAT = int: exact for uint8-valued windows (checked per keypoint; others are flagged status = 0 and left
 // to the SAT = double instance), half the LDS, so twice the resident keypoints per CU.
-template <typename SAT>
+// DESC = false (packed bits only, what the matchers ask for): no float staging array -- 14.9 instead of 19 KB of LDS per
+// keypoint, i.e. 10 instead of 8 resident keypoints per CU; the kernel is bound by how many windows are in flight.
+template <typename SAT, bool DESC, int OW>
 __global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restrict__ image, int h, int w,
                                                           const float *__restrict__ kpts, int k,
                                                           const float *__restrict__ theta_map,
@@ -43,8 +48,11 @@ __global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restric
                                                           uint32_t *__restrict__ bits,
                                                           uint8_t *__restrict__ status) {
   constexpr bool INT = sizeof(SAT) == 4;
+  constexpr int OOFF = OW / 2 - 1;  // window origin = floor(k) - OOFF
+  constexpr int OSP = OW + 1;       // SAT edge
+  constexpr int RB = OW / 4;        // rows / columns per batch of the in-LDS prefix pass
   __shared__ SAT sat[OSP * OSP];
-  __shared__ float vals[1024];
+  __shared__ float vals[DESC ? 1024 : 1];
   const int lane = threadIdx.x;
   const int flat = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
   if (!INT && status && status[flat]) return;                          // the integer instance did this keypoint
@@ -72,20 +80,19 @@ __global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restric
   if (lane < OW) {
     const int gx = clampi(ox + lane, 0, w - 1);
     SAT acc = (SAT)0;
-#pragma unroll 4
-    for (int r0 = 0; r0 < OW; r0 += 15) {
-      float px[15];
+    // ALL of the column's 60 loads are issued before the first is used (round 3): in four batches of 15 every window
+    // cost four dependent round trips to memory, and at 8-10 waves per CU (LDS) nothing hides them
+    float px[OW];
 #pragma unroll
-      for (int r = 0; r < 15; ++r) px[r] = im[(size_t)clampi(oy + r0 + r, 0, h - 1) * w + gx];
+    for (int r = 0; r < OW; ++r) px[r] = im[(size_t)clampi(oy + r, 0, h - 1) * w + gx];
 #pragma unroll
-      for (int r = 0; r < 15; ++r) {
-        if (INT) {
-          const int v = (int)px[r];
-          integral = integral && ((float)v == px[r]) && (v >= 0) && (v <= 255);
-        }
-        acc += (SAT)px[r];
-        sat[(r0 + r + 1) * OSP + (lane + 1)] = acc;
+    for (int r = 0; r < OW; ++r) {
+      if (INT) {
+        const int v = (int)px[r];
+        integral = integral && ((float)v == px[r]) && (v >= 0) && (v <= 255);
       }
+      acc += (SAT)px[r];
+      sat[(r + 1) * OSP + (lane + 1)] = acc;
     }
   }
   if (INT) {
@@ -98,12 +105,12 @@ __global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restric
     SAT *row = sat + (lane + 1) * OSP + 1;
     SAT acc = (SAT)0;
 #pragma unroll 4
-    for (int c0 = 0; c0 < OW; c0 += 15) {
-      SAT v[15];
+    for (int c0 = 0; c0 < OW; c0 += RB) {
+      SAT v[RB];
 #pragma unroll
-      for (int c = 0; c < 15; ++c) v[c] = row[c0 + c];
+      for (int c = 0; c < RB; ++c) v[c] = row[c0 + c];
 #pragma unroll
-      for (int c = 0; c < 15; ++c) { acc += v[c]; row[c0 + c] = acc; }
+      for (int c = 0; c < RB; ++c) { acc += v[c]; row[c0 + c] = acc; }
     }
   }
   __syncthreads();
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restric
         }
       }
       sumsq += v * v;
-      if (desc) vals[p] = v;
+      if (DESC && desc) vals[p] = v;
       continue;
     }
     const double s1 = box_sum(nearest_centre_o(p1y, scale_y, h), nearest_centre_o(p1x, scale_x, w));
@@ -174,17 +181,17 @@ __global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restric
         brow[2 * g] = (uint32_t)word;
         brow[2 * g + 1] = (uint32_t)(word >> 32);
       }
-      if (desc) vals[p] = bitv ? 1.0f : 0.0f;
+      if (DESC && desc) vals[p] = bitv ? 1.0f : 0.0f;
     } else {
       const float c = (float)((s1 - s2) / area - t);                    // bad.py:559
       float v = c;
       if (mode == MI_BAD_SOFT) v = 1.0f / (1.0f + expf(c * temperature));   // bad.py:565
       v = valid ? v : 0.0f;
       sumsq += v * v;
-      vals[p] = v;
+      if (DESC) vals[p] = v;
     }
   }
-  if (!desc) return;
+  if (!DESC || !desc) return;
   float inv = 1.0f;
   if (normalize) {                                                      // bad.py:573
     const float ss = (mode == MI_BAD_HARD) ? (float)pop : wave_sum(sumsq);
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restric
 extern "C" int mi_sparse_bad_oriented(const float *image, int n, int h, int w, const float *keypoints, int k,
                                       const float *orientation_map, const float *keypoint_angles,
                                       const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
-                                      float temperature, int normalize, int bilinear, float *desc,
+                                      float temperature, int normalize, int bilinear, float max_reach, float *desc,
                                       uint32_t *bits, uint8_t *status, mi_stream_t stream) {
   MI_ENTER();
   if (!image || !keypoints || !pair_geom || !pair_thr) return MI_E_NULL;
@@ -213,13 +220,13 @@ extern "C" int mi_sparse_bad_oriented(const float *image, int n, int h, int w, c
   if (bits && mode != MI_BAD_HARD) return MI_E_PARAM;
   const float scale_y = (float)(2.0 / ((double)(h - 1) + 1e-8));
   const float scale_x = (float)(2.0 / ((double)(w - 1) + 1e-8));
-  if (status) {                                                         // integer tables first, the rest in fp64
-    hipLaunchKernelGGL(bad_oriented_kernel<int>, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, image, h, w,
-                       keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, num_pairs, mode,
-                       temperature, normalize, scale_y, scale_x, bilinear ? 1 : 0, desc, bits, status);
-  }
-  hipLaunchKernelGGL(bad_oriented_kernel<double>, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, image, h,
-                     w, keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, num_pairs, mode,
-                     temperature, normalize, scale_y, scale_x, bilinear ? 1 : 0, desc, bits, status);
+  if (!(max_reach >= 0.0f)) return MI_E_PARAM;
+  const bool small = !bilinear && max_reach > 0.0f && max_reach <= 22.5f;   // see the window note at the top
+#define BO_LAUNCH(SAT, DESC, OWIN) hipLaunchKernelGGL((bad_oriented_kernel<SAT, DESC, OWIN>), dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, image, h, w, keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, num_pairs, mode, temperature, normalize, scale_y, scale_x, bilinear ? 1 : 0, desc, bits, status)
+#define BO_PICK(SAT) do { if (desc) { if (small) BO_LAUNCH(SAT, true, 48); else BO_LAUNCH(SAT, true, 60); } else { if (small) BO_LAUNCH(SAT, false, 48); else BO_LAUNCH(SAT, false, 60); } } while (0)
+  if (status) BO_PICK(int);                                             // integer tables first, the rest in fp64
+  BO_PICK(double);
+#undef BO_PICK
+#undef BO_LAUNCH
   return mi_launch_status();
 }

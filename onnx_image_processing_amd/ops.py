@@ -221,9 +221,11 @@ def angle_at_keypoints(image: torch.Tensor, keypoints: torch.Tensor, moment_kern
 
 def sparse_bad_oriented(image: torch.Tensor, keypoints: torch.Tensor, orientation: torch.Tensor,
                         pair_geom: torch.Tensor, pair_thr: torch.Tensor, mode: int, temperature: float,
-                        normalize: bool, want_desc: bool = True, want_bits: bool = False, bilinear: bool = False):
+                        normalize: bool, want_desc: bool = True, want_bits: bool = False, bilinear: bool = False,
+                        max_reach: float = 0.0):
     """orientation: dense map (B,1,H,W) -- the reference's argument -- or per-keypoint angles (B,K).
-    bilinear: sampling_mode="bilinear" of the box-mean maps instead of "nearest"."""
+    bilinear: sampling_mode="bilinear" of the box-mean maps instead of "nearest".
+    max_reach: upper bound of |pair offset| + box radius over the table in pixels (0 = unknown: the 60-pixel window)."""
     img = _images(image, "image")
     n, _, h, w = img.shape
     if keypoints.dim() != 3 or keypoints.shape[0] != n or keypoints.shape[2] != 2:
@@ -243,8 +245,9 @@ def sparse_bad_oriented(image: torch.Tensor, keypoints: torch.Tensor, orientatio
     status = torch.empty((n, k), dtype=torch.uint8, device=img.device)      # int32-table fast path bookkeeping
     N.call("mi_sparse_bad_oriented", N.dev(img, F32, "image"), n, h, w, N.dev(kp, F32, "keypoints"), k, amap, akp,
            N.dev(pair_geom, torch.int32, "pair_geom"), N.dev(pair_thr, F32, "pair_thr"), p, int(mode),
-           float(temperature), int(bool(normalize)), int(bool(bilinear)), desc.data_ptr() if want_desc else None,
-           bits.data_ptr() if want_bits else None, status.data_ptr(), N.stream_ptr())
+           float(temperature), int(bool(normalize)), int(bool(bilinear)), float(max_reach),
+           desc.data_ptr() if want_desc else None, bits.data_ptr() if want_bits else None, status.data_ptr(),
+           N.stream_ptr())
     return desc, bits
 
 

@@ -58,6 +58,11 @@ class SparseBAD(nn.Module):
         geom = b[:, 0] | (b[:, 1] << 5) | (b[:, 2] << 10) | (b[:, 3] << 15) | (b[:, 4] << 20)
         self.register_buffer("pair_geom", geom.to(torch.int32), persistent=False)
         self.register_buffer("pair_thr", thr.clone(), persistent=False)
+        # largest |offset from the patch centre| + box radius of the table, in pixels (rounded up a hair): the bound
+        # mi_sparse_bad_oriented uses to size its per-keypoint window (22.22 for both learned tables)
+        off = box[:, :4] - 16.0
+        reach = torch.maximum(torch.hypot(off[:, 0], off[:, 2]), torch.hypot(off[:, 1], off[:, 3])) + box[:, 4]
+        self.max_reach = float(reach.max().item()) + 1e-3
         self._plan = None          # device-side fast-path plan, built lazily per device
         self.use_fast_path = True  # tests switch this off to exercise the general kernel path
 
@@ -91,7 +96,8 @@ class SparseBAD(nn.Module):
             orientation = torch.zeros(keypoints.shape[:2], dtype=torch.float32, device=image.device)
         if orientation is not None:                      # oriented branch, bad.py:487-517
             desc, _ = ops.sparse_bad_oriented(image, keypoints, orientation, self.pair_geom, self.pair_thr, self.mode,
-                                              self.temperature, self.normalize_descriptors, bilinear=bilinear)
+                                              self.temperature, self.normalize_descriptors, bilinear=bilinear,
+                                              max_reach=self.max_reach)
             return desc
         desc, _ = ops.sparse_bad(image, keypoints, self.pair_geom, self.pair_thr, self.mode, self.temperature,
                                  self.normalize_descriptors, want_desc=True, want_bits=False, plan=self._get_plan())
@@ -111,7 +117,8 @@ class SparseBAD(nn.Module):
         if orientation is not None:
             _, bits = ops.sparse_bad_oriented(image, keypoints, orientation, self.pair_geom, self.pair_thr,
                                               N.MI_BAD_HARD, self.temperature, self.normalize_descriptors,
-                                              want_desc=False, want_bits=True, bilinear=bilinear)
+                                              want_desc=False, want_bits=True, bilinear=bilinear,
+                                              max_reach=self.max_reach)
             return bits
         _, bits = ops.sparse_bad(image, keypoints, self.pair_geom, self.pair_thr, N.MI_BAD_HARD, self.temperature,
                                  self.normalize_descriptors, want_desc=False, want_bits=True, plan=self._get_plan())

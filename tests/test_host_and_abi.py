@@ -268,9 +268,10 @@ def test_argument_validation_of_the_widened_entries(lib_path):
     assert lib.mi_dog_responses(p, 1, 8, 8, p, 1, 9, p, None, None) == -3                            # fewer than 2 scales
     assert lib.mi_dog_responses(p, 1, 8, 8, p, 3, 8, p, None, None) == -3                            # even kernel
     assert lib.mi_dog_responses(p, 1, 8, 8, p, 3, 9, None, None, None) == -1                         # no output at all
-    lib.mi_sparse_bad_oriented.argtypes = [vp, ci, ci, ci, vp, ci, vp, vp, vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, vp]
-    assert lib.mi_sparse_bad_oriented(p, 1, 64, 64, p, 4, p, p, p, p, 256, 2, 10.0, 1, 0, p, None, None, None) == -1   # two angle sources
-    assert lib.mi_sparse_bad_oriented(p, 1, 64, 64, p, 4, p, None, p, p, 100, 2, 10.0, 1, 0, p, None, None, None) == -3  # pairs % 64
+    lib.mi_sparse_bad_oriented.argtypes = [vp, ci, ci, ci, vp, ci, vp, vp, vp, vp, ci, ci, cf, ci, ci, cf, vp, vp, vp, vp]
+    assert lib.mi_sparse_bad_oriented(p, 1, 64, 64, p, 4, p, p, p, p, 256, 2, 10.0, 1, 0, 0.0, p, None, None, None) == -1   # two angle sources
+    assert lib.mi_sparse_bad_oriented(p, 1, 64, 64, p, 4, p, None, p, p, 100, 2, 10.0, 1, 0, 0.0, p, None, None, None) == -3  # pairs % 64
+    assert lib.mi_sparse_bad_oriented(p, 1, 64, 64, p, 4, p, None, p, p, 256, 2, 10.0, 1, 0, -1.0, p, None, None, None) == -3  # negative reach
 
 
 def test_match_pairs_host_side_checks(lib_path):
