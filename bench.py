@@ -562,6 +562,24 @@ def side_workload(args, rank, world, dev) -> None:
             nbytes = roof[2] * B * h * w * roof[3]
             t_ms = float(np.mean(timed))
             traffic, tsrc = pmc_traffic(roof[4], B, args.workload)
+            if args.workload == "vo" and world == 1 and not args.no_extras:
+                # the model's own use: ONE frame pair per call (sample/visual_odometry.py:520-545), host synchronised after each
+                from onnx_image_processing_amd.graph import GraphedModule
+                one = (img1[:1].contiguous(), img2[:1].contiguous())
+
+                def timed(fn, iters=100):
+                    for _ in range(10):
+                        fn()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(iters):
+                        fn()
+                        torch.cuda.synchronize()
+                    return (time.perf_counter() - t0) / iters * 1e3
+                eager = timed(lambda: model(*one))
+                graphed = GraphedModule(model, *one)
+                line["latency_one_pair"] = {"eager_ms": eager, "graph_ms": timed(graphed.graph.replay),
+                                            "what": "one 640x480 pair per call through the VO model, host synchronised after every call"}
             line["roofline"] = {"kernel": roof[1], "bound": "hbm", "achieved": nbytes / (t_ms * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "traffic": traffic, "traffic_source": tsrc, "bytes_per_launch": nbytes,

@@ -34,9 +34,9 @@ echo latency done
 # HBM-traffic passes each (so that their roofline objects carry a `traffic` figure)
 for wl in c3 c3dense c4 vo; do
   timeout -k 10 300 python3 "$B" --workload $wl --pairs-per-gpu 128 > "$OUT/$wl.json" 2> "$OUT/$wl.err"
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/${wl}stats" -o $wl -- python3 "$B" --workload $wl --pairs-per-gpu 128 --steps 5 --warmup 2 > "$OUT/${wl}stats.log" 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/${wl}stats" -o $wl -- python3 "$B" --workload $wl --pairs-per-gpu 128 --steps 5 --warmup 2 --no-extras > "$OUT/${wl}stats.log" 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_${wl}_$c" -o pmc -- python3 "$B" --workload $wl --pairs-per-gpu 128 --steps 2 --warmup 1 > "$OUT/pmc_${wl}_$c.log" 2>&1
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_${wl}_$c" -o pmc -- python3 "$B" --workload $wl --pairs-per-gpu 128 --steps 2 --warmup 1 --no-extras > "$OUT/pmc_${wl}_$c.log" 2>&1
   done
   echo $wl done
 done
