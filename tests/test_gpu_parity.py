@@ -1771,3 +1771,47 @@ print(json.dumps(facts))
     import json as _json
     facts = _json.loads(r.stdout.strip().splitlines()[-1])
     assert facts["ranks_seen"] == 1 and facts["backend"] == "nccl" and len(facts["ms_per_step_per_rank"]) == 1
+
+
+def test_c_host_without_python_or_torch_gets_the_same_matches(mods, tmp_path):
+    """tests/native/host_match_pairs.c -- plain C, hipMalloc'd buffers, the library through dlopen, a workspace full of
+    garbage -- run as a child process on the frames and pair table the Python modules get: keypoints, matches, scores and
+    validity equal MatchExtractionWrapper's bit for bit (2 pairs: the merged launches and the single-launch Sinkhorn; 40
+    pairs: one image side per launch, ticket-scheduled K1, the forked Sinkhorn halves are not reached below 64)."""
+    import subprocess
+    import sys as _sys
+    sys_path_tests = os.path.join(ROOT, "tests")
+    if sys_path_tests not in _sys.path:
+        _sys.path.insert(0, sys_path_tests)
+    from test_host_and_abi import _build_c_host
+    from onnx_image_processing_amd import _native as N
+    from onnx_image_processing_amd.synth import synth_batch_u8
+    exe = _build_c_host(tmp_path)
+    cfg = dict(block_size=3, num_pairs=512, binarize=True, soft_binarize=False, sinkhorn_iterations=20, epsilon=0.05,
+               nms_radius=5)
+    K, Mx = 512, 100
+    model = mods["MatchExtractionWrapper"](mods["ShiTomasiSparseBADSinkhornMatcher"](max_keypoints=K, **cfg),
+                                           max_matches=Mx, match_threshold=0.1).to(DEV)
+    geom = model.feature_matcher.descriptor.pair_geom.cpu().numpy().astype(np.uint32)
+    thr = model.feature_matcher.descriptor.pair_thr.cpu().numpy().astype(np.float32)
+    for batch in (2, 40):
+        a8, b8 = synth_batch_u8(5100, batch, 480, 640)
+        fin, fout = str(tmp_path / f"in{batch}.bin"), str(tmp_path / f"out{batch}.bin")
+        with open(fin, "wb") as f:
+            f.write(np.array([batch, 480, 640, K, 512, Mx], np.int32).tobytes())
+            f.write(a8.tobytes()); f.write(b8.tobytes()); f.write(geom.tobytes()); f.write(thr.tobytes())
+        r = subprocess.run([exe, N.LIB_PATH, fin, fout], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        raw = open(fout, "rb").read()
+        nk, nm, ns = batch * K * 2, batch * Mx * 2, batch * Mx
+        fl = np.frombuffer(raw, np.float32, 2 * nk + 2 * nm + ns)
+        valid = np.frombuffer(raw, np.uint8, ns, offset=4 * (2 * nk + 2 * nm + ns))
+        rcs = np.frombuffer(raw, np.int32, 2, offset=4 * (2 * nk + 2 * nm + ns) + ns)
+        assert rcs.tolist() == [0, 0]
+        want = [t.cpu().numpy() for t in model.forward_single_call(gpu(a8), gpu(b8), want_keypoints=True)]
+        got = (fl[:nk].reshape(batch, K, 2), fl[nk:2 * nk].reshape(batch, K, 2), fl[2 * nk:2 * nk + nm].reshape(batch, Mx, 2),
+               fl[2 * nk + nm:2 * nk + 2 * nm].reshape(batch, Mx, 2), fl[2 * nk + 2 * nm:].reshape(batch, Mx),
+               valid.reshape(batch, Mx).astype(bool))
+        for x, y in zip(got, want):
+            assert np.array_equal(x, y), batch
+        assert int(valid.sum()) == batch * Mx

@@ -414,3 +414,29 @@ def _gather_schedule_checks(lib, SparseBAD):
     a, b = ctypes.c_int(0), ctypes.c_int(0)
     assert lib.mi_debug_bad_plan_passes(None, 512, ctypes.byref(a), ctypes.byref(b)) == -1
     assert lib.mi_debug_bad_plan_passes(geom.ctypes.data, 100, ctypes.byref(a), ctypes.byref(b)) == -3
+
+
+def _build_c_host(tmp_path):
+    """tests/native/host_match_pairs.c with plain gcc (C99): the header is valid C, the host needs the HIP runtime only."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/lib/libamdhip64.so"):
+        pytest.skip("gcc / libamdhip64 not available")
+    exe = str(tmp_path / "host_match_pairs")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", f"-I{os.path.join(ROOT, 'include')}",
+           os.path.join(ROOT, "tests", "native", "host_match_pairs.c"), "-o", exe, "-L/opt/rocm/lib", "-lamdhip64", "-ldl",
+           "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_c_host_compiles_against_the_header_only(tmp_path, lib_path):
+    """A host without Python or torch: plain C99 + the HIP runtime, the library opened with dlopen.  Here (no GPU) it must
+    compile warning-free and depend on nothing of this repository or of torch at link time; the GPU suite runs it."""
+    import subprocess
+    exe = _build_c_host(tmp_path)
+    deps = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libamdhip64" in deps and "mi355x" not in deps and "torch" not in deps and "python" not in deps
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage" in r.stderr
