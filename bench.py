@@ -831,12 +831,16 @@ def main() -> None:
             if "mi_nms_candidates" in stages:
                 t = float(np.mean(stages["mi_nms_candidates"]))
                 other["mi_nms_candidates"] = {"bytes_per_call": 4.0 * B * H * W, "unit": "GB/s",
-                                              "achieved": 4.0 * B * H * W / (t * 1e-3) / 1e9}
+                                              "achieved": 4.0 * B * H * W / (t * 1e-3) / 1e9, "bound": "hbm",
+                                              "peak": HBM_PEAK_GBS, "frac": 4.0 * B * H * W / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
             if "mi_sinkhorn_dots" in stages:
                 t = float(np.mean(stages["mi_sinkhorn_dots"]))
                 nb = 2.0 * B * K * K * CFG["sinkhorn_iterations"]
                 other["mi_sinkhorn_dots (20 iterations, 2 B/element/iteration)"] = {
-                    "bytes_per_call": nb, "unit": "GB/s", "achieved": nb / (t * 1e-3) / 1e9}
+                    "bytes_per_call": nb, "unit": "GB/s", "achieved": nb / (t * 1e-3) / 1e9, "bound": "hbm",
+                    "peak": HBM_PEAK_GBS, "frac": nb / (t * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "note": "memory-bound: a 22 % cut of the row kernel's VALU instructions left the call time unchanged "
+                            "(same-box A/B, DESIGN.md K6); counter traffic 136 MB per 224-pair launch"}
             if "mi_cost_dots_bits" in stages:
                 t = float(np.mean(stages["mi_cost_dots_bits"]))
                 ops_ = 2.0 * B * K * K * NUM_PAIRS

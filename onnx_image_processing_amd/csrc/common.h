@@ -115,6 +115,23 @@ __device__ __forceinline__ void wave_max4(float *v) {     // v[0..3], registers
   v[1] = mi_readlane_f(m, 32);
   v[3] = mi_readlane_f(m, 48);
 }
+// The same reduction left in the lanes: every lane of 16-lane row g holds the total of vector MI_ROW_OF_GROUP(g)
+// (no broadcast).  For per-row work that is itself done once per row: one lane-parallel instruction instead of four
+// wave-uniform ones.
+#define MI_ROW_OF_GROUP(g) ((g) == 1 ? 2 : (g) == 2 ? 1 : (g))     // rows [0, 2, 1, 3]; its own inverse
+__device__ __forceinline__ float wave_sum4_rows(const float *v) {
+  float a0, a1, b0, b1, c0, c1;
+  MI_SWAP32(v[0], v[1], a0, a1);
+  MI_SWAP32(v[2], v[3], b0, b1);
+  const float m01 = a0 + a1, m23 = b0 + b1;
+  MI_SWAP16(m01, m23, c0, c1);
+  float m = c0 + c1;
+  m += MI_DPP(0.0f, m, 0xB1, 0xf);
+  m += MI_DPP(0.0f, m, 0x4E, 0xf);
+  m += MI_DPP(0.0f, m, 0x141, 0xf);
+  m += MI_DPP(0.0f, m, 0x140, 0xf);
+  return m;
+}
 __device__ __forceinline__ void wave_sum4(float *v) {
   float a0, a1, b0, b1, c0, c1;
   MI_SWAP32(v[0], v[1], a0, a1);

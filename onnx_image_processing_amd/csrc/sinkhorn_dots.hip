@@ -61,6 +61,22 @@ __device__ __forceinline__ void publish_wave_max(float x, float *__restrict__ au
   if ((threadIdx.x & 63) == 0) aux_pair[blockIdx.x * 4 + (threadIdx.x >> 6)] = x;
 }
 
+// Maximum of the low 32 lanes, wave-uniform.  v_max_f32 with the DPP operand inside the instruction: five instructions;
+// the compiler's form of the same butterfly (fmaxf on update_dpp) is four per step -- a register copy, the DPP move and
+// a canonicalising v_max of each operand in front of the maximum proper.  (The s_nop cover the two wait states a DPP
+// read of a freshly written VGPR needs: the assembler pads nothing inside an asm statement.)
+__device__ __forceinline__ float max32_lane31(float v) {
+  asm volatile(
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 0"
+      : "+v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+}
+
 // v_j <- v_j + log nu_j - log(sum of the bands' P_ij + exp(B_j))   (B_j: dustbin row, log domain)
 __device__ __forceinline__ float combine_column(const float *__restrict__ part_b, int nparts, int m, int j,
                                                 float vold, float log_n) {
@@ -198,11 +214,12 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
   // wq*log2(e) - S*log2(e) once per wave and x lands in the exponent's units.
   float nm_pair = 0.0f;          // -S * log2(e)
   if constexpr (FAST) {
-    const float *ab = aux + (size_t)b * SKD_AUX;
-    float wmax = ab[0];                          // one slot per 64 columns: (m + 63) / 64 of them matter
-#pragma unroll
-    for (int k = 1; k < SKD_AUX; ++k)
-      if (k * 64 < m) wmax = fmaxf(wmax, ab[k]);   // wave-uniform (scalar branch)
+    // one slot per 64 columns; the slots past the matrix hold -inf (sk_dots_init_kernel, the column kernel's idle
+    // waves), so all of them are read: one load per lane and a wave maximum instead of a chain of dependent scalar
+    // loads at the head of every workgroup
+    static_assert(SKD_AUX <= 64, "one aux slot per lane");
+    static_assert(SKD_AUX <= 32, "max32_to_lane31 folds the low 32 lanes");
+    const float wmax = max32_lane31(lane < SKD_AUX ? aux[(size_t)b * SKD_AUX + lane] : -INFINITY);
     const float S = fmaxf(wmax + zp.g_bound, xd0 + zp.d_bound);
     nm_pair = -(S * SKD_L2E);
 #pragma unroll
@@ -222,15 +239,36 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
   float x[RW][E8][8];            // (z_ij - c_i) + v_j (in the exponent's units, shifted, on the fast path), then e_ij in place
   float mx[RW], xd[RW], ci[RW];
   bool live[RW];
+  // ROWS (RW == 4): what is computed once per row -- its constants, its dustbin-column entry, log and reciprocal of its
+  // sum, its u -- is done in the lanes, the 16 lanes of group g working for row MI_ROW_OF_GROUP(g) (the layout
+  // wave_sum4_rows leaves the sums in): 1 instruction instead of 4 wave-uniform ones, 3 transcendentals instead of 12,
+  // and the few values the element loops need as scalars are read out with v_readlane.  Same operations on the same
+  // values: nothing changes in the results.
+  constexpr bool ROWS = RW == 4;
+  const int myrow = MI_ROW_OF_GROUP(lane >> 4);
+  float civ = 0.0f, giv = 0.0f, xdv = 0.0f;
+  if constexpr (ROWS) {
+    const float2 riv = row_info[(size_t)b * n + min(row0 + myrow, n - 1)];
+    const float g0 = -2.0f * zp.neg_inv_eps * riv.x;
+    giv = FAST ? g0 * SKD_L2E : g0;
+    civ = riv.y * zp.neg_inv_eps;
+    xdv = xd0 - civ;
+  }
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
     const int i = row0 + r;
     live[r] = i < n;
-    const float2 ri = row_info[(size_t)b * n + min(i, n - 1)];                     // wave-uniform
-    const float g0 = -2.0f * zp.neg_inv_eps * ri.x;
-    const float gi = FAST ? g0 * SKD_L2E : g0;
-    ci[r] = ri.y * zp.neg_inv_eps;
-    xd[r] = xd0 - ci[r];
+    float gi;
+    if constexpr (ROWS) {
+      gi = mi_readlane_f(giv, 16 * MI_ROW_OF_GROUP(r));
+      if constexpr (!FAST) { ci[r] = mi_readlane_f(civ, 16 * MI_ROW_OF_GROUP(r)); xd[r] = xd0 - ci[r]; }
+    } else {
+      const float2 ri = row_info[(size_t)b * n + min(i, n - 1)];                     // wave-uniform
+      const float g0 = -2.0f * zp.neg_inv_eps * ri.x;
+      gi = FAST ? g0 * SKD_L2E : g0;
+      ci[r] = ri.y * zp.neg_inv_eps;
+      xd[r] = xd0 - ci[r];
+    }
 #pragma unroll
     for (int e = 0; e < E8; ++e) {
       const uint32_t w4[4] = {raw[r][e].x, raw[r][e].y, raw[r][e].z, raw[r][e].w};
@@ -262,9 +300,10 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
       for (int e = 0; e < E8; ++e) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) x[r][e][q] = __builtin_amdgcn_exp2f(x[r][e][q]);           // 0 outside the matrix
-        s[r] += ((x[r][e][0] + x[r][e][1]) + (x[r][e][2] + x[r][e][3])) + ((x[r][e][4] + x[r][e][5]) + (x[r][e][6] + x[r][e][7]));
+        const float tree = ((x[r][e][0] + x[r][e][1]) + (x[r][e][2] + x[r][e][3])) + ((x[r][e][4] + x[r][e][5]) + (x[r][e][6] + x[r][e][7]));
+        s[r] = e == 0 ? tree : s[r] + tree;      // (0 + tree == tree: a sum of exponentials is never -0)
       }
-      ed[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(xd[r], SKD_L2E, nm[r]));                   // dustbin column entry
+      if constexpr (!ROWS) ed[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(xd[r], SKD_L2E, nm[r]));   // dustbin column entry
     }
   } else {
     if constexpr (RW % 4 == 0) {
@@ -283,24 +322,39 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
 #pragma unroll
         for (int q = 0; q < 8; ++q)
           x[r][e][q] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[r][e][q], SKD_L2E, nm[r]));   // 0 outside the matrix
-        s[r] += ((x[r][e][0] + x[r][e][1]) + (x[r][e][2] + x[r][e][3])) + ((x[r][e][4] + x[r][e][5]) + (x[r][e][6] + x[r][e][7]));
+        const float tree = ((x[r][e][0] + x[r][e][1]) + (x[r][e][2] + x[r][e][3])) + ((x[r][e][4] + x[r][e][5]) + (x[r][e][6] + x[r][e][7]));
+        s[r] = e == 0 ? tree : s[r] + tree;      // (0 + tree == tree: a sum of exponentials is never -0)
       }
-      ed[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(xd[r], SKD_L2E, nm[r]));                   // dustbin column entry
+      if constexpr (!ROWS) ed[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(xd[r], SKD_L2E, nm[r]));   // dustbin column entry
     }
   }
-  if constexpr (RW % 4 == 0) {
-#pragma unroll
-    for (int r = 0; r < RW; r += 4) wave_sum4(s + r);
+  float wgtv = 0.0f, edv = 0.0f;
+  if constexpr (ROWS) {
+    // per row, in the lanes (see ROWS above): dustbin-column entry, the row's total, u_i, 1 / total
+    float nmv = nm[0];
+    if constexpr (!FAST) nmv = myrow == 1 ? nm[1] : myrow == 2 ? nm[2] : myrow == 3 ? nm[3] : nm[0];
+    edv = __builtin_amdgcn_exp2f(__builtin_fmaf(xdv, SKD_L2E, nmv));
+    const float stv = wave_sum4_rows(s) + edv;
+    const bool livev = row0 + myrow < n;
+    if ((lane & 15) == 0 && livev)                                                  // sinkhorn.py:139
+      u[(size_t)b * (n + 1) + row0 + myrow] = (nmv - __builtin_amdgcn_logf(stv)) * SKD_LN2 - civ;
+    wgtv = livev ? __builtin_amdgcn_rcpf(stv) : 0.0f;
   } else {
 #pragma unroll
     for (int r = 0; r < RW; ++r) s[r] = wave_sum_dpp(s[r]);
   }
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
-    const float st = s[r] + ed[r];
-    if (lane == 0 && live[r])                                                       // sinkhorn.py:139
-      u[(size_t)b * (n + 1) + row0 + r] = (nm[r] - __builtin_amdgcn_logf(st)) * SKD_LN2 - ci[r];
-    const float wgt = live[r] ? __builtin_amdgcn_rcpf(st) : 0.0f;
+    float wgt;
+    if constexpr (ROWS) {
+      wgt = mi_readlane_f(wgtv, 16 * MI_ROW_OF_GROUP(r));
+      ed[r] = mi_readlane_f(edv, 16 * MI_ROW_OF_GROUP(r));
+    } else {
+      const float st = s[r] + ed[r];
+      if (lane == 0 && live[r])                                                     // sinkhorn.py:139
+        u[(size_t)b * (n + 1) + row0 + r] = (nm[r] - __builtin_amdgcn_logf(st)) * SKD_LN2 - ci[r];
+      wgt = live[r] ? __builtin_amdgcn_rcpf(st) : 0.0f;
+    }
 #pragma unroll
     for (int e = 0; e < E8; ++e)
 #pragma unroll
