@@ -16,7 +16,7 @@ K = 512
 rng = np.random.default_rng(5)
 m = SinkhornMatcher(iterations=20, epsilon=0.05)
 lib = N.use_debug_library()          # the mi_debug_* hooks live in lib/libmi355x_match_debug.so
-for parts in (1, 2):
+for parts in (1, 2, 3, 4):
     lib.mi_debug_set(6, parts)
     for B in (16, 32, 64, 128, 224, 448, 896):
         bits1 = torch.from_numpy(rng.integers(0, 2 ** 31, (B, K, 16), dtype=np.int64).astype(np.int32)).cuda()
