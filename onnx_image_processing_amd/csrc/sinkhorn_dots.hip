@@ -272,16 +272,24 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
 #pragma unroll
     for (int e = 0; e < E8; ++e) {
       const uint32_t w4[4] = {raw[r][e].x, raw[r][e].y, raw[r][e].z, raw[r][e].w};
+      if constexpr (E8 == 1) {
 #pragma unroll
-      for (int q = 0; q < 8; q += 2) {
-        // two columns per instruction: v_pk_mul_f32 / v_pk_fma_f32 (the same IEEE operations; a packed fma costs 1.9 ns
-        // against 2 x 1.5)
-        typedef float v2f __attribute__((ext_vector_type(2)));
-        const v2f dot = {(float)(w4[q >> 1] & 0xFFFFu), (float)(w4[q >> 1] >> 16)};
-        const v2f tt = {tq[e][q], tq[e][q + 1]}, ww = {wq[e][q], wq[e][q + 1]}, gg = {gi, gi};
-        const v2f xx = __builtin_elementwise_fma(dot * tt, gg, ww);
-        x[r][e][q] = xx.x;
-        x[r][e][q + 1] = xx.y;
+        for (int q = 0; q < 8; q += 2) {
+          // two columns per instruction: v_pk_mul_f32 / v_pk_fma_f32 (the same IEEE operations; a packed fma costs 1.9 ns
+          // against 2 x 1.5)
+          typedef float v2f __attribute__((ext_vector_type(2)));
+          const v2f dot = {(float)(w4[q >> 1] & 0xFFFFu), (float)(w4[q >> 1] >> 16)};
+          const v2f tt = {tq[e][q], tq[e][q + 1]}, ww = {wq[e][q], wq[e][q + 1]}, gg = {gi, gi};
+          const v2f xx = __builtin_elementwise_fma(dot * tt, gg, ww);
+          x[r][e][q] = xx.x;
+          x[r][e][q + 1] = xx.y;
+        }
+      } else {                 // the two-chunk instance: the pairs' register tuples cost it a wave of occupancy (65 VGPRs)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float dot = (float)((q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu));
+          x[r][e][q] = __builtin_fmaf(dot * tq[e][q], gi, wq[e][q]);
+        }
       }
       if constexpr (!FAST)
         mx[r] = fmaxf(e == 0 ? xd[r] : mx[r], fmaxf(fmaxf(fmaxf(x[r][e][0], x[r][e][1]), fmaxf(x[r][e][2], x[r][e][3])),
