@@ -513,19 +513,40 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
     const int j = lane * 8 + q;
     tq[q] = (j < m) ? col_info[(size_t)b * m + min(j, m - 1)].x : 0.0f;
   }
-  uint4 raw[RW];
+  // dt = dot_ij * t_j, the first factor of every iteration's x_ij = fma(dot * t_j, g_i, w_j): converted and multiplied
+  // ONCE (the same two roundings as in the multi-launch row kernel, which redoes them per iteration from the uint16 it
+  // has to re-read anyway; here they were two of the ~8 instructions per element and iteration)
+  float dt[RW][8];
   float gi[RW], ci[RW];
   bool live[RW];
+  {
+    uint4 raw[RW];
 #pragma unroll
-  for (int r = 0; r < RW; ++r) {
-    const int i = min(row0 + r, n - 1);
-    live[r] = row0 + r < n;
-    raw[r] = *reinterpret_cast<const uint4 *>(dots + ((size_t)b * n + i) * pitch + min(lane * 8, pitch - 8));
-    const float2 ri = row_info[(size_t)b * n + i];
-    const float g0 = -2.0f * zp.neg_inv_eps * ri.x;
-    gi[r] = FAST ? g0 * SKD_L2E : g0;
-    ci[r] = ri.y * zp.neg_inv_eps;
+    for (int r = 0; r < RW; ++r) {
+      const int i = min(row0 + r, n - 1);
+      live[r] = row0 + r < n;
+      raw[r] = *reinterpret_cast<const uint4 *>(dots + ((size_t)b * n + i) * pitch + min(lane * 8, pitch - 8));
+      const float2 ri = row_info[(size_t)b * n + i];
+      const float g0 = -2.0f * zp.neg_inv_eps * ri.x;
+      gi[r] = FAST ? g0 * SKD_L2E : g0;
+      ci[r] = ri.y * zp.neg_inv_eps;
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const uint32_t w4[4] = {raw[r].x, raw[r].y, raw[r].z, raw[r].w};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float dot = (float)((q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu));
+        dt[r][q] = dot * tq[q];
+      }
+    }
   }
+  // ROWS (RW == 4): the per-row scalars of an iteration computed in the lanes, as in sk_band_dots_kernel
+  constexpr bool ROWS = RW == 4;
+  const int myrow = MI_ROW_OF_GROUP(lane >> 4);
+  const bool livev = row0 + myrow < n;
+  float civ = 0.0f;
+  if constexpr (ROWS) civ = row_info[(size_t)b * n + min(row0 + myrow, n - 1)].y * zp.neg_inv_eps;
   // ---- the column half's state lives in registers: thread t owns column t (its v_j and nie * |b_j|^2); the dustbin
   // column m is owned by thread m, or by thread 0 as a second column when m == NT
   const bool own0 = t <= m;                                  // column t exists (t == m: the dustbin column)
@@ -605,12 +626,8 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
       xd[r] = xd0 - ci[r];
-      const uint32_t w4[4] = {raw[r].x, raw[r].y, raw[r].z, raw[r].w};
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float dot = (float)((q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu));
-        x[r][q] = __builtin_fmaf(dot * tq[q], gi[r], wq[q]);
-      }
+      for (int q = 0; q < 8; ++q) x[r][q] = __builtin_fmaf(dt[r][q], gi[r], wq[q]);
       if constexpr (!FAST)
         mx[r] = fmaxf(xd[r], fmaxf(fmaxf(fmaxf(x[r][0], x[r][1]), fmaxf(x[r][2], x[r][3])),
                                    fmaxf(fmaxf(x[r][4], x[r][5]), fmaxf(x[r][6], x[r][7]))));
@@ -624,9 +641,8 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
         nm[r] = nm_pair;
 #pragma unroll
         for (int q = 0; q < 8; ++q) x[r][q] = __builtin_amdgcn_exp2f(x[r][q]);
-        sr[r] = 0.0f;
-        sr[r] += ((x[r][0] + x[r][1]) + (x[r][2] + x[r][3])) + ((x[r][4] + x[r][5]) + (x[r][6] + x[r][7]));
-        ed[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(xd[r], SKD_L2E, nm[r]));
+        sr[r] = ((x[r][0] + x[r][1]) + (x[r][2] + x[r][3])) + ((x[r][4] + x[r][5]) + (x[r][6] + x[r][7]));   // (never -0)
+        if constexpr (!ROWS) ed[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(xd[r], SKD_L2E, nm[r]));
       }
     } else {
       wave_max4(mx);
@@ -635,22 +651,38 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
         nm[r] = -(mx[r] * SKD_L2E);
 #pragma unroll
         for (int q = 0; q < 8; ++q) x[r][q] = __builtin_amdgcn_exp2f(__builtin_fmaf(x[r][q], SKD_L2E, nm[r]));
-        sr[r] = 0.0f;
-        sr[r] += ((x[r][0] + x[r][1]) + (x[r][2] + x[r][3])) + ((x[r][4] + x[r][5]) + (x[r][6] + x[r][7]));
-        ed[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(xd[r], SKD_L2E, nm[r]));
+        sr[r] = ((x[r][0] + x[r][1]) + (x[r][2] + x[r][3])) + ((x[r][4] + x[r][5]) + (x[r][6] + x[r][7]));   // (never -0)
+        if constexpr (!ROWS) ed[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(xd[r], SKD_L2E, nm[r]));
       }
     }
-    wave_sum4(sr);
+    float wgtv = 0.0f, edv = 0.0f;
+    if constexpr (ROWS) {
+      float nmv = nm[0];
+      if constexpr (!FAST) nmv = myrow == 1 ? nm[1] : myrow == 2 ? nm[2] : myrow == 3 ? nm[3] : nm[0];
+      edv = __builtin_amdgcn_exp2f(__builtin_fmaf(xd0 - civ, SKD_L2E, nmv));
+      const float stv = wave_sum4_rows(sr) + edv;
+      if (it == iterations - 1 && (lane & 15) == 0 && livev)                             // sinkhorn.py:139
+        u[(size_t)b * (n + 1) + row0 + myrow] = (nmv - __builtin_amdgcn_logf(stv)) * SKD_LN2 - civ;
+      wgtv = livev ? __builtin_amdgcn_rcpf(stv) : 0.0f;
+    } else {
+      wave_sum4(sr);
+    }
     float colsum[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) colsum[q] = 0.0f;
     float dustcol = 0.0f;
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
-      const float st = sr[r] + ed[r];
-      if (it == iterations - 1 && lane == 0 && live[r])                                  // sinkhorn.py:139
-        u[(size_t)b * (n + 1) + row0 + r] = (nm[r] - __builtin_amdgcn_logf(st)) * SKD_LN2 - ci[r];
-      const float wgt = live[r] ? __builtin_amdgcn_rcpf(st) : 0.0f;
+      float wgt;
+      if constexpr (ROWS) {
+        wgt = mi_readlane_f(wgtv, 16 * MI_ROW_OF_GROUP(r));
+        ed[r] = mi_readlane_f(edv, 16 * MI_ROW_OF_GROUP(r));
+      } else {
+        const float st = sr[r] + ed[r];
+        if (it == iterations - 1 && lane == 0 && live[r])                                // sinkhorn.py:139
+          u[(size_t)b * (n + 1) + row0 + r] = (nm[r] - __builtin_amdgcn_logf(st)) * SKD_LN2 - ci[r];
+        wgt = live[r] ? __builtin_amdgcn_rcpf(st) : 0.0f;
+      }
 #pragma unroll
       for (int q = 0; q < 8; ++q) colsum[q] = __builtin_fmaf(x[r][q], wgt, colsum[q]);
       dustcol = __builtin_fmaf(ed[r], wgt, dustcol);
