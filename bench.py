@@ -361,10 +361,17 @@ def measure_latency(model, img1, img2, a8, b8, iters: int = 200) -> dict:
         row = {}
         for name, fn, x, y in (("module", model, f1, f2), ("single_call", one_call, f1, f2), ("single_call_u8", one_call, u1, u2)):
             eager = timed(lambda: fn(x, y))
+            want = [t.clone() for t in fn(x, y)]
             graphed = GraphedModule(fn, x, y)
             graph = timed(graphed.graph.replay)
+            # what the timed replays (host synchronised after each, other launches in between) left in the graph's output
+            # buffers is the eager result, bit for bit: a replay that returned all-invalid matches would time the same
+            same = all(torch.equal(g, w) for g, w in zip(graphed.static_outputs, want))
+            if not same:
+                raise RuntimeError(f"latency/{name}/{b}: the replayed graph's outputs differ from the eager call's")
             row[name] = {"eager_ms": eager, "graph_ms": graph, "eager_pairs_per_sec": b / (eager * 1e-3),
-                         "graph_pairs_per_sec": b / (graph * 1e-3)}
+                         "graph_pairs_per_sec": b / (graph * 1e-3), "graph_equals_eager": True,
+                         "valid_matches": int(want[3].sum().item())}
         if b == 1:
             # the reference harness's own situation (sample/image_matching.py:313-328): frames are HOST arrays and the
             # results are wanted on the host -- uint8 frames from pinned memory in, keypoint / match records out

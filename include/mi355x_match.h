@@ -92,7 +92,8 @@ MI_API int mi_corner_response_u8(const uint8_t *image, int n, int h, int w, int 
 MI_API int mi_convert_u8_f32(const uint8_t *src, long long count, float *dst, mi_stream_t stream);
 /* mi_corner_response / _u8 (pixels_are_u8 = 0 / 1) with dynamic tile scheduling for large batches: tile_counter =
  * MI_TILE_COUNTER_BYTES of device memory, 4-byte aligned, of ANY content: the call clears the block on `stream`
- * (a memset node) ahead of the kernel that draws tickets from it, so a block left dirty by a launch that died cannot
+ * (with a small kernel -- no entry point of this library issues hipMemsetAsync, whose captured form does not survive
+ * hipGraph replays on ROCm 7.2) ahead of the kernel that draws tickets from it, so a block left dirty by a launch that died cannot
  * make a later call skip tiles.  A block must not be shared by calls that may run concurrently (different streams
  * need different blocks).  NULL = the static schedule of the two entry points above.  Same scores; equally sized
  * static shares do not finish together because the SIMDs issue oldest-first, tickets make them. */

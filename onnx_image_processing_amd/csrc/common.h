@@ -23,6 +23,32 @@ static inline int mi_launch_status() {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Clearing device memory on a stream WITHOUT hipMemsetAsync.  A memset call captured into a hipGraph becomes a memset
+// node, and on this stack (ROCm 7.2, torch 2.10 graphs) such a node zeroes correctly on the first replay only: later
+// replays were observed filling the range with a 16-byte pattern taken from a recycled argument block (the arguments of
+// whatever kernel the host launched since; reproduced with a bare hipMemsetAsync in a captured stream once the host
+// synchronises the device between replays: tools/graph_memset_probe.py).  A one-pair-per-call host synchronises
+// after every replay, so the status word of mi_sinkhorn_dots came back non-zero ("solver timed out": every match
+// invalid) and K1's ticket counters would start mid-range.  A kernel node keeps its arguments.  16-byte stores when
+// the block allows, 4-byte stores otherwise.
+template <typename W>
+static __global__ __launch_bounds__(256) void mi_zero_kernel(W *__restrict__ p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = W{};
+}
+static inline int mi_zero_async(void *p, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return MI_OK;
+  if (((uintptr_t)p % 4) != 0 || bytes % 4 != 0) return MI_E_ALIGN;
+  if (((uintptr_t)p % 16) == 0 && bytes % 16 == 0) {
+    const size_t n = bytes / 16;
+    hipLaunchKernelGGL(mi_zero_kernel<uint4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint4 *>(p), n);
+  } else {
+    const size_t n = bytes / 4;
+    hipLaunchKernelGGL(mi_zero_kernel<uint32_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint32_t *>(p), n);
+  }
+  return mi_launch_status();
+}
+
 // Two equally shaped batches behind ONE launch (image1 / image2 of mi_match_pairs, and the keypoint arrays that belong
 // to them): item i of n = 2 * per_set lives in `a` for i < per_set and in `b` otherwise.  A single batch is
 // {ptr, nullptr, n}.  Which batch an item came from never changes what is computed for it.

@@ -700,9 +700,9 @@ int launch_stream(MiSets image, int n, int h, int w, float *score, unsigned *til
   // draw and its last workgroup's reset would otherwise start this launch's tickets mid-range (tiles skipped, score
   // rows never written, rc 0).  The kernel still leaves the block zero; nothing relies on that any more.
   unsigned *ctr = total > 2LL * grid ? tile_ctr : nullptr;
-  if (ctr && hipMemsetAsync(ctr, 0, MI_TILE_COUNTER_BYTES, s) != hipSuccess) {
-    const int e = mi_launch_status();
-    return e != MI_OK ? e : MI_E_PARAM;
+  if (ctr) {                                       // (a kernel, not hipMemsetAsync: common.h, mi_zero_async)
+    const int e = mi_zero_async(ctr, MI_TILE_COUNTER_BYTES, s);
+    if (e != MI_OK) return e;
   }
   hipLaunchKernelGGL((corner_stream_kernel<BS, R, std::is_same<PIX, uint8_t>::value>), dim3(grid), dim3(256), 0,
                      s, image, score, h, w, tiles_x, tiles_y, (int)total, ctr, MI_HOOK(corner_clk, (unsigned long long *)nullptr));

@@ -1007,12 +1007,13 @@ int mi_sinkhorn_dots_impl(const uint16_t *dots, const float *row_info, const flo
   const bool fast = sqnorm_bound > 0.0 && (double)zp.g_bound * 1.4426950408889634 < (double)SKD_FAST_LIMIT;
   unsigned *statusw = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(workspace) + dots_status_offset(batch, n, m));
   if (use_single_launch(batch, n, m, flags)) {
-    // single-launch form: zero the granule tags and the status word (one memset node), then one kernel
+    // single-launch form: zero the granule tags and the status word (one small kernel: common.h, mi_zero_async), then
+    // one kernel
     char *gbase = reinterpret_cast<char *>(workspace) + dots_base_bytes(batch, n, m);
     const size_t gbytes = persist_granule_bytes(batch, n);
     if (!prezeroed) {
-      hipError_t me = hipMemsetAsync(gbase, 0, gbytes + 16, s);
-      if (me != hipSuccess) return (int)me;
+      const int me = mi_zero_async(gbase, gbytes + 16, s);
+      if (me != MI_OK) return me;
     }
     unsigned long long *gran = reinterpret_cast<unsigned long long *>(gbase);
     unsigned *failw = statusw;                       // == gbase + gbytes

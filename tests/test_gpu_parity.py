@@ -1265,6 +1265,49 @@ def test_hipgraph_replay_equals_eager(mods):
         graphed(gpu(a[:, :, :50]), gpu(b))
 
 
+def test_hipgraph_replay_survives_device_synchronisation(mods):
+    """The one-pair-per-call host (the VO loop) synchronises after every replay and launches other work in between.
+    A hipMemsetAsync captured into the graph (the library's former way of clearing the Sinkhorn hand-off area and K1's
+    ticket counters) zeroed correctly on the first replay only on this stack -- later replays filled the range with a
+    recycled argument block, so the solver's status word came back non-zero and every match invalid (round 3; the
+    clears are kernels now, csrc/common.h mi_zero_async).  Module path and the one-call path, one pair and a batch
+    large enough for K1's ticket schedule."""
+    from onnx_image_processing_amd.graph import GraphedModule
+    g = load_golden("small_hamming_96x128_k48")
+    cfg = cfg_of(g)
+    a, b = _images(g)
+    model = mods["MatchExtractionWrapper"](mods["ShiTomasiSparseBADSinkhornMatcher"](max_keypoints=int(g["k"]), **cfg),
+                                           max_matches=40, match_threshold=0.1).to(DEV)
+    noise = torch.empty(1 << 16, dtype=torch.int32, device=DEV)
+    for single in (False, True):
+        fwd = model.forward_single_call if single else model
+        ga, gb = gpu(a), gpu(b)
+        eager = [t.clone() for t in fwd(ga, gb)]
+        assert int(eager[3].sum()) > 10
+        graphed = GraphedModule(fwd, ga, gb)
+        for it in range(4):
+            out = graphed(ga, gb)
+            torch.cuda.synchronize()                                 # the host waits for every call ...
+            for x, y in zip(out, eager):
+                assert torch.equal(x, y), (single, it)
+            noise.fill_(0x55555555 + it)                             # ... and launches something else before the next
+            torch.cuda.synchronize()
+    # a batch whose corner response takes the ticket schedule (more than two tiles per resident workgroup)
+    a2, b2 = synth_batch(9100, 40, 480, 640)
+    m2 = mods["MatchExtractionWrapper"](mods["ShiTomasiSparseBADSinkhornMatcher"](max_keypoints=128, **cfg),
+                                        max_matches=40, match_threshold=0.1).to(DEV)
+    g1, g2 = gpu(a2), gpu(b2)
+    eager = [t.clone() for t in m2(g1, g2)]
+    graphed = GraphedModule(m2, g1, g2)
+    for it in range(3):
+        out = graphed(g1, g2)
+        torch.cuda.synchronize()
+        for x, y in zip(out, eager):
+            assert torch.equal(x, y), it
+        noise.fill_(it)
+        torch.cuda.synchronize()
+
+
 def _wrapper_96(mods, k=48):
     cfg = dict(block_size=3, num_pairs=256, binarize=True, soft_binarize=False, sinkhorn_iterations=10, epsilon=0.1,
                nms_radius=2)
