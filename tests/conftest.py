@@ -25,8 +25,8 @@ def pytest_sessionstart(session):
     """MI_POISON_EMPTY=1: every torch.empty / empty_like / new_empty on the GPU comes back filled with a poison pattern
     (NaN for floating types, 0x5A bytes otherwise) instead of whatever the allocator recycled -- a result that depends
     on the previous content of an output or workspace buffer (a workspace assumed zero, a row a kernel forgot to write)
-    then fails a parity test instead of passing by luck -- and is followed by a 512-byte guard band (0xA5) that the
-    `_guard_bands_intact` fixture checks after every test: a kernel that writes past the end of a buffer it was handed
+    then fails a parity test instead of passing by luck -- and sits between two 512-byte guard bands (0xA5) that the
+    `_guard_bands_intact` fixture checks after every test: a kernel that writes outside a buffer it was handed
     fails the test that ran it.  A validation mode for the GPU suite, off by default."""
     if os.environ.get("MI_POISON_EMPTY", "0") != "1":
         return
@@ -41,10 +41,11 @@ def pytest_sessionstart(session):
         for d in shape:
             numel *= int(d)
         item = torch.empty((), dtype=dtype).element_size()
-        flat = orig_empty((numel * item + _GUARD_BYTES,), dtype=torch.uint8, device=device)
-        flat[: numel * item].view(torch.uint8).fill_(0x5A)
-        flat[numel * item:].fill_(0xA5)
-        out = flat[: numel * item].view(dtype).view(*shape) if numel else orig_empty(tuple(shape), dtype=dtype, device=device)
+        flat = orig_empty((numel * item + 2 * _GUARD_BYTES,), dtype=torch.uint8, device=device)
+        flat.fill_(0xA5)                               # guard bands in front of and behind the payload
+        flat[_GUARD_BYTES: _GUARD_BYTES + numel * item].fill_(0x5A)
+        out = (flat[_GUARD_BYTES: _GUARD_BYTES + numel * item].view(dtype).view(*shape) if numel
+               else orig_empty(tuple(shape), dtype=dtype, device=device))
         if numel and out.is_floating_point():
             out.fill_(float("nan"))
         out._mi_guard_base = flat                      # keeps the allocation (and its guard band) alive with the view
@@ -88,7 +89,8 @@ def _guard_bands_intact():
         if flat is None:
             continue
         live.append((ref, nbytes))
-        assert bool((flat[nbytes:] == 0xA5).all()), f"a kernel wrote past the end of a {nbytes}-byte buffer (guard band damaged)"
+        assert bool((flat[:_GUARD_BYTES] == 0xA5).all()), f"a kernel wrote in front of a {nbytes}-byte buffer (guard band damaged)"
+        assert bool((flat[_GUARD_BYTES + nbytes:] == 0xA5).all()), f"a kernel wrote past the end of a {nbytes}-byte buffer (guard band damaged)"
     _guards[:] = live
 
 
