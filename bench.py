@@ -584,8 +584,12 @@ def side_workload(args, rank, world, dev) -> None:
                         torch.cuda.synchronize()
                     return (time.perf_counter() - t0) / iters * 1e3
                 eager = timed(lambda: model(*one))
+                want = [t.clone() for t in model(*one)]
                 graphed = GraphedModule(model, *one)
-                line["latency_one_pair"] = {"eager_ms": eager, "graph_ms": timed(graphed.graph.replay),
+                graph_ms = timed(graphed.graph.replay)
+                if not all(torch.equal(g, w) for g, w in zip(graphed.static_outputs, want)):
+                    raise RuntimeError("latency_one_pair: the replayed graph's outputs differ from the eager call's")
+                line["latency_one_pair"] = {"eager_ms": eager, "graph_ms": graph_ms, "graph_equals_eager": True,
                                             "what": "one 640x480 pair per call through the VO model, host synchronised after every call"}
             line["roofline"] = {"kernel": roof[1], "bound": "hbm", "achieved": nbytes / (t_ms * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -1292,6 +1292,28 @@ def test_hipgraph_replay_survives_device_synchronisation(mods):
                 assert torch.equal(x, y), (single, it)
             noise.fill_(0x55555555 + it)                             # ... and launches something else before the next
             torch.cuda.synchronize()
+    # the other models a per-frame host would replay: the visual-odometry model and the AKAZE matcher
+    from onnx_image_processing_amd.pytorch_model.feature_detection import (AKAZESparseBADSinkhornMatcher,
+                                                                           ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix)
+    a1, b1 = synth_batch(9000, 1, 240, 320)
+    cam = torch.tensor([[300.0, 0.0, 160.0], [0.0, 300.0, 120.0], [0.0, 0.0, 1.0]])
+    vo = ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix(K=cam, max_keypoints=128, block_size=5, num_pairs=512, binarize=True,
+                                                            soft_binarize=False, sinkhorn_iterations=10, epsilon=0.05,
+                                                            nms_radius=3).to(DEV)
+    ak = mods["MatchExtractionWrapper"](AKAZESparseBADSinkhornMatcher(max_keypoints=128, num_pairs=256, binarize=False,
+                                                                       sinkhorn_iterations=10, epsilon=0.05, nms_radius=3),
+                                        max_matches=40, match_threshold=0.1).to(DEV)
+    for m in (vo, ak):
+        x1, x2 = gpu(a1), gpu(b1)
+        eager = [t.clone() for t in m(x1, x2)]
+        graphed = GraphedModule(m, x1, x2)
+        for it in range(3):
+            out = graphed(x1, x2)
+            torch.cuda.synchronize()
+            for x, y in zip(out, eager):
+                assert torch.equal(x, y), (type(m).__name__, it)
+            noise.fill_(it)
+            torch.cuda.synchronize()
     # a batch whose corner response takes the ticket schedule (more than two tiles per resident workgroup)
     a2, b2 = synth_batch(9100, 40, 480, 640)
     m2 = mods["MatchExtractionWrapper"](mods["ShiTomasiSparseBADSinkhornMatcher"](max_keypoints=128, **cfg),
