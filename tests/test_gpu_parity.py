@@ -1330,6 +1330,46 @@ def test_hipgraph_replay_survives_device_synchronisation(mods):
         torch.cuda.synchronize()
 
 
+def test_host_threads_on_their_own_streams(mods):
+    """Four host threads, each with its own stream and its own model instance, run one-pair forwards (ctypes releases the
+    GIL: the C entry points really run concurrently -- the helper-stream registry, the occupancy cache, the BAD plan
+    cache and the single-launch Sinkhorn's workgroups of four calls sharing the device) and every result equals the
+    single-threaded one."""
+    import threading
+    g = load_golden("small_hamming_96x128_k48")
+    cfg = cfg_of(g)
+    a, b = _images(g)
+    make = lambda: mods["MatchExtractionWrapper"](mods["ShiTomasiSparseBADSinkhornMatcher"](max_keypoints=int(g["k"]), **cfg),
+                                                  max_matches=40, match_threshold=0.1).to(DEV)
+    want = [t.clone() for t in make()(gpu(a), gpu(b))]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(tid):
+        try:
+            model = make()
+            stream = torch.cuda.Stream()
+            x, y = gpu(a), gpu(b)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(stream):
+                for it in range(40):
+                    out = model(x, y) if (it + tid) % 2 else model.forward_single_call(x, y)
+                    stream.synchronize()
+                    for o, w in zip(out, want):
+                        if not torch.equal(o, w):
+                            errors.append((tid, it))
+                            return
+        except Exception as e:                                   # noqa: BLE001 -- reported by the assertion below
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def _wrapper_96(mods, k=48):
     cfg = dict(block_size=3, num_pairs=256, binarize=True, soft_binarize=False, sinkhorn_iterations=10, epsilon=0.1,
                nms_radius=2)
