@@ -1830,6 +1830,38 @@ def test_match_pairs_argument_checks(mods):
             .forward_single_call(img, img)                                               # soft descriptors: not covered
 
 
+def test_bench_with_a_forced_rccl_group_of_one():
+    """bench.py itself with MI_BENCH_FORCE_DIST=1: the N-rank control flow of the script (process group joined after the
+    pre-warm, barriers, the pipelined gather of every step's records, the per-rank facts) on real RCCL with one rank.
+    stdout must hold exactly the JSON line (RCCL's version banner goes to stderr), the line must say what it ran on, and
+    the per-pair rate must be that of a run without a group: joining the group BEFORE the first step used to cost the
+    Sinkhorn its stream overlap (175 k instead of 200 k pairs/s per rank, round 3)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        port = sck.getsockname()[1]
+    env = dict(os.environ, MI_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "5", "--cpu-pairs", "0", "--no-extras"]
+    forced = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert forced.returncode == 0, forced.stderr[-2000:]
+    lines = forced.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), forced.stdout[:500]
+    line = json.loads(lines[0])
+    assert line["backend"] == "nccl" and line["ranks_seen"] == 1 and line["n_gpus"] == 1
+    assert line["config"]["result_gather"].startswith("FORCED group of one rank")
+    assert line["config"]["mean_valid_matches_per_pair"] > 50
+    env.pop("MI_BENCH_FORCE_DIST")
+    plain = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    base = json.loads(plain.stdout.splitlines()[-1])
+    assert line["value"] > 0.93 * base["value"], (line["value"], base["value"])
+
+
 def test_rccl_process_group_of_one_runs_the_gather_path(tmp_path):
     """The N > 1 code of bench.py -- init_process_group(backend "nccl" = RCCL), gather of match records, max-over-ranks
     reduction, per-rank facts, barriers, teardown -- on real hardware.  A one-GPU box cannot host two RCCL ranks, so the
