@@ -29,7 +29,9 @@ extern "C" {
  * key 10: workgroups per image of the top-k histogram passes when the candidates are selected from global memory
  * (-1 = automatic, the default; 1 = the single-workgroup form).
  * key 4: Sinkhorn band kernel, 0 = probability form, lean instruction stream (default), 2 = first
- * probability-form kernel, 1 = log-domain (max,sum) partials (results agree to fp32 rounding). */
+ * probability-form kernel, 1 = log-domain (max,sum) partials (results agree to fp32 rounding).
+ * key 11: stream schedule of mi_sinkhorn_dots for >= 64 pairs: -1 = self-tuned per caller stream (default), 0 = halves
+ * on {caller's stream, helper 0}, 1 = halves on {helper 0, helper 1}, 2 = unsplit (same duals bit for bit). */
 MI_API int mi_debug_set(int key, int value);
 /* top-k kernel phase time stamps (100 MHz clock) of workgroup 0 into `buffer` (8 x uint64, device memory); NULL = off */
 MI_API int mi_debug_topk_stamps(void *buffer);

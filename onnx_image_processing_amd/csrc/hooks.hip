@@ -28,7 +28,7 @@ MI_API int mi_debug_set(int key, int value) {
   if (key == 0) {                                  // every selector back to the product's value, probes off
     mi_hooks.corner_impl = 0; mi_hooks.corner_rows = 4; mi_hooks.corner_rows_u8_default = 1;
     mi_hooks.sinkhorn_log_partials = 0; mi_hooks.sinkhorn_split = 2; mi_hooks.sinkhorn_persist = 1;
-    mi_hooks.sinkhorn_stamps = 0; mi_hooks.topk_select = 1; mi_hooks.topk_split = -1;
+    mi_hooks.sinkhorn_stamps = 0; mi_hooks.topk_select = 1; mi_hooks.topk_split = -1; mi_hooks.sinkhorn_schedule = -1;
     mi_hooks.corner_clk = nullptr; mi_hooks.topk_prof = nullptr;
     return MI_OK;
   }
@@ -40,6 +40,7 @@ MI_API int mi_debug_set(int key, int value) {
   if (key == 8) { mi_hooks.sinkhorn_stamps = value; return MI_OK; }
   if (key == 9) { mi_hooks.topk_select = value; return MI_OK; }
   if (key == 10) { mi_hooks.topk_split = value; return MI_OK; }
+  if (key == 11 && value >= -1 && value <= 2) { mi_hooks.sinkhorn_schedule = value; return MI_OK; }
   return MI_E_PARAM;
 }
 

@@ -11,6 +11,8 @@
 // row pass leaves P_ij = e_ij / s_i in registers, the column update is v_j += log nu_j -
 // log(sum_i P_ij), the dustbin row is merged in the log domain).
 #include "common.h"
+
+#include <mutex>
 #include "stream_registry.h"
 
 #include <math.h>
@@ -790,19 +792,42 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
 // unchanged: everything is ordered after earlier work on `s` and before later work on it.  The streams and
 // events belong to ONE caller (device, stream) -- stream_registry.h says why -- and are created on the first
 // call with >= 64 pairs on that stream; at most SK_MAX_CALLERS callers get them, later ones run unforked.
+//
+// Which streams the two half-batches go to is SELF-TUNED per caller (round 3).  Whether two streams' kernels overlap
+// depends on how the runtime mapped them onto the device's few hardware queues, i.e. on everything the process created
+// before them: with the halves on {caller's stream, helper 0} a 448-pair call takes 0.92 ms -- unless an RCCL communicator
+// was created first, then 1.15 ms, while {helper 0, helper 1} takes 0.92 there and 1.02 without the communicator; the
+// unsplit call takes 1.00 either way.  So the first calls of a caller try the three schedules in turn, each bracketed by
+// two timing events on the caller's stream; later calls collect the elapsed times WITHOUT waiting (hipEventQuery) and
+// from then on every call uses the fastest.  Nothing is tried inside a stream capture (a capture before the decision
+// gets schedule 0), the schedules compute the same duals bit for bit, and the decision only ever changes speed.
 constexpr int SK_MAX_PARTS = 4;
 constexpr size_t SK_MAX_CALLERS = 64;
+constexpr int SK_SCHEDULES = 3;          // 0: halves on {caller, helper 0}; 1: halves on {helper 0, helper 1}; 2: unsplit
+constexpr int SK_TRIALS = 2 * SK_SCHEDULES;
 struct ForkJoin {
   hipStream_t side[SK_MAX_PARTS - 1] = {};
   hipEvent_t fork = nullptr, join[SK_MAX_PARTS - 1] = {};
   bool ok = false;
+  // self-tuning state (guarded by mu; calls on one stream are normally serial anyway)
+  std::mutex mu;
+  hipEvent_t t0[SK_TRIALS] = {}, t1[SK_TRIALS] = {};
+  bool pending[SK_TRIALS] = {};
+  int started = 0, finished = 0, decided = -1;
+  float best_ms[SK_SCHEDULES] = {1e30f, 1e30f, 1e30f};
   ForkJoin() {
     ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < SK_MAX_PARTS - 1; ++i)
       ok = ok && hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) == hipSuccess &&
            hipEventCreateWithFlags(&join[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < SK_TRIALS; ++i)
+      ok = ok && hipEventCreate(&t0[i]) == hipSuccess && hipEventCreate(&t1[i]) == hipSuccess;
   }
   ~ForkJoin() {
+    for (int i = 0; i < SK_TRIALS; ++i) {
+      if (t0[i]) (void)hipEventDestroy(t0[i]);
+      if (t1[i]) (void)hipEventDestroy(t1[i]);
+    }
     for (int i = 0; i < SK_MAX_PARTS - 1; ++i) {
       if (join[i]) (void)hipEventDestroy(join[i]);
       if (side[i]) (void)hipStreamDestroy(side[i]);
@@ -811,6 +836,49 @@ struct ForkJoin {
   }
   ForkJoin(const ForkJoin &) = delete;
   ForkJoin &operator=(const ForkJoin &) = delete;
+  // The schedule of this call and, while the caller is still being tuned, the trial slot whose events bracket it (-1:
+  // none).  Never blocks: finished trials are harvested with hipEventQuery.
+  int pick(hipStream_t s, int *trial) {
+    *trial = -1;
+    std::lock_guard<std::mutex> lock(mu);
+    // inside a stream capture nothing is queried or recorded: the decision taken so far (or schedule 0) is captured
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return decided >= 0 ? decided : 0; }
+    if (cap != hipStreamCaptureStatusNone) return decided >= 0 ? decided : 0;
+    for (int i = 0; i < started; ++i) {
+      if (!pending[i]) continue;
+      if (hipEventQuery(t1[i]) != hipSuccess) { (void)hipGetLastError(); continue; }
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, t0[i], t1[i]) == hipSuccess && ms > 0.0f) {
+        if (ms < best_ms[i % SK_SCHEDULES]) best_ms[i % SK_SCHEDULES] = ms;
+      } else {
+        (void)hipGetLastError();
+      }
+      pending[i] = false;
+      ++finished;
+    }
+    if (decided < 0 && finished == SK_TRIALS) {
+      decided = 0;
+      for (int c = 1; c < SK_SCHEDULES; ++c)
+        if (best_ms[c] < best_ms[decided]) decided = c;
+    }
+    if (decided >= 0) return decided;
+    if (started == SK_TRIALS) return 0;
+    const int slot = started;
+    if (hipEventRecord(t0[slot], s) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    ++started;
+    *trial = slot;
+    return slot % SK_SCHEDULES;
+  }
+  void close_trial(int slot, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (hipEventRecord(t1[slot], s) == hipSuccess) {
+      pending[slot] = true;
+    } else {                                                  // the slot counts as done (nothing learnt from it)
+      (void)hipGetLastError();
+      ++finished;
+    }
+  }
 };
 using ForkJoinKey = std::pair<int, hipStream_t>;   // (device, caller stream)
 mi::KeyedRegistry<ForkJoinKey, ForkJoin> &fork_join_registry() {
@@ -846,10 +914,20 @@ int launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int ba
   if (parts < 1 || batch < 32 * parts) parts = 1;
   ForkJoin *fj = parts > 1 ? fork_join_for(s) : nullptr;
   if (!fj) parts = 1;
+  // first_side: the first part that runs on a helper stream (1: part 0 stays on the caller's stream; 0: every part on a
+  // helper).  With the default two parts the caller's schedule is self-tuned (ForkJoin above).
+  int first_side = 1, trial = -1;
+  if (parts == 2) {
+    const int fixed = MI_HOOK(sinkhorn_schedule, -1);
+    const int sched = fixed >= 0 ? fixed : fj->pick(s, &trial);
+    if (sched == 1) first_side = 0;
+    if (sched == 2) parts = 1;
+  }
   if (parts > 1) {
     // any failure here leaves the side streams unused: run unforked (a side stream that already waits is harmless)
     bool forked = hipEventRecord(fj->fork, s) == hipSuccess;
-    for (int q = 1; forked && q < parts; ++q) forked = hipStreamWaitEvent(fj->side[q - 1], fj->fork, 0) == hipSuccess;
+    for (int q = first_side; forked && q < parts; ++q)
+      forked = hipStreamWaitEvent(fj->side[q - first_side], fj->fork, 0) == hipSuccess;
     if (!forked) {
       (void)hipGetLastError();
       parts = 1;
@@ -860,7 +938,7 @@ int launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int ba
     const int vz = it == 0 ? 1 : 0;
     for (int q = 0; q < parts; ++q) {
       const int b0 = (int)((long long)batch * q / parts), nbatch = (int)((long long)batch * (q + 1) / parts) - b0;
-      hipStream_t st = q ? fj->side[q - 1] : s;
+      hipStream_t st = (parts > 1 && q >= first_side) ? fj->side[q - first_side] : s;
       const uint16_t *d0 = dots + (size_t)b0 * n * pitch;
       const float2 *ri0 = ri + (size_t)b0 * n, *ci0 = ci + (size_t)b0 * m;
       float *u0 = u + (size_t)b0 * (n + 1), *v0 = v + (size_t)b0 * (m + 1);
@@ -873,11 +951,12 @@ int launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int ba
     }
   }
   // join: without it later work on `s` would not be ordered after the side streams, so a failure is an error
-  for (int q = 1; q < parts; ++q) {
-    hipError_t e = hipEventRecord(fj->join[q - 1], fj->side[q - 1]);
-    if (e == hipSuccess) e = hipStreamWaitEvent(s, fj->join[q - 1], 0);
+  for (int q = first_side; q < parts; ++q) {
+    hipError_t e = hipEventRecord(fj->join[q - first_side], fj->side[q - first_side]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, fj->join[q - first_side], 0);
     if (e != hipSuccess) return (int)e;
   }
+  if (trial >= 0) fj->close_trial(trial, s);
   return mi_launch_status();
 }
 

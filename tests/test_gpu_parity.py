@@ -385,6 +385,39 @@ def test_sinkhorn_single_launch_equals_multi_launch(mods, batch, n, m, normalize
     assert ok, worst
 
 
+def test_sinkhorn_stream_schedules_agree(mods):
+    """mi_sinkhorn_dots for >= 64 pairs picks the streams of its two half-batches itself (caller + helper, two helpers,
+    or unsplit -- whichever the first calls on a caller stream measured fastest; csrc/sinkhorn_dots.hip ForkJoin).  The
+    schedules are the same arithmetic: duals and P of every fixed schedule (debug library, key 11) and of the self-tuned
+    default -- through its trial calls and after its decision, on the default stream and on a second stream -- are
+    identical."""
+    from onnx_image_processing_amd import _native as N, ops
+    rng = np.random.default_rng(77)
+    b1 = rng.integers(0, 2 ** 32, size=(70, 300, 16), dtype=np.uint64).astype(np.uint32)
+    b2 = rng.integers(0, 2 ** 32, size=(70, 280, 16), dtype=np.uint64).astype(np.uint32)
+    b2[:, :100] = b1[:, :100]
+    t1, t2 = gpu(b1.view(np.int32)), gpu(b2.view(np.int32))
+    run = lambda: [t.clone() for t in ops.sinkhorn_bits(t1, t2, True, 0.05, 1.0, 12, return_duals=True)]
+    with N.debug_library() as lib:
+        want = None
+        for sched in (0, 1, 2):
+            assert lib.mi_debug_set(11, sched) == 0
+            got = run()
+            want = want or got
+            for x, y in zip(got, want):
+                assert torch.equal(x, y), sched
+        assert lib.mi_debug_set(11, -1) == 0
+        assert lib.mi_debug_set(11, 3) != 0
+    other = torch.cuda.Stream()
+    for stream in (torch.cuda.current_stream(), other):
+        with torch.cuda.stream(stream):
+            for call in range(9):                                # six trial calls, then the decided schedule
+                for x, y in zip(run(), want):
+                    assert torch.equal(x, y), call
+                stream.synchronize()
+    assert torch.isfinite(want[0]).all()
+
+
 @pytest.mark.parametrize("n,m", [(512, 512), (97, 301), (5, 3), (700, 1000), (64, 1500)])
 def test_sinkhorn_fused_equals_two_pass(mods, n, m):
     """The band-fused iteration (Z read once) and the two-pass form agree to fp32 rounding, and both
