@@ -813,8 +813,9 @@ struct ForkJoin {
   std::mutex mu;
   hipEvent_t t0[SK_TRIALS] = {}, t1[SK_TRIALS] = {};
   bool pending[SK_TRIALS] = {};
+  double work[SK_TRIALS] = {};           // matrix elements x iterations of the trial call: times are compared per unit
   int started = 0, finished = 0, decided = -1;
-  float best_ms[SK_SCHEDULES] = {1e30f, 1e30f, 1e30f};
+  double best[SK_SCHEDULES] = {1e300, 1e300, 1e300};
   ForkJoin() {
     ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < SK_MAX_PARTS - 1; ++i)
@@ -838,7 +839,7 @@ struct ForkJoin {
   ForkJoin &operator=(const ForkJoin &) = delete;
   // The schedule of this call and, while the caller is still being tuned, the trial slot whose events bracket it (-1:
   // none).  Never blocks: finished trials are harvested with hipEventQuery.
-  int pick(hipStream_t s, int *trial) {
+  int pick(hipStream_t s, double call_work, int *trial) {
     *trial = -1;
     std::lock_guard<std::mutex> lock(mu);
     // inside a stream capture nothing is queried or recorded: the decision taken so far (or schedule 0) is captured
@@ -849,8 +850,9 @@ struct ForkJoin {
       if (!pending[i]) continue;
       if (hipEventQuery(t1[i]) != hipSuccess) { (void)hipGetLastError(); continue; }
       float ms = 0.0f;
-      if (hipEventElapsedTime(&ms, t0[i], t1[i]) == hipSuccess && ms > 0.0f) {
-        if (ms < best_ms[i % SK_SCHEDULES]) best_ms[i % SK_SCHEDULES] = ms;
+      if (hipEventElapsedTime(&ms, t0[i], t1[i]) == hipSuccess && ms > 0.0f && work[i] > 0.0) {
+        const double per_unit = (double)ms / work[i];
+        if (per_unit < best[i % SK_SCHEDULES]) best[i % SK_SCHEDULES] = per_unit;
       } else {
         (void)hipGetLastError();
       }
@@ -860,12 +862,13 @@ struct ForkJoin {
     if (decided < 0 && finished == SK_TRIALS) {
       decided = 0;
       for (int c = 1; c < SK_SCHEDULES; ++c)
-        if (best_ms[c] < best_ms[decided]) decided = c;
+        if (best[c] < best[decided]) decided = c;
     }
     if (decided >= 0) return decided;
     if (started == SK_TRIALS) return 0;
     const int slot = started;
     if (hipEventRecord(t0[slot], s) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    work[slot] = call_work;
     ++started;
     *trial = slot;
     return slot % SK_SCHEDULES;
@@ -919,7 +922,7 @@ int launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int ba
   int first_side = 1, trial = -1;
   if (parts == 2) {
     const int fixed = MI_HOOK(sinkhorn_schedule, -1);
-    const int sched = fixed >= 0 ? fixed : fj->pick(s, &trial);
+    const int sched = fixed >= 0 ? fixed : fj->pick(s, (double)batch * n * m * iterations, &trial);
     if (sched == 1) first_side = 0;
     if (sched == 2) parts = 1;
   }
