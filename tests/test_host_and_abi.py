@@ -316,6 +316,18 @@ def test_stream_registry_native_unit(tmp_path):
     assert r.returncode == 0 and "stream_registry ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_library_does_not_import_hip_memset(lib_path):
+    """No entry point clears memory with hipMemset*: a memset call captured into a hipGraph became a node that zeroed its
+    range on the first replay only on ROCm 7.2 (tools/graph_memset_probe.py); the library's clears
+    are kernels (csrc/common.h mi_zero_async).  The import table of both libraries is the cheapest place to hold that."""
+    import subprocess
+    from onnx_image_processing_amd import _native
+    for path in (lib_path, _native.DEBUG_LIB_PATH):
+        syms = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+        assert "hipLaunchKernel" in syms or "hipModuleLaunchKernel" in syms or "__hipPushCallConfiguration" in syms
+        assert not [ln for ln in syms.splitlines() if "hipMemset" in ln], path
+
+
 def test_dots_form_refuses_small_epsilon(lib_path):
     """MI_DOTS_MIN_EPSILON: the packed Sinkhorn form drops the cost clamp and is refused below epsilon = 0.005 on the
     host, before any launch."""
