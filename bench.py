@@ -6,7 +6,10 @@
 
 Both forms work for N > 1: under torchrun the ranks exist already; a bare `python bench.py --gpus N` starts N fresh rank
 processes itself (launch_ranks) before touching the GPU.  The N > 1 line records the world size the backend actually
-formed (`ranks_seen`, `backend`) and every rank's own ms per step.
+formed (`ranks_seen`, `backend`) and every rank's own ms per step.  The process group is joined after two untimed
+steps (join_group: a communicator created before the first step changed the runtime's hardware-queue mapping and cost the
+Sinkhorn call its stream overlap), stdout carries nothing but the JSON line (RCCL's version banner goes to stderr), and
+`MI_BENCH_FORCE_DIST=1 python bench.py` runs the N-rank control flow with a real RCCL group of ONE rank on a one-GPU box.
 
 One "step" = one pass of the whole path (Shi-Tomasi -> NMS/top-k -> sparse BAD -> cost -> Sinkhorn -> mutual-NN match
 extraction; the reference's MatchExtractionWrapper form) over a batch of B synthetic pairs per GPU that is already
