@@ -14,12 +14,24 @@
  *     work), nothing synchronises, nothing allocates device memory.  mi_sinkhorn_dots (and
  *     mi_match_pairs through it) overlaps the halves of a batch of >= 64 pairs on helper streams
  *     joined back into `stream` by events; those helpers belong to the calling (device, stream) and
- *     are created on its first such call (mi_release_stream_resources frees them);
+ *     are created on its first such call (mi_release_stream_resources frees them).  WHICH streams the
+ *     halves run on is tuned per calling stream and per shape (batch, n, m, iterations): the first
+ *     9 such calls of a shape try three schedules -- halves on {stream, helper}, on {helper, helper},
+ *     unsplit -- three times each, every trial call bracketed by two hipEventRecord on `stream`; later
+ *     calls read the elapsed times without waiting (hipEventQuery) and use the fastest schedule; the
+ *     decision is re-measured every 8192 calls.  Same results bit for bit whatever the schedule.  Inside
+ *     a stream capture nothing is tried, recorded or queried: the capture takes the decision in force,
+ *     or the unsplit schedule when there is none.  mi_sinkhorn_dots_schedule reports the schedule in
+ *     force, mi_sinkhorn_dots_set_schedule pins one, and the flag MI_SOLVER_NO_FORK keeps every kernel
+ *     of the call on `stream` (no helper stream, no event, no tuning);
  *   - threads and devices: the device of `stream` must be the calling thread's current device.  Calls
  *     on DIFFERENT streams may run concurrently from different host threads; calls on the SAME
- *     stream must be serialised by the caller (as for any HIP stream).  The library holds no other
- *     mutable state and has no process-wide switches (the kernel-variant test hooks of
- *     include/mi355x_match_debug.h exist only in the separate libmi355x_match_debug.so);
+ *     stream must be serialised by the caller (as for any HIP stream).  Mutable state of the library:
+ *     (a) per calling (device, stream): the helper streams / events above and the schedule tuner's
+ *     trial times and decisions (mutex-guarded); (b) per device: one cached occupancy query (the
+ *     single-launch Sinkhorn form) and the compute-unit count.  No process-wide switches (the
+ *     kernel-variant test hooks of include/mi355x_match_debug.h exist only in the separate
+ *     libmi355x_match_debug.so);
  *   - co-residency: ONE kernel of this library needs its whole grid resident on the device at the same
  *     time -- the single-launch Sinkhorn form mi_sinkhorn_dots / mi_match_pairs use for <= 8 pairs
  *     (<= 128 workgroups of 512 threads whose bands hand column sums to each other inside the launch).
@@ -66,7 +78,20 @@ enum { MI_DIST_L2 = 0, MI_DIST_L1 = 1 };
 /* smallest epsilon of the packed (uint16 dot product) Sinkhorn form, see mi_sinkhorn_dots */
 #define MI_DOTS_MIN_EPSILON 0.005
 /* flags of mi_sinkhorn_dots / mi_match_params (see "co-residency" above) */
-enum { MI_SOLVER_DEFAULT = 0, MI_SOLVER_MULTI_LAUNCH = 1 /* never the single-launch Sinkhorn form */ };
+enum {
+  MI_SOLVER_DEFAULT = 0,
+  MI_SOLVER_MULTI_LAUNCH = 1, /* never the single-launch Sinkhorn form */
+  MI_SOLVER_NO_FORK = 2       /* never fork onto helper streams: every kernel of the call on `stream` (e.g. for a
+                                 capture that must not contain cross-stream branches, or a device with one hardware
+                                 queue); bit-identical results, the >= 64-pair Sinkhorn runs ~8 % slower */
+};
+/* stream schedules of mi_sinkhorn_dots for >= 64 pairs (see the conventions above) */
+enum {
+  MI_SCHEDULE_UNDECIDED = -1,  /* nothing decided or pinned yet for this stream / shape */
+  MI_SCHEDULE_CALLER_HELPER = 0, /* halves on {caller's stream, helper 0} */
+  MI_SCHEDULE_TWO_HELPERS = 1, /* halves on {helper 0, helper 1} */
+  MI_SCHEDULE_UNSPLIT = 2      /* one part on the caller's stream */
+};
 
 MI_API int mi_abi_version(void);
 MI_API const char *mi_error_string(int code);
@@ -74,6 +99,16 @@ MI_API const char *mi_error_string(int code);
  * before destroying a stream that was passed to mi_sinkhorn_dots / mi_match_pairs with >= 64 pairs; the
  * stream's helper work must have completed (synchronise the stream first). */
 MI_API int mi_release_stream_resources(mi_stream_t stream);
+/* The stream schedule in force for mi_sinkhorn_dots calls of this shape on (current device, stream): the pinned
+ * schedule, the tuner's decision, or MI_SCHEDULE_UNDECIDED.  Never blocks (finished trials are collected with
+ * hipEventQuery).  Hosts log it next to their timings; a capture taken while it is undecided records the unsplit
+ * schedule. */
+MI_API int mi_sinkhorn_dots_schedule(mi_stream_t stream, int batch, int n, int m, int iterations);
+/* Pin `schedule` (MI_SCHEDULE_CALLER_HELPER .. MI_SCHEDULE_UNSPLIT) for every shape on (current device, stream) --
+ * nothing is tried or timed while pinned --, or MI_SCHEDULE_UNDECIDED to unpin and forget every decision (tuning starts
+ * over).  Creates the stream's helper resources if they do not exist yet (MI_E_CAPACITY when the library already serves
+ * 64 caller streams). */
+MI_API int mi_sinkhorn_dots_set_schedule(mi_stream_t stream, int schedule);
 
 /* ---- detector/shi_tomasi.py:66-112  ShiTomasiScore.forward ---------------------------------
  * score[n,1,h,w] = max(0, (a+c)/2 - sqrt(((a-c)/2)^2 + b^2 + 1e-10)) of the Sobel structure
@@ -325,12 +360,27 @@ MI_API int mi_akaze_diffuse(const float *l_in, int n, int h, int w, float kappa,
                      mi_stream_t stream);
 /* One scale of AKAZE.forward (akaze.py:430-440) in one launch: l_out = `iterations` diffusion steps of l_in,
  * scores = mi_akaze_hessian_scores(l_out); identical maps, 12 instead of 8 * iterations + 8 bytes per pixel of HBM
- * traffic (the steps run on an LDS-resident tile).  Fused for iterations 1..3 and nms_size 3 / 5 / 7
- * (mi_akaze_scale_fused returns 1); other values run the per-step kernels and then need `tmp` (n*h*w floats) when
- * iterations > 1.  l_out must not alias l_in. */
+ * traffic.  Fused for iterations 1..3 and nms_size 3 / 5 / 7 (mi_akaze_scale_fused returns 1) -- as a rolling window
+ * that streams down the image (even w, 8-byte aligned maps, nms_size 3 / 5) or on an LDS-resident tile --; other
+ * values run the per-step kernels and then need `tmp` (n*h*w floats) when iterations > 1.  l_out must not alias l_in.
+ * kappa must lie in [MI_AKAZE_KAPPA_MIN, MI_AKAZE_KAPPA_MAX] (the range the fused kernels' exactly rounded division
+ * helpers are verified for; MI_E_PARAM otherwise -- mi_akaze_diffuse + mi_akaze_hessian_scores take any kappa > 0). */
+#define MI_AKAZE_KAPPA_MIN 1e-3f
+#define MI_AKAZE_KAPPA_MAX 1e6f
 MI_API int mi_akaze_scale_fused(int iterations, int nms_size);
 MI_API int mi_akaze_scale(const float *l_in, int n, int h, int w, int iterations, float kappa, float dt, float threshold,
                    int nms_size, float *l_out, float *scores, float *tmp, mi_stream_t stream);
+/* The LAST scale with AKAZE.forward's selection across scales (akaze.py:436-451) folded in: l_out as mi_akaze_scale;
+ * instead of this scale's score map, best (n,h,w) = max over the num_prev (<= 7) earlier scales' maps prev_scores
+ * (num_prev,n,h,w) and this scale's, and attain (n,h,w) uint8: bit s set when earlier scale s reaches that maximum,
+ * bit num_prev when this scale does -- what mi_akaze_combine computes from stacked maps, without the stack's last map
+ * and without a pass of its own (the streaming form reads the earlier maps where it writes its output row).
+ * mi_akaze_orientation_from_attain: mi_akaze_orientation_at_keypoints from `attain` instead of the stacked maps. */
+MI_API int mi_akaze_scale_select(const float *l_in, int n, int h, int w, int iterations, float kappa, float dt,
+                          float threshold, int nms_size, float *l_out, const float *prev_scores, int num_prev,
+                          float *best, uint8_t *attain, float *tmp, mi_stream_t stream);
+MI_API int mi_akaze_orientation_from_attain(const uint8_t *attain, const float *scale_theta, int num_scales, int n, int h,
+                                     int w, const float *keypoints, int k, float *theta, mi_stream_t stream);
 MI_API int mi_akaze_hessian_scores(const float *l, int n, int h, int w, float threshold, int nms_size, float *scores,
                             mi_stream_t stream);
 MI_API int mi_akaze_combine(const float *scale_scores, const float *scale_orientations, int num_scales, int n, int h,
@@ -406,7 +456,8 @@ typedef struct mi_match_params {
   int sinkhorn_iterations;
   int max_matches;           /* MutualNearestNeighborMatcher */
   float match_threshold;
-  int flags;                 /* MI_SOLVER_DEFAULT or MI_SOLVER_MULTI_LAUNCH (see "co-residency" in the conventions) */
+  int flags;                 /* MI_SOLVER_DEFAULT or an OR of MI_SOLVER_MULTI_LAUNCH ("co-residency" in the conventions)
+                                and MI_SOLVER_NO_FORK */
 } mi_match_params;
 MI_API size_t mi_match_pairs_workspace_bytes(int batch, int h, int w, const mi_match_params *params);
 MI_API int mi_match_pairs(const float *image1, const float *image2, int batch, int h, int w,

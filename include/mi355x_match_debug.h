@@ -31,7 +31,9 @@ extern "C" {
  * key 4: Sinkhorn band kernel, 0 = probability form, lean instruction stream (default), 2 = first
  * probability-form kernel, 1 = log-domain (max,sum) partials (results agree to fp32 rounding).
  * key 11: stream schedule of mi_sinkhorn_dots for >= 64 pairs: -1 = self-tuned per caller stream (default), 0 = halves
- * on {caller's stream, helper 0}, 1 = halves on {helper 0, helper 1}, 2 = unsplit (same duals bit for bit). */
+ * on {caller's stream, helper 0}, 1 = halves on {helper 0, helper 1}, 2 = unsplit (same duals bit for bit).
+ * key 12: fused AKAZE scale (mi_akaze_scale / mi_akaze_scale_select), 0 = streaming rolling-window kernel where it
+ * applies (default), 1 = LDS-tile kernel / per-step kernels (same maps bit for bit). */
 MI_API int mi_debug_set(int key, int value);
 /* top-k kernel phase time stamps (100 MHz clock) of workgroup 0 into `buffer` (8 x uint64, device memory); NULL = off */
 MI_API int mi_debug_topk_stamps(void *buffer);
@@ -45,6 +47,14 @@ MI_API int mi_debug_bad_plan_passes(const uint32_t *pair_geom_host, int num_pair
  * device that can hold `blocks_per_cu` workgroups of the single-launch kernel on each of `cus` compute units: the pure
  * host decision function the library applies to the occupancy query's answer.  Host only, no GPU. */
 MI_API int mi_debug_sinkhorn_dots_form(int batch, int n, int m, int flags, int blocks_per_cu, int cus);
+
+/* The decision logic of mi_sinkhorn_dots' stream-schedule tuner (csrc/sk_tuner.h) on a fresh state, driven by a
+ * script of n_ops operations with injected timings.  Host only, no GPU.  op 0: an eager call of the shape with batch =
+ * arg -> out = schedule | (slot & 0xff) << 8 | (entry & 0xff) << 16 (slot = entry = 0xff: no trial handed out);
+ * op 1: trial (entry = arg >> 8, slot = arg & 0xff) finished in val milliseconds; op 2: that trial abandoned;
+ * op 3: out = the schedule in force for batch = arg (-1: undecided); op 4: out = the schedule a capture would get;
+ * op 5: pin schedule arg (-1: unpin and forget), out = 0 / -1. */
+MI_API int mi_debug_tuner_script(int n_ops, const int *op, const int *arg, const double *val, int *out);
 
 /* Exhaustive check of the fused AKAZE kernel's exact-rounding helpers (csrc/akaze_math.h) against the IEEE operators:
  * every float whose bit pattern lies in [lo_bits, hi_bits) is tried; which = 0: sqrt, 1: x / kappa through the

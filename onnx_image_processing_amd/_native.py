@@ -19,6 +19,8 @@ LIB_PATH = os.environ.get("MI355X_MATCH_LIB") or os.path.join(_PKG, "lib", "libm
 # name -> argtypes (return type is int unless listed in _RESTYPE); mirrors include/mi355x_match.h
 SIGNATURES = {
     "mi_abi_version": [],
+    "mi_sinkhorn_dots_schedule": [c_void_p, c_int, c_int, c_int, c_int],
+    "mi_sinkhorn_dots_set_schedule": [c_void_p, c_int],
     "mi_error_string": [c_int],
     "mi_release_stream_resources": [c_void_p],
     "mi_corner_response": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
@@ -76,6 +78,10 @@ SIGNATURES = {
     "mi_akaze_scale_fused": [c_int, c_int],
     "mi_akaze_scale": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
                        c_void_p],
+    "mi_akaze_scale_select": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p, c_void_p,
+                              c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mi_akaze_orientation_from_attain": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+                                         c_void_p],
     "mi_akaze_hessian_scores": [c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     "mi_akaze_combine": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mi_akaze_orientation_at_keypoints": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
@@ -100,6 +106,7 @@ SIGNATURES["mi_match_pairs"] = [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.
 DEBUG_SIGNATURES = {"mi_debug_set": [c_int, c_int], "mi_debug_topk_stamps": [c_void_p], "mi_debug_clock_probe": [c_void_p],
                     "mi_debug_bad_plan_passes": [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
                     "mi_debug_sinkhorn_dots_form": [c_int, c_int, c_int, c_int, c_int, c_int],
+                    "mi_debug_tuner_script": [c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)],
                     "mi_debug_akaze_math_check": [c_int, c_float, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p]}
 SIGNATURES["mi_match_pairs_u8"] = SIGNATURES["mi_match_pairs"]
 _RESTYPE = {"mi_essential_matrix_workspace_bytes": c_size_t, "mi_sinkhorn_dots_status_word": c_void_p, "mi_match_pairs_workspace_bytes": c_size_t, "mi_error_string": c_char_p, "mi_sinkhorn_workspace_bytes": c_size_t, "mi_bad_plan_bytes": c_size_t,

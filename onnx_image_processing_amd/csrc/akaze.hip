@@ -15,6 +15,7 @@
 // 64x16 tiles through LDS, four pixels per thread; the NMS window maximum is separable (rows, then columns).
 #include "common.h"
 #include "akaze_math.h"
+#include "hooks.h"
 
 #include <math.h>
 
@@ -482,8 +483,12 @@ extern "C" int mi_akaze_scale(const float *l_in, int n, int h, int w, int iterat
   MI_ENTER();
   if (!l_in || !l_out || !scores || l_in == l_out) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
-  if (iterations <= 0 || !(kappa > 0.0f) || nms_size <= 0 || (nms_size & 1) == 0 || nms_size > 15) return MI_E_PARAM;
+  if (iterations <= 0 || !mi_akaze_kappa_ok(kappa) || nms_size <= 0 || (nms_size & 1) == 0 || nms_size > 15) return MI_E_PARAM;
   hipStream_t s = (hipStream_t)stream;
+  // the streaming rolling-window form (akaze_stream.hip): even widths, 8-byte aligned maps, nms_size 3 / 5
+  if (MI_HOOK(akaze_impl, 0) == 0 && mi_akaze_stream_supported(h, w, iterations, nms_size, l_in, l_out, scores))
+    return mi_akaze_scale_stream(l_in, n, h, w, iterations, kappa, dt, threshold, nms_size, l_out, scores, 0, nullptr, 0,
+                                 nullptr, stream);
   if (mi_akaze_scale_fused(iterations, nms_size)) {
     const int halo = 2 * iterations + 1 + nms_size / 2;
     const int tx = ceil_div(w, 64 - 2 * halo), ty = ceil_div(h, AS_H);
@@ -507,4 +512,79 @@ extern "C" int mi_akaze_scale(const float *l_in, int n, int h, int w, int iterat
     cur = dst;
   }
   return mi_akaze_hessian_scores(l_out, n, h, w, threshold, nms_size, scores, stream);
+}
+
+// ---- the LAST scale with AKAZE.forward's selection across scales folded in (akaze.py:436-451) ---------------------
+namespace {
+// best = max(prev maps, cur); attain bit s = prev map s reaches it, bit num_prev = cur does.  cur may alias best.
+__global__ __launch_bounds__(256) void select_kernel(const float *__restrict__ prev, int num_prev, size_t plane,
+                                                     const float *cur, float *best, uint8_t *__restrict__ attain) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= plane) return;
+  const float c = cur[i];
+  float mx = c;
+  for (int s = 0; s < num_prev; ++s) mx = fmaxf(mx, prev[(size_t)s * plane + i]);
+  unsigned a = (c == mx) ? (1u << num_prev) : 0u;
+  for (int s = 0; s < num_prev; ++s) a |= (prev[(size_t)s * plane + i] == mx) ? (1u << s) : 0u;
+  best[i] = mx;
+  attain[i] = (uint8_t)a;
+}
+
+// orientation = mean of the per-scale keypoint orientations over the scales that attain the maximum (:442-451)
+__global__ __launch_bounds__(256) void attain_kp_kernel(const uint8_t *__restrict__ attain,
+                                                        const float *__restrict__ theta_s, int nscales, int n, int h,
+                                                        int w, const float *__restrict__ kpts, int k,
+                                                        float *__restrict__ theta) {
+  const int flat = blockIdx.x * 256 + threadIdx.x;
+  if (flat >= n * k) return;
+  const int img = flat / k;
+  const float ky = fminf(fmaxf(kpts[(size_t)flat * 2 + 0], 0.0f), (float)(h - 1));
+  const float kx = fminf(fmaxf(kpts[(size_t)flat * 2 + 1], 0.0f), (float)(w - 1));
+  const float sy = (float)(2.0 / ((double)(h - 1) + 1e-8)), sx = (float)(2.0 / ((double)(w - 1) + 1e-8));
+  const float ny = ((ky * sy - 1.0f + 1.0f) / 2.0f) * (float)(h - 1);
+  const float nx = ((kx * sx - 1.0f + 1.0f) / 2.0f) * (float)(w - 1);
+  const int cy = (int)nearbyintf(fminf(fmaxf(ny, 0.0f), (float)(h - 1)));
+  const int cx = (int)nearbyintf(fminf(fmaxf(nx, 0.0f), (float)(w - 1)));
+  const unsigned a = attain[((size_t)img * h + cy) * w + cx];
+  const float cnt = fmaxf((float)__popc(a & ((1u << nscales) - 1u)), 1.0f);
+  float acc = 0.0f;
+  for (int s = 0; s < nscales; ++s) {
+    const float m = (((a >> s) & 1u) ? 1.0f : 0.0f) / cnt;
+    acc += theta_s[(size_t)s * n * k + flat] * m;
+  }
+  theta[flat] = acc;
+}
+}  // namespace
+
+extern "C" int mi_akaze_scale_select(const float *l_in, int n, int h, int w, int iterations, float kappa, float dt,
+                                     float threshold, int nms_size, float *l_out, const float *prev_scores,
+                                     int num_prev, float *best, uint8_t *attain, float *tmp, mi_stream_t stream) {
+  MI_ENTER();
+  if (!l_in || !l_out || !best || !attain || l_in == l_out || (num_prev > 0 && !prev_scores)) return MI_E_NULL;
+  if (n <= 0 || h <= 0 || w <= 0) return MI_E_SHAPE;
+  if (num_prev < 0 || num_prev > 7) return MI_E_PARAM;
+  if (iterations <= 0 || !mi_akaze_kappa_ok(kappa) || nms_size <= 0 || (nms_size & 1) == 0 || nms_size > 15) return MI_E_PARAM;
+  if (MI_HOOK(akaze_impl, 0) == 0 && mi_akaze_stream_supported(h, w, iterations, nms_size, l_in, l_out, best) &&
+      ((uintptr_t)prev_scores & 7u) == 0 && ((uintptr_t)attain & 1u) == 0)
+    return mi_akaze_scale_stream(l_in, n, h, w, iterations, kappa, dt, threshold, nms_size, l_out, best, 1, prev_scores,
+                                 num_prev, attain, stream);
+  // general parameters: this scale's map into `best`, then the selection in place
+  const int e = mi_akaze_scale(l_in, n, h, w, iterations, kappa, dt, threshold, nms_size, l_out, best, tmp, stream);
+  if (e != MI_OK) return e;
+  const size_t plane = (size_t)n * h * w, blocks = (plane + 255) / 256;
+  if (blocks > 0x7fffffffULL) return MI_E_SHAPE;
+  hipLaunchKernelGGL(select_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, prev_scores, num_prev, plane,
+                     best, best, attain);
+  return mi_launch_status();
+}
+
+extern "C" int mi_akaze_orientation_from_attain(const uint8_t *attain, const float *scale_theta, int num_scales, int n,
+                                                int h, int w, const float *keypoints, int k, float *theta,
+                                                mi_stream_t stream) {
+  MI_ENTER();
+  if (!attain || !scale_theta || !keypoints || !theta) return MI_E_NULL;
+  if (num_scales <= 0 || num_scales > 8 || n <= 0 || h <= 0 || w <= 0 || k <= 0 || (long long)n * k > 0x7fffffffLL) return MI_E_SHAPE;
+  hipLaunchKernelGGL(attain_kp_kernel, dim3(ceil_div(n * k, 256)), dim3(256), 0, (hipStream_t)stream, attain, scale_theta,
+                     num_scales, n, h, w, keypoints, k, theta);
+  return mi_launch_status();
 }

@@ -203,6 +203,20 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// The fused AKAZE scale kernels divide through akaze_math.h's exact-rounding helpers, verified exhaustively for
+// kappa in [1e-3, 3] and image gradients of the uint8 range (1 + (|g| / kappa)^2 < 2^40); outside
+// [MI_AKAZE_KAPPA_MIN, MI_AKAZE_KAPPA_MAX] 1 / kappa or |g| / kappa can overflow or leave the verified range, so
+// mi_akaze_scale / mi_akaze_scale_select refuse (MI_E_PARAM); mi_akaze_diffuse (IEEE operators) takes any kappa > 0.
+static inline bool mi_akaze_kappa_ok(float kappa) { return kappa >= MI_AKAZE_KAPPA_MIN && kappa <= MI_AKAZE_KAPPA_MAX; }
+// akaze_stream.hip: the rolling-window form of one AKAZE scale (mode 0: this scale's score map; mode 1: the selection
+// across scales); mi_akaze_stream_supported says whether it applies (even width, 8-byte aligned maps, nms_size 3 / 5,
+// iterations 1..3)
+int mi_akaze_stream_supported(int h, int w, int iterations, int nms_size, const void *l_in, const void *l_out,
+                              const void *scores);
+int mi_akaze_scale_stream(const float *l_in, int n, int h, int w, int iterations, float kappa, float dt, float threshold,
+                          int nms_size, float *l_out, float *scores, int mode, const float *prev_scores, int num_prev,
+                          uint8_t *attain, mi_stream_t stream);
+
 // ---- internal launchers shared between translation units (not part of the C ABI): the entry points of
 // include/mi355x_match.h with `MiSets` in place of a single batch pointer.  mi_match_pairs uses them to put both images
 // of every pair behind one launch per stage when the batch is small (the one-pair-per-call latency path).

@@ -29,6 +29,7 @@ MI_API int mi_debug_set(int key, int value) {
     mi_hooks.corner_impl = 0; mi_hooks.corner_rows = 4; mi_hooks.corner_rows_u8_default = 1;
     mi_hooks.sinkhorn_log_partials = 0; mi_hooks.sinkhorn_split = 2; mi_hooks.sinkhorn_persist = 1;
     mi_hooks.sinkhorn_stamps = 0; mi_hooks.topk_select = 1; mi_hooks.topk_split = -1; mi_hooks.sinkhorn_schedule = -1;
+    mi_hooks.akaze_impl = 0;
     mi_hooks.corner_clk = nullptr; mi_hooks.topk_prof = nullptr;
     return MI_OK;
   }
@@ -40,12 +41,39 @@ MI_API int mi_debug_set(int key, int value) {
   if (key == 8) { mi_hooks.sinkhorn_stamps = value; return MI_OK; }
   if (key == 9) { mi_hooks.topk_select = value; return MI_OK; }
   if (key == 10) { mi_hooks.topk_split = value; return MI_OK; }
+  if (key == 12 && (value == 0 || value == 1)) { mi_hooks.akaze_impl = value; return MI_OK; }
   if (key == 11 && value >= -1 && value <= 2) { mi_hooks.sinkhorn_schedule = value; return MI_OK; }
   return MI_E_PARAM;
 }
 
 MI_API int mi_debug_bad_plan_passes(const uint32_t *pair_geom_host, int num_pairs, int *canonical, int *scheduled) {
   return mi_bad_plan_passes_host(pair_geom_host, num_pairs, canonical, scheduled);
+}
+
+// ---- the stream-schedule tuner's decision logic (csrc/sk_tuner.h) driven by a script, no GPU involved -------------
+#include "sk_tuner.h"
+MI_API int mi_debug_tuner_script(int n_ops, const int *op, const int *arg, const double *val, int *out) {
+  if (n_ops < 0 || (n_ops > 0 && (!op || !arg || !val || !out))) return MI_E_NULL;
+  mi::TunerLogic t;
+  int last_entry = -1, last_slot = -1;
+  for (int i = 0; i < n_ops; ++i) {
+    mi::TunerShape s;
+    s.batch = arg[i]; s.n = 512; s.m = 512; s.iterations = 20;
+    switch (op[i]) {
+      case 0: {                                                 // eager call of shape `arg`: schedule | slot << 8 | entry << 16
+        const int sched = t.begin(s, &last_entry, &last_slot);
+        out[i] = sched | ((last_slot & 0xff) << 8) | ((last_entry & 0xff) << 16);
+        break;
+      }
+      case 1: t.finish(arg[i] >> 8, arg[i] & 0xff, val[i]); out[i] = 0; break;      // arg = entry << 8 | slot
+      case 2: t.abandon(arg[i] >> 8, arg[i] & 0xff); out[i] = 0; break;
+      case 3: out[i] = t.current(s); break;
+      case 4: out[i] = t.for_capture(s); break;
+      case 5: out[i] = t.set(arg[i]) ? 0 : -1; break;
+      default: return MI_E_PARAM;
+    }
+  }
+  return MI_OK;
 }
 
 MI_API int mi_debug_sinkhorn_dots_form(int batch, int n, int m, int flags, int blocks_per_cu, int cus) {

@@ -89,7 +89,7 @@ int check_params(const mi_match_params *p) {
   if (p->block_size <= 0 || p->block_size % 2 == 0 || p->nms_radius < 0 || p->max_keypoints <= 0) return MI_E_PARAM;
   if (p->num_pairs <= 0 || p->num_pairs % 64 != 0 || p->num_pairs > 1024) return MI_E_PARAM;
   if (p->sinkhorn_iterations <= 0 || !(p->epsilon >= MI_DOTS_MIN_EPSILON) || p->max_matches <= 0) return MI_E_PARAM;
-  if ((p->flags & ~MI_SOLVER_MULTI_LAUNCH) != 0) return MI_E_PARAM;
+  if ((p->flags & ~(MI_SOLVER_MULTI_LAUNCH | MI_SOLVER_NO_FORK)) != 0) return MI_E_PARAM;
   return MI_OK;
 }
 

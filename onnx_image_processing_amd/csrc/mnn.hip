@@ -591,7 +591,7 @@ extern "C" int mi_core_maxima(const float *p, int batch, int n, int m, float *ro
   return mi_launch_status();
 }
 
-extern "C" int mi_abi_version(void) { return 2; }
+extern "C" int mi_abi_version(void) { return 3; }
 
 extern "C" const char *mi_error_string(int code) {
   switch (code) {

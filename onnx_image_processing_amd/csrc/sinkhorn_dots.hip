@@ -13,6 +13,7 @@
 #include "common.h"
 
 #include <mutex>
+#include "sk_tuner.h"
 #include "stream_registry.h"
 
 #include <math.h>
@@ -793,42 +794,61 @@ __global__ __launch_bounds__(512) void sk_persist_kernel(const uint16_t *__restr
 // events belong to ONE caller (device, stream) -- stream_registry.h says why -- and are created on the first
 // call with >= 64 pairs on that stream; at most SK_MAX_CALLERS callers get them, later ones run unforked.
 //
-// Which streams the two half-batches go to is SELF-TUNED per caller (round 3).  Whether two streams' kernels overlap
-// depends on how the runtime mapped them onto the device's few hardware queues, i.e. on everything the process created
-// before them: with the halves on {caller's stream, helper 0} a 448-pair call takes 0.92 ms -- unless an RCCL communicator
-// was created first, then 1.15 ms, while {helper 0, helper 1} takes 0.92 there and 1.02 without the communicator; the
-// unsplit call takes 1.00 either way.  So the first calls of a caller try the three schedules in turn, each bracketed by
-// two timing events on the caller's stream; later calls collect the elapsed times WITHOUT waiting (hipEventQuery) and
-// from then on every call uses the fastest.  Nothing is tried inside a stream capture (a capture before the decision
-// gets schedule 0), the schedules compute the same duals bit for bit, and the decision only ever changes speed.
+// Which streams the two half-batches go to is SELF-TUNED per caller and per shape (round 3; hardened in round 4: the
+// decision logic and its rules live in sk_tuner.h, HIP-free and unit-tested with injected timings).  Whether two
+// streams' kernels overlap depends on how the runtime mapped them onto the device's few hardware queues, i.e. on
+// everything the process created before them: with the halves on {caller's stream, helper 0} a 448-pair call takes
+// 0.92 ms -- unless an RCCL communicator was created first, then 1.15 ms, while {helper 0, helper 1} takes 0.92 there and
+// 1.02 without the communicator; the unsplit call takes 1.00 either way.  So the first calls of a shape on a caller
+// stream try the three schedules in turn, each bracketed by two timing events on the caller's stream; later calls
+// collect the elapsed times WITHOUT waiting (hipEventQuery) and from then on the shape uses the fastest.  What this
+// adds to the caller's stream: two hipEventRecord per trial call (SK_TRIALS calls per shape and window).  Inside a
+// stream capture nothing is tried, queried or recorded: the capture gets the decision in force, or the UNSPLIT schedule
+// when there is none (no cross-stream fork inside a captured graph unless it was measured -- or pinned -- to pay).  The
+// timing calls are made in relaxed capture mode (hipThreadExchangeStreamCaptureMode), so a capture in global mode on
+// ANOTHER thread of the process does not turn them into capture errors.  MI_SOLVER_NO_FORK rules the fork out
+// altogether; mi_sinkhorn_dots_set_schedule pins a schedule, mi_sinkhorn_dots_schedule reports the one in force.
 constexpr int SK_MAX_PARTS = 4;
 constexpr size_t SK_MAX_CALLERS = 64;
-constexpr int SK_SCHEDULES = 3;          // 0: halves on {caller, helper 0}; 1: halves on {helper 0, helper 1}; 2: unsplit
-constexpr int SK_TRIALS = 2 * SK_SCHEDULES;
+using mi::SK_SCHEDULES;
+using mi::SK_SHAPES;
+using mi::SK_TRIALS;
+// hipEventRecord / hipEventQuery / stream and event creation under another thread's global-mode capture
+struct RelaxedCaptureMode {
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  bool swapped;
+  RelaxedCaptureMode() {
+    swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+    if (!swapped) (void)hipGetLastError();
+  }
+  ~RelaxedCaptureMode() {
+    if (swapped && hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) (void)hipGetLastError();
+  }
+  RelaxedCaptureMode(const RelaxedCaptureMode &) = delete;
+  RelaxedCaptureMode &operator=(const RelaxedCaptureMode &) = delete;
+};
 struct ForkJoin {
   hipStream_t side[SK_MAX_PARTS - 1] = {};
   hipEvent_t fork = nullptr, join[SK_MAX_PARTS - 1] = {};
   bool ok = false;
   // self-tuning state (guarded by mu; calls on one stream are normally serial anyway)
   std::mutex mu;
-  hipEvent_t t0[SK_TRIALS] = {}, t1[SK_TRIALS] = {};
-  bool pending[SK_TRIALS] = {};
-  double work[SK_TRIALS] = {};           // matrix elements x iterations of the trial call: times are compared per unit
-  int started = 0, finished = 0, decided = -1;
-  double best[SK_SCHEDULES] = {1e300, 1e300, 1e300};
+  mi::TunerLogic logic;
+  hipEvent_t t0[SK_SHAPES][SK_TRIALS] = {}, t1[SK_SHAPES][SK_TRIALS] = {};   // created when an entry's first trial begins
+  bool closed[SK_SHAPES][SK_TRIALS] = {};                                     // t1 recorded: waiting to be harvested
   ForkJoin() {
+    RelaxedCaptureMode relaxed;
     ok = hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < SK_MAX_PARTS - 1; ++i)
       ok = ok && hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking) == hipSuccess &&
            hipEventCreateWithFlags(&join[i], hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < SK_TRIALS; ++i)
-      ok = ok && hipEventCreate(&t0[i]) == hipSuccess && hipEventCreate(&t1[i]) == hipSuccess;
   }
   ~ForkJoin() {
-    for (int i = 0; i < SK_TRIALS; ++i) {
-      if (t0[i]) (void)hipEventDestroy(t0[i]);
-      if (t1[i]) (void)hipEventDestroy(t1[i]);
-    }
+    for (int e = 0; e < SK_SHAPES; ++e)
+      for (int i = 0; i < SK_TRIALS; ++i) {
+        if (t0[e][i]) (void)hipEventDestroy(t0[e][i]);
+        if (t1[e][i]) (void)hipEventDestroy(t1[e][i]);
+      }
     for (int i = 0; i < SK_MAX_PARTS - 1; ++i) {
       if (join[i]) (void)hipEventDestroy(join[i]);
       if (side[i]) (void)hipStreamDestroy(side[i]);
@@ -837,50 +857,74 @@ struct ForkJoin {
   }
   ForkJoin(const ForkJoin &) = delete;
   ForkJoin &operator=(const ForkJoin &) = delete;
-  // The schedule of this call and, while the caller is still being tuned, the trial slot whose events bracket it (-1:
-  // none).  Never blocks: finished trials are harvested with hipEventQuery.
-  int pick(hipStream_t s, double call_work, int *trial) {
-    *trial = -1;
-    std::lock_guard<std::mutex> lock(mu);
-    // inside a stream capture nothing is queried or recorded: the decision taken so far (or schedule 0) is captured
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return decided >= 0 ? decided : 0; }
-    if (cap != hipStreamCaptureStatusNone) return decided >= 0 ? decided : 0;
-    for (int i = 0; i < started; ++i) {
-      if (!pending[i]) continue;
-      if (hipEventQuery(t1[i]) != hipSuccess) { (void)hipGetLastError(); continue; }
-      float ms = 0.0f;
-      if (hipEventElapsedTime(&ms, t0[i], t1[i]) == hipSuccess && ms > 0.0f && work[i] > 0.0) {
-        const double per_unit = (double)ms / work[i];
-        if (per_unit < best[i % SK_SCHEDULES]) best[i % SK_SCHEDULES] = per_unit;
-      } else {
-        (void)hipGetLastError();
+  // finished trials -> the decision logic; never waits (mu held, relaxed capture mode)
+  void harvest() {
+    for (int e = 0; e < SK_SHAPES; ++e)
+      for (int i = 0; i < SK_TRIALS; ++i) {
+        if (!closed[e][i]) continue;
+        if (hipEventQuery(t1[e][i]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        closed[e][i] = false;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, t0[e][i], t1[e][i]) == hipSuccess && ms > 0.0f) {
+          logic.finish(e, i, (double)ms);
+        } else {
+          (void)hipGetLastError();
+          logic.abandon(e, i);
+        }
       }
-      pending[i] = false;
-      ++finished;
-    }
-    if (decided < 0 && finished == SK_TRIALS) {
-      decided = 0;
-      for (int c = 1; c < SK_SCHEDULES; ++c)
-        if (best[c] < best[decided]) decided = c;
-    }
-    if (decided >= 0) return decided;
-    if (started == SK_TRIALS) return 0;
-    const int slot = started;
-    if (hipEventRecord(t0[slot], s) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    work[slot] = call_work;
-    ++started;
-    *trial = slot;
-    return slot % SK_SCHEDULES;
   }
-  void close_trial(int slot, hipStream_t s) {
-    std::lock_guard<std::mutex> lock(mu);
-    if (hipEventRecord(t1[slot], s) == hipSuccess) {
-      pending[slot] = true;
-    } else {                                                  // the slot counts as done (nothing learnt from it)
-      (void)hipGetLastError();
-      ++finished;
+  bool events_for(int e) {
+    for (int i = 0; i < SK_TRIALS; ++i) {
+      if (!t0[e][i] && hipEventCreate(&t0[e][i]) != hipSuccess) { t0[e][i] = nullptr; (void)hipGetLastError(); return false; }
+      if (!t1[e][i] && hipEventCreate(&t1[e][i]) != hipSuccess) { t1[e][i] = nullptr; (void)hipGetLastError(); return false; }
     }
+    return true;
+  }
+  // The schedule of this call and, while its shape is being tuned, the trial (*entry, *slot) whose events bracket it
+  // (-1: none).  Never blocks.  Every trial handed out must be closed (close_trial) or abandoned (abandon_trial).
+  int pick(hipStream_t s, const mi::TunerShape &shape, int *entry, int *slot) {
+    *entry = *slot = -1;
+    std::lock_guard<std::mutex> lock(mu);
+    // inside a stream capture nothing is queried or recorded: the decision in force, else the unsplit schedule
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return logic.for_capture(shape); }
+    if (cap != hipStreamCaptureStatusNone) return logic.for_capture(shape);
+    RelaxedCaptureMode relaxed;
+    harvest();
+    const int sched = logic.begin(shape, entry, slot);
+    if (*slot >= 0) {
+      closed[*entry][*slot] = false;
+      if (!events_for(*entry) || hipEventRecord(t0[*entry][*slot], s) != hipSuccess) {
+        (void)hipGetLastError();
+        logic.abandon(*entry, *slot);                          // nothing learnt from this slot; the call still runs `sched`
+        *entry = *slot = -1;
+      }
+    }
+    return sched;
+  }
+  void close_trial(int entry, int slot, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(mu);
+    RelaxedCaptureMode relaxed;
+    if (hipEventRecord(t1[entry][slot], s) == hipSuccess) {
+      closed[entry][slot] = true;
+    } else {                                                   // the slot ends without a sample
+      (void)hipGetLastError();
+      logic.abandon(entry, slot);
+    }
+  }
+  void abandon_trial(int entry, int slot) {                    // an error between the trial's two events
+    std::lock_guard<std::mutex> lock(mu);
+    logic.abandon(entry, slot);
+  }
+  int current(const mi::TunerShape &shape) {
+    std::lock_guard<std::mutex> lock(mu);
+    RelaxedCaptureMode relaxed;
+    harvest();
+    return logic.current(shape);
+  }
+  bool set(int schedule) {
+    std::lock_guard<std::mutex> lock(mu);
+    return logic.set(schedule);
   }
 };
 using ForkJoinKey = std::pair<int, hipStream_t>;   // (device, caller stream)
@@ -902,7 +946,7 @@ ForkJoin *fork_join_for(hipStream_t s) {
 template <int E8, int RW, int NW, bool FAST>
 int launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int batch, int n, int m, int pitch,
                  ZParams zp, int iterations, float *u, float *v, float *part, float *wp, float *tp, float *aux,
-                 float log_m, float log_n, unsigned *statusw, hipStream_t s) {
+                 float log_m, float log_n, unsigned *statusw, bool no_fork, hipStream_t s) {
   const int nb = ceil_div(n, NW * RW);
   constexpr int CP = 512 * E8;    // padded column count of wp / tp
   hipLaunchKernelGGL(sk_dots_init_kernel, dim3(CP / 256, batch), dim3(256), 0, s, ci, m, CP, zp.neg_inv_eps, wp, tp,
@@ -911,18 +955,20 @@ int launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int ba
   // the GPU drains and refills (about 5 us per iteration).  With enough pairs the batch is cut into parts
   // on separate streams: while one part is in its column kernel / launch gap another part's row kernel
   // keeps the CUs busy.  The parts are independent problems, so results do not change.
-  MI_CHECK_LAUNCH();
+  MI_CHECK_LAUNCH();                                           // (before any trial is handed out)
   int parts = MI_HOOK(sinkhorn_split, 2);
   if (parts > SK_MAX_PARTS) parts = SK_MAX_PARTS;
-  if (parts < 1 || batch < 32 * parts) parts = 1;
+  if (parts < 1 || batch < 32 * parts || no_fork) parts = 1;   // MI_SOLVER_NO_FORK: everything on the caller's stream
   ForkJoin *fj = parts > 1 ? fork_join_for(s) : nullptr;
   if (!fj) parts = 1;
   // first_side: the first part that runs on a helper stream (1: part 0 stays on the caller's stream; 0: every part on a
   // helper).  With the default two parts the caller's schedule is self-tuned (ForkJoin above).
-  int first_side = 1, trial = -1;
+  int first_side = 1, trial_entry = -1, trial = -1;
   if (parts == 2) {
     const int fixed = MI_HOOK(sinkhorn_schedule, -1);
-    const int sched = fixed >= 0 ? fixed : fj->pick(s, (double)batch * n * m * iterations, &trial);
+    mi::TunerShape shape;
+    shape.batch = batch; shape.n = n; shape.m = m; shape.iterations = iterations;
+    const int sched = fixed >= 0 ? fixed : fj->pick(s, shape, &trial_entry, &trial);
     if (sched == 1) first_side = 0;
     if (sched == 2) parts = 1;
   }
@@ -957,10 +1003,17 @@ int launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int ba
   for (int q = first_side; q < parts; ++q) {
     hipError_t e = hipEventRecord(fj->join[q - first_side], fj->side[q - first_side]);
     if (e == hipSuccess) e = hipStreamWaitEvent(s, fj->join[q - first_side], 0);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) {
+      if (trial >= 0) fj->abandon_trial(trial_entry, trial);   // the slot must end, or its window never closes
+      return (int)e;
+    }
   }
-  if (trial >= 0) fj->close_trial(trial, s);
-  return mi_launch_status();
+  const int launched = mi_launch_status();
+  if (trial >= 0) {
+    if (launched == MI_OK) fj->close_trial(trial_entry, trial, s);
+    else fj->abandon_trial(trial_entry, trial);
+  }
+  return launched;
 }
 
 int dots_rows_per_band(int m) { return m <= 512 ? 32 : (m <= 1024 ? 16 : 0); }   // 8 rows per wave measured slower
@@ -1044,6 +1097,26 @@ extern "C" int mi_release_stream_resources(mi_stream_t stream) {
   return MI_OK;
 }
 
+// The stream schedule of mi_sinkhorn_dots for >= 64 pairs, see include/mi355x_match.h
+extern "C" int mi_sinkhorn_dots_schedule(mi_stream_t stream, int batch, int n, int m, int iterations) {
+  const int fixed = MI_HOOK(sinkhorn_schedule, -1);
+  if (fixed >= 0) return fixed;
+  int device = -1;
+  if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); return MI_SCHEDULE_UNDECIDED; }
+  ForkJoin *fj = fork_join_registry().find(ForkJoinKey(device, (hipStream_t)stream));
+  if (!fj) return MI_SCHEDULE_UNDECIDED;
+  mi::TunerShape shape;
+  shape.batch = batch; shape.n = n; shape.m = m; shape.iterations = iterations;
+  return fj->current(shape);
+}
+
+extern "C" int mi_sinkhorn_dots_set_schedule(mi_stream_t stream, int schedule) {
+  if (schedule < -1 || schedule >= SK_SCHEDULES) return MI_E_PARAM;
+  ForkJoin *fj = fork_join_for((hipStream_t)stream);          // creates the caller's helper resources if need be
+  if (!fj) return MI_E_CAPACITY;
+  return fj->set(schedule) ? MI_OK : MI_E_PARAM;
+}
+
 size_t mi_sinkhorn_dots_handoff_region(void *workspace, int batch, int n, int m, int flags, void **region) {
   if (!use_single_launch(batch, n, m, flags)) return 0;
   *region = reinterpret_cast<char *>(workspace) + dots_base_bytes(batch, n, m);
@@ -1067,7 +1140,7 @@ int mi_sinkhorn_dots_impl(const uint16_t *dots, const float *row_info, const flo
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
   if (pitch < m || pitch % 8 != 0 || ((uintptr_t)dots % 16) != 0 || ((uintptr_t)workspace % 16) != 0) return MI_E_ALIGN;
   if (iterations <= 0 || !(epsilon >= MI_DOTS_MIN_EPSILON)) return MI_E_PARAM;   // below it: the fp32-Z form (clamped cost)
-  if ((flags & ~MI_SOLVER_MULTI_LAUNCH) != 0) return MI_E_PARAM;
+  if ((flags & ~(MI_SOLVER_MULTI_LAUNCH | MI_SOLVER_NO_FORK)) != 0) return MI_E_PARAM;
   const size_t need = mi_sinkhorn_dots_workspace_bytes(batch, n, m);
   if (need == 0) return MI_E_PARAM;                 // m > 1024: use the fp32 form
   if (workspace_bytes < need) return MI_E_CAPACITY;
@@ -1113,7 +1186,7 @@ int mi_sinkhorn_dots_impl(const uint16_t *dots, const float *row_info, const flo
                          zp, u, v, p);
     return mi_launch_status();
   }
-#define SKD_LAUNCH(E8, RW, FAST) launch_dots<E8, RW, 8, FAST>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, wp, tp, aux, log_m, log_n, statusw, s)
+#define SKD_LAUNCH(E8, RW, FAST) launch_dots<E8, RW, 8, FAST>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, wp, tp, aux, log_m, log_n, statusw, (flags & MI_SOLVER_NO_FORK) != 0, s)
   int e;
   if (m <= 512) e = fast ? SKD_LAUNCH(1, 4, true) : SKD_LAUNCH(1, 4, false);
   else e = fast ? SKD_LAUNCH(2, 2, true) : SKD_LAUNCH(2, 2, false);

@@ -36,6 +36,13 @@ class KeyedRegistry {
     return raw;
   }
 
+  // The resource of `key` if it exists (never creates).
+  Resource *find(const Key &key) {
+    std::lock_guard<std::mutex> lock(mu_);
+    auto it = items_.find(key);
+    return it == items_.end() ? nullptr : it->second.get();
+  }
+
   // Drop the resource of `key` (its destructor releases streams / events).  Returns whether one existed.
   bool release(const Key &key) {
     std::lock_guard<std::mutex> lock(mu_);

@@ -39,17 +39,34 @@ def _images(image: torch.Tensor, what: str, keep_u8: bool = False) -> torch.Tens
 TILE_COUNTER_BYTES = 16640          # include/mi355x_match.h MI_TILE_COUNTER_BYTES
 
 # Sinkhorn solver flags handed to mi_sinkhorn_dots / mi_match_pairs (include/mi355x_match.h, "co-residency"):
-# 0 = MI_SOLVER_DEFAULT; MI_SOLVER_MULTI_LAUNCH for a process that shares its GPU with long-running foreign kernels.
+# 0 = MI_SOLVER_DEFAULT; MI_SOLVER_MULTI_LAUNCH for a process that shares its GPU with long-running foreign kernels;
+# MI_SOLVER_NO_FORK keeps the >= 64-pair Sinkhorn on the caller's stream (no helper streams, no events, no tuning).
 # A preference of this Python layer (the C library has no process-wide switch); results are identical either way.
-MI_SOLVER_DEFAULT, MI_SOLVER_MULTI_LAUNCH = 0, 1
+MI_SOLVER_DEFAULT, MI_SOLVER_MULTI_LAUNCH, MI_SOLVER_NO_FORK = 0, 1, 2
 _solver_flags = MI_SOLVER_DEFAULT
 
 
 def set_solver_flags(flags: int) -> None:
     global _solver_flags
-    if flags not in (MI_SOLVER_DEFAULT, MI_SOLVER_MULTI_LAUNCH):
-        raise ValueError(f"solver flags must be MI_SOLVER_DEFAULT (0) or MI_SOLVER_MULTI_LAUNCH (1), got {flags}")
+    if not isinstance(flags, int) or flags & ~(MI_SOLVER_MULTI_LAUNCH | MI_SOLVER_NO_FORK):
+        raise ValueError("solver flags must be MI_SOLVER_DEFAULT (0) or an OR of MI_SOLVER_MULTI_LAUNCH (1) and "
+                         f"MI_SOLVER_NO_FORK (2), got {flags}")
     _solver_flags = int(flags)
+
+
+MI_SCHEDULE_UNDECIDED, MI_SCHEDULE_CALLER_HELPER, MI_SCHEDULE_TWO_HELPERS, MI_SCHEDULE_UNSPLIT = -1, 0, 1, 2
+
+
+def sinkhorn_schedule(batch: int, n: int, m: int, iterations: int) -> int:
+    """The stream schedule in force for mi_sinkhorn_dots calls of this shape on torch's current stream
+    (`mi_sinkhorn_dots_schedule`): MI_SCHEDULE_UNDECIDED until the tuner has decided or a schedule is pinned."""
+    return int(N.load().mi_sinkhorn_dots_schedule(N.stream_ptr(), int(batch), int(n), int(m), int(iterations)))
+
+
+def set_sinkhorn_schedule(schedule: int) -> None:
+    """Pin a stream schedule for torch's current stream, or MI_SCHEDULE_UNDECIDED to start tuning over
+    (`mi_sinkhorn_dots_set_schedule`)."""
+    N.check(N.load().mi_sinkhorn_dots_set_schedule(N.stream_ptr(), int(schedule)), "mi_sinkhorn_dots_set_schedule")
 
 
 def corner_response(image: torch.Tensor, block_size: int) -> torch.Tensor:
@@ -461,6 +478,59 @@ def akaze_scale(image: torch.Tensor, iterations: int, kappa: float, dt: float, t
            int(nms_size), out.data_ptr(), N.dev(scores, F32, "scores"), tmp.data_ptr() if tmp is not None else None,
            N.stream_ptr())
     return out, scores
+
+
+AKAZE_KAPPA_MIN, AKAZE_KAPPA_MAX = 1e-3, 1e6          # include/mi355x_match.h MI_AKAZE_KAPPA_MIN / _MAX
+
+
+def akaze_kappa_fused(kappa: float) -> bool:
+    """kappa inside the range the fused scale kernels accept (their exactly rounded division helpers are verified for
+    it); outside, the modules run the per-step kernels (IEEE operators)."""
+    return AKAZE_KAPPA_MIN <= float(kappa) <= AKAZE_KAPPA_MAX
+
+
+def akaze_attain(scale_scores: torch.Tensor, scores: torch.Tensor) -> torch.Tensor:
+    """(S,N,1,H,W) per-scale maps + their maximum -> attain (N,1,H,W) uint8, bit s = scale s reaches it (the general-
+    parameter route of AKAZE.detect_select; elementwise torch ops on the device)."""
+    bits = torch.zeros(scores.shape, dtype=torch.int32, device=scores.device)
+    for s in range(scale_scores.shape[0]):
+        bits |= (scale_scores[s] == scores).to(torch.int32) << s
+    return bits.to(U8)
+
+
+def akaze_scale_select(image: torch.Tensor, iterations: int, kappa: float, dt: float, threshold: float, nms_size: int,
+                       prev_scores: torch.Tensor | None):
+    """The last AKAZE scale with the selection across scales folded in (`mi_akaze_scale_select`): (diffused image,
+    best = max over prev_scores (S-1,N,1,H,W) and this scale's score map, attain (N,1,H,W) uint8: bit s = scale s
+    reaches best)."""
+    img = _images(image, "image")
+    n, _, h, w = img.shape
+    num_prev = 0 if prev_scores is None else int(prev_scores.shape[0])
+    if num_prev > 7:
+        raise RuntimeError(f"at most 8 scales, got {num_prev + 1}")
+    if num_prev and tuple(prev_scores.shape[1:]) != (n, 1, h, w):
+        raise RuntimeError(f"prev_scores must be (S-1,{n},1,{h},{w}), got {tuple(prev_scores.shape)}")
+    out = torch.empty_like(img)
+    best = torch.empty_like(img)
+    attain = torch.empty((n, 1, h, w), dtype=U8, device=img.device)
+    fused = bool(N.load().mi_akaze_scale_fused(int(iterations), int(nms_size)))
+    tmp = None if fused or iterations <= 1 else torch.empty_like(img)
+    N.call("mi_akaze_scale_select", N.dev(img, F32, "image"), n, h, w, int(iterations), float(kappa), float(dt),
+           float(threshold), int(nms_size), out.data_ptr(),
+           N.dev(prev_scores, F32, "prev_scores") if num_prev else None, num_prev, best.data_ptr(), attain.data_ptr(),
+           tmp.data_ptr() if tmp is not None else None, N.stream_ptr())
+    return out, best, attain
+
+
+def akaze_orientation_from_attain(attain: torch.Tensor, scale_theta: torch.Tensor, keypoints: torch.Tensor) -> torch.Tensor:
+    n, _, h, w = attain.shape
+    s = int(scale_theta.shape[0])
+    kp = keypoints.float().contiguous()
+    k = kp.shape[1]
+    theta = torch.empty((n, k), dtype=F32, device=attain.device)
+    N.call("mi_akaze_orientation_from_attain", N.dev(attain, U8, "attain"), N.dev(scale_theta, F32, "scale_theta"), s, n,
+           h, w, N.dev(kp, F32, "keypoints"), k, theta.data_ptr(), N.stream_ptr())
+    return theta
 
 
 def akaze_hessian_scores(image: torch.Tensor, threshold: float, nms_size: int,

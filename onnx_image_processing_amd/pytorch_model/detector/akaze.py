@@ -85,8 +85,9 @@ class AKAZE(nn.Module):
     mean of the orientation maps of the scales attaining that max.
 
     `detect(image)` (extension) returns (scores, scale_scores (S,N,1,H,W), scale_images) without
-    the S dense orientation maps, and `orientation_at_keypoints` evaluates the same selection at
-    keypoints only -- what the matcher needs."""
+    the S dense orientation maps, `detect_select(image)` the same scores with the per-pixel set of
+    scales that reach them instead of the stack, and `orientation_at_keypoints` evaluates the same
+    selection at keypoints only -- what the matcher needs."""
 
     def __init__(self, num_scales: int = 3, diffusion_iterations: int = 3, kappa: float = 0.05,
                  threshold: float = 0.001, nms_size: int = 5, orientation_patch_size: int = 15,
@@ -98,6 +99,17 @@ class AKAZE(nn.Module):
         self.detector = HessianDetector(threshold=threshold, nms_size=nms_size)
         self.orientation_estimator = OrientationEstimator(patch_size=orientation_patch_size, sigma=orientation_sigma)
 
+    def _scale(self, i: int, cur: torch.Tensor, scores_out: torch.Tensor):
+        layer = self.diffusion_layers[i]
+        if layer.num_iterations > 0 and ops.akaze_kappa_fused(layer.kappa):
+            # one launch per scale: diffusion steps + Hessian + NMS (streaming rolling window / LDS tile)
+            cur, _ = ops.akaze_scale(cur, layer.num_iterations, layer.kappa, layer.dt, self.detector.threshold,
+                                     self.detector.nms_size, scores_out=scores_out)
+        else:                                            # kappa outside the fused kernels' verified range: IEEE per-step kernels
+            cur = ops.akaze_diffuse(cur, layer.num_iterations, layer.kappa, layer.dt)
+            ops.akaze_hessian_scores(cur, self.detector.threshold, self.detector.nms_size, out=scores_out)
+        return cur
+
     @torch.no_grad()
     def detect(self, image: torch.Tensor):
         img = ops._images(image, "image")
@@ -106,19 +118,39 @@ class AKAZE(nn.Module):
         scale_images = []
         cur = img
         for i in range(self.num_scales):
-            layer = self.diffusion_layers[i]
-            if layer.num_iterations > 0:                 # one launch per scale: diffusion steps + Hessian + NMS on one tile
-                cur, _ = ops.akaze_scale(cur, layer.num_iterations, layer.kappa, layer.dt, self.detector.threshold,
-                                         self.detector.nms_size, scores_out=scale_scores[i])
-            else:
-                ops.akaze_hessian_scores(cur, self.detector.threshold, self.detector.nms_size, out=scale_scores[i])
+            cur = self._scale(i, cur, scale_scores[i])
             scale_images.append(cur)
         scores, _ = ops.akaze_combine(scale_scores, None)
         return scores, scale_scores, scale_images
 
     @torch.no_grad()
+    def detect_select(self, image: torch.Tensor):
+        """detect() with the selection across scales folded into the last scale's launch (extension): returns
+        (scores, attain (N,1,H,W) uint8 -- bit s: scale s reaches the maximum --, scale_images).  Same scores as
+        detect(); the stacked per-scale maps' last plane and the separate max-over-scales pass are never written."""
+        img = ops._images(image, "image")
+        n, _, h, w = img.shape
+        last = self.diffusion_layers[-1]
+        if self.num_scales > 8 or last.num_iterations <= 0 or not ops.akaze_kappa_fused(last.kappa):
+            scores, scale_scores, scale_images = self.detect(image)
+            return scores, ops.akaze_attain(scale_scores, scores), scale_images
+        prev = torch.empty((self.num_scales - 1, n, 1, h, w), dtype=torch.float32, device=img.device)
+        scale_images = []
+        cur = img
+        for i in range(self.num_scales - 1):
+            cur = self._scale(i, cur, prev[i])
+            scale_images.append(cur)
+        cur, scores, attain = ops.akaze_scale_select(cur, last.num_iterations, last.kappa, last.dt, self.detector.threshold,
+                                                     self.detector.nms_size, prev if self.num_scales > 1 else None)
+        scale_images.append(cur)
+        return scores, attain, scale_images
+
+    @torch.no_grad()
     def orientation_at_keypoints(self, scale_scores: torch.Tensor, scale_images, keypoints: torch.Tensor):
+        """scale_scores: the stacked per-scale maps of detect() (float32) or the attain map of detect_select() (uint8)."""
         theta = torch.stack([self.orientation_estimator.at_keypoints(im, keypoints) for im in scale_images])
+        if scale_scores.dtype == torch.uint8:
+            return ops.akaze_orientation_from_attain(scale_scores, theta.contiguous(), keypoints)
         return ops.akaze_orientation_at_keypoints(scale_scores, theta.contiguous(), keypoints)
 
     @torch.no_grad()

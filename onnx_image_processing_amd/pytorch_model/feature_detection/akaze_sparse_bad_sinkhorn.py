@@ -41,7 +41,7 @@ class AKAZESparseBADSinkhornMatcher(nn.Module):
 
     def _detect_describe(self, image):
         packed = self.descriptor.mode == N.MI_BAD_HARD and self.matcher.distance_type == "l2"
-        scores, scale_scores, scale_images = self.detector.detect(image)
+        scores, scale_scores, scale_images = self.detector.detect_select(image)
         kp, _ = detect_keypoints(scores.squeeze(1), self.nms_radius, self.max_keypoints, self.score_threshold,
                                  self.border_margin)
         theta = self.detector.orientation_at_keypoints(scale_scores, scale_images, kp)

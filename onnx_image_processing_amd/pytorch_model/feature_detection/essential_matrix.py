@@ -108,7 +108,7 @@ class AKAZESparseBADSinkhornWithEssentialMatrix(_EssentialHead):
                         border_margin, top_k, n_iter, n_iter_manifold)
 
     def _detect(self, image):
-        scores, scale_scores, scale_images = self.detector.detect(image)
+        scores, scale_scores, scale_images = self.detector.detect_select(image)
         kp, ksc = detect_keypoints(scores.squeeze(1), self.nms_radius, self.max_keypoints, self.score_threshold,
                                    self.border_margin)
         return kp, ksc, self.detector.orientation_at_keypoints(scale_scores, scale_images, kp)

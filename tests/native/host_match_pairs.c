@@ -55,8 +55,8 @@ int main(int argc, char **argv) {
     fprintf(stderr, "missing symbol\n");
     return 1;
   }
-  if (abi_version() != 2) {
-    fprintf(stderr, "ABI version %d, expected 2\n", abi_version());
+  if (abi_version() != 3) {
+    fprintf(stderr, "ABI version %d, expected 3\n", abi_version());
     return 1;
   }
 

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     assert len(names) >= 18
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/mi355x_match.h but not exported"
-    assert lib.mi_abi_version() == 2
+    assert lib.mi_abi_version() == 3
     lib.mi_error_string.restype = ctypes.c_char_p
     assert lib.mi_error_string(0) == b"ok" and b"NULL" in lib.mi_error_string(-1)
 
@@ -42,10 +42,10 @@ def test_binding_covers_the_header(lib_path):
     assert sorted(_native.SIGNATURES) == header_functions()
     assert sorted(_native.DEBUG_SIGNATURES) == header_functions(DEBUG_HEADER) == [
         "mi_debug_akaze_math_check", "mi_debug_bad_plan_passes", "mi_debug_clock_probe", "mi_debug_set",
-        "mi_debug_sinkhorn_dots_form", "mi_debug_topk_stamps"]
+        "mi_debug_sinkhorn_dots_form", "mi_debug_topk_stamps", "mi_debug_tuner_script"]
     _native.load()
     with _native.debug_library() as dbg:                     # the debug build exports both headers
-        assert dbg.mi_abi_version() == 2
+        assert dbg.mi_abi_version() == 3
 
 
 def _exported(path):
@@ -87,7 +87,7 @@ def test_sinkhorn_form_decision_is_a_host_check(lib_path):
         assert dbg.mi_debug_sinkhorn_dots_form(1, 512, 512, 0, 4, 256) == 1
     lib = _native.load()
     ptr = ctypes.cast(ctypes.create_string_buffer(64), ctypes.c_void_p)
-    assert lib.mi_sinkhorn_dots(ptr, ptr, ptr, 1, 8, 8, 8, 0.05, 1.0, 1.0, 5, ptr, ptr, None, ptr, 1 << 20, 2, None) == -3   # unknown flag
+    assert lib.mi_sinkhorn_dots(ptr, ptr, ptr, 1, 8, 8, 8, 0.05, 1.0, 1.0, 5, ptr, ptr, None, ptr, 1 << 20, 4, None) == -3   # unknown flag
     base = ctypes.create_string_buffer(1 << 16)
     addr = ctypes.addressof(base)
     assert lib.mi_sinkhorn_dots_status_word(None, 1, 8, 8) is None
@@ -290,7 +290,7 @@ def test_match_pairs_host_side_checks(lib_path):
     assert 64 * 4_000_000 < big < 64 * 6_000_000
     assert prm.flags == 0
     for field, bad in (("max_keypoints", 2000), ("num_pairs", 100), ("block_size", 4), ("sinkhorn_iterations", 0),
-                       ("epsilon", 0.0), ("max_matches", 0), ("flags", 2)):
+                       ("epsilon", 0.0), ("max_matches", 0), ("flags", 4)):
         good = getattr(prm, field)
         setattr(prm, field, bad)
         assert lib.mi_match_pairs_workspace_bytes(1, 480, 640, ctypes.byref(prm)) == 0, field
@@ -314,6 +314,82 @@ def test_stream_registry_native_unit(tmp_path):
         subprocess.run(base, check=True, capture_output=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "stream_registry ok" in r.stdout, r.stdout + r.stderr
+
+
+def _tuner(script):
+    """Run [(op, arg, val), ...] through mi_debug_tuner_script (csrc/sk_tuner.h on a fresh state); returns the outputs."""
+    from onnx_image_processing_amd import _native as N
+    n = len(script)
+    op = (ctypes.c_int * n)(*[o for o, _, _ in script])
+    arg = (ctypes.c_int * n)(*[a for _, a, _ in script])
+    val = (ctypes.c_double * n)(*[float(v) for _, _, v in script])
+    out = (ctypes.c_int * n)()
+    with N.debug_library() as lib:
+        assert lib.mi_debug_tuner_script(n, op, arg, val, out) == 0
+    return list(out)
+
+
+def _decode(x):
+    sched, slot, entry = x & 0xff, (x >> 8) & 0xff, (x >> 16) & 0xff
+    return sched, (None if slot == 0xff else slot), (None if entry == 0xff else entry)
+
+
+def test_stream_schedule_tuner_decision_logic(lib_path):
+    """The decision logic of mi_sinkhorn_dots' stream-schedule tuner with INJECTED timings (no GPU): round-robin trials,
+    minimum per schedule (one noisy sample does not pin a slow schedule), a trial abandoned between its two events still
+    lets the window close (round 3's review: `finished` could never reach the trial count), trials of different shapes
+    are never compared, a capture before the decision gets the unsplit schedule, pin / unpin, expiry."""
+    BEGIN, FINISH, ABANDON, CURRENT, CAPTURE, SET = range(6)
+    # nine eager calls of one shape: schedules 0 1 2 0 1 2 0 1 2, slots 0..8, undecided meanwhile
+    out = _tuner([(CAPTURE, 448, 0)] + [(BEGIN, 448, 0)] * 9 + [(CURRENT, 448, 0), (BEGIN, 448, 0), (CAPTURE, 448, 0)])
+    assert out[0] == 2                                                     # capture while undecided: unsplit
+    assert [_decode(x) for x in out[1:10]] == [(i % 3, i, 0) for i in range(9)]
+    assert out[10] == -1 and _decode(out[11]) == (0, None, None) and out[12] == 2   # all issued, none harvested yet
+    # timings: schedule 1 is the fastest; one of its samples is hit by a noisy neighbour (10x) -- the minimum decides
+    times = {0: [1.00, 1.01, 0.99], 1: [0.90, 9.0, 0.91], 2: [1.10, 1.12, 1.11]}
+    fin = [(FINISH, (0 << 8) | i, times[i % 3][i // 3]) for i in range(9)]
+    out = _tuner([(BEGIN, 448, 0)] * 9 + fin + [(CURRENT, 448, 0), (BEGIN, 448, 0), (CAPTURE, 448, 0), (CURRENT, 64, 0), (CAPTURE, 64, 0)])
+    assert out[18] == 1 and _decode(out[19]) == (1, None, None) and out[20] == 1
+    assert out[21] == -1 and out[22] == 2                                  # another shape: nothing decided, unsplit capture
+    # a failed join before close_trial: that slot is abandoned, the window still closes on the other eight
+    ops = [(BEGIN, 448, 0)] * 9 + [(ABANDON, 4, 0)] + [f for f in fin if f[1] != 4] + [(CURRENT, 448, 0)]
+    assert _tuner(ops)[-1] == 1
+    # every trial abandoned (events could not be recorded): the window closes on the eager default, not "never"
+    assert _tuner([(BEGIN, 448, 0)] * 9 + [(ABANDON, i, 0) for i in range(9)] + [(CURRENT, 448, 0)])[-1] == 0
+    # started == trials with fewer finished: undecided, eager calls run schedule 0, and late results still decide
+    out = _tuner([(BEGIN, 448, 0)] * 9 + fin[:5] + [(CURRENT, 448, 0), (BEGIN, 448, 0)] + fin[5:] + [(CURRENT, 448, 0)])
+    assert out[14] == -1 and _decode(out[15]) == (0, None, None) and out[-1] == 1
+    # two shapes interleaved: each has its own window and decision (64 pairs: unsplit wins; 448: schedule 0)
+    script, slots = [], {64: 0, 448: 0}
+    for i in range(9):
+        for b in (64, 448):
+            script.append((BEGIN, b, 0))
+    outs = _tuner(script)
+    ent = {64: _decode(outs[0])[2], 448: _decode(outs[1])[2]}
+    assert ent[64] != ent[448]
+    fin2 = []
+    for i in range(9):
+        fin2.append((FINISH, (ent[64] << 8) | i, [0.30, 0.31, 0.25][i % 3]))
+        fin2.append((FINISH, (ent[448] << 8) | i, [0.90, 1.00, 1.10][i % 3]))
+    out = _tuner(script + fin2 + [(CURRENT, 64, 0), (CURRENT, 448, 0)])
+    assert out[-2:] == [2, 0]
+    # a fifth shape while four windows have trials in flight: runs unsplit untried; once a window has closed its entry
+    # can be evicted (least recently used) and the new shape is tuned
+    four = [(BEGIN, b, 0) for b in (64, 128, 256, 448)]
+    out = _tuner(four + [(BEGIN, 512, 0)])
+    assert _decode(out[-1]) == (2, None, None)
+    close64 = [(BEGIN, 64, 0)] * 8 + [(FINISH, (0 << 8) | i, 1.0) for i in range(9)]
+    out = _tuner(four + close64 + [(BEGIN, 512, 0), (CURRENT, 64, 0)])
+    assert _decode(out[-2]) == (0, 0, 0) and out[-1] == -1                 # entry 0 re-used for the new shape
+    # pin / unpin
+    out = _tuner([(SET, 2, 0), (BEGIN, 448, 0), (CURRENT, 448, 0), (CAPTURE, 64, 0), (SET, -1, 0), (CURRENT, 448, 0), (BEGIN, 448, 0), (SET, 3, 0)])
+    assert _decode(out[1]) == (2, None, None) and out[2] == 2 and out[3] == 2 and out[5] == -1
+    assert _decode(out[6]) == (0, 0, 0) and out[7] == -1
+    # expiry: after 8192 calls on a decision a new window opens; the old decision stays in force until it closes
+    script = [(BEGIN, 448, 0)] * 9 + fin + [(BEGIN, 448, 0)] * 8191
+    out = _tuner(script + [(BEGIN, 448, 0), (CURRENT, 448, 0)])
+    assert all(_decode(x) == (1, None, None) for x in out[18:18 + 8191])
+    assert _decode(out[-2]) == (0, 0, 0) and out[-1] == 1
 
 
 def test_library_does_not_import_hip_memset(lib_path):
