@@ -381,6 +381,12 @@ MI_API int mi_akaze_scale_select(const float *l_in, int n, int h, int w, int ite
                           float *best, uint8_t *attain, float *tmp, mi_stream_t stream);
 MI_API int mi_akaze_orientation_from_attain(const uint8_t *attain, const float *scale_theta, int num_scales, int n, int h,
                                      int w, const float *keypoints, int k, float *theta, mi_stream_t stream);
+/* The same orientation in ONE launch from the diffused images themselves: scale_images = num_scales maps (n,h,w),
+ * scale_stride floats apart (a stacked (S,n,h,w) tensor: n*h*w); per keypoint the patch_size^2 Gaussian moments
+ * (mi_angle_at_keypoints) are evaluated only for the scales `attain` names -- typically one of three. */
+MI_API int mi_akaze_orientation_select(const float *scale_images, size_t scale_stride, int num_scales,
+                                const uint8_t *attain, int n, int h, int w, const float *keypoints, int k,
+                                int patch_size, const float *moment_kernels, float *theta, mi_stream_t stream);
 MI_API int mi_akaze_hessian_scores(const float *l, int n, int h, int w, float threshold, int nms_size, float *scores,
                             mi_stream_t stream);
 MI_API int mi_akaze_combine(const float *scale_scores, const float *scale_orientations, int num_scales, int n, int h,

@@ -82,6 +82,8 @@ SIGNATURES = {
                               c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "mi_akaze_orientation_from_attain": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                          c_void_p],
+    "mi_akaze_orientation_select": [c_void_p, c_size_t, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int,
+                                    c_void_p, c_void_p, c_void_p],
     "mi_akaze_hessian_scores": [c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p],
     "mi_akaze_combine": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mi_akaze_orientation_at_keypoints": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,

@@ -565,7 +565,7 @@ extern "C" int mi_akaze_scale_select(const float *l_in, int n, int h, int w, int
   if (num_prev < 0 || num_prev > 7) return MI_E_PARAM;
   if (iterations <= 0 || !mi_akaze_kappa_ok(kappa) || nms_size <= 0 || (nms_size & 1) == 0 || nms_size > 15) return MI_E_PARAM;
   if (MI_HOOK(akaze_impl, 0) == 0 && mi_akaze_stream_supported(h, w, iterations, nms_size, l_in, l_out, best) &&
-      ((uintptr_t)prev_scores & 7u) == 0 && ((uintptr_t)attain & 1u) == 0)
+      num_prev <= MI_AKAZE_STREAM_MAX_PREV && ((uintptr_t)prev_scores & 7u) == 0 && ((uintptr_t)attain & 1u) == 0)
     return mi_akaze_scale_stream(l_in, n, h, w, iterations, kappa, dt, threshold, nms_size, l_out, best, 1, prev_scores,
                                  num_prev, attain, stream);
   // general parameters: this scale's map into `best`, then the selection in place

@@ -211,6 +211,7 @@ static inline bool mi_akaze_kappa_ok(float kappa) { return kappa >= MI_AKAZE_KAP
 // akaze_stream.hip: the rolling-window form of one AKAZE scale (mode 0: this scale's score map; mode 1: the selection
 // across scales); mi_akaze_stream_supported says whether it applies (even width, 8-byte aligned maps, nms_size 3 / 5,
 // iterations 1..3)
+#define MI_AKAZE_STREAM_MAX_PREV 3
 int mi_akaze_stream_supported(int h, int w, int iterations, int nms_size, const void *l_in, const void *l_out,
                               const void *scores);
 int mi_akaze_scale_stream(const float *l_in, int n, int h, int w, int iterations, float kappa, float dt, float threshold,

@@ -68,6 +68,62 @@ __global__ __launch_bounds__(256) void angle_map_kernel(const float *__restrict_
   }
 }
 
+// the pixel the reference's grid_sample(nearest) reads for a keypoint: same normalise / un-normalise / round-half-even
+// arithmetic as the descriptor's centres (descriptor/bad.py:464-465,487-500)
+__device__ __forceinline__ void nearest_pixel(const float *__restrict__ kpts, int flat, int h, int w, int &cy, int &cx) {
+  const float ky = fminf(fmaxf(kpts[(size_t)flat * 2 + 0], 0.0f), (float)(h - 1));
+  const float kx = fminf(fmaxf(kpts[(size_t)flat * 2 + 1], 0.0f), (float)(w - 1));
+  const float sy = (float)(2.0 / ((double)(h - 1) + 1e-8)), sx = (float)(2.0 / ((double)(w - 1) + 1e-8));
+  const float ny = ((ky * sy - 1.0f + 1.0f) / 2.0f) * (float)(h - 1);
+  const float nx = ((kx * sx - 1.0f + 1.0f) / 2.0f) * (float)(w - 1);
+  cy = (int)nearbyintf(fminf(fmaxf(ny, 0.0f), (float)(h - 1)));
+  cx = (int)nearbyintf(fminf(fmaxf(nx, 0.0f), (float)(w - 1)));
+}
+
+// atan2 of the Gaussian-weighted first moments of the ps x ps patch centred on (cy, cx), one wave per patch, the lane's
+// patch elements lane, lane + 64, ... (zero padding).  PS > 0: compile-time patch size -- the element coordinates are
+// constants per lane and every load of the lane is issued before the first multiply (branch-free: clamped address, the
+// value dropped afterwards); PS = 0: any size.  Summation order: per lane ascending, then wave_sum -- both instances.
+template <int PS>
+__device__ __forceinline__ float patch_angle(const float *__restrict__ im, int h, int w, int cy, int cx, int ps_rt,
+                                             const float *__restrict__ weights, int lane) {
+  const int ps = PS > 0 ? PS : ps_rt;
+  const int half = ps / 2, area = ps * ps;
+  float m10 = 0.0f, m01 = 0.0f;
+  if constexpr (PS > 0) {
+    constexpr int NQ = (PS * PS + 63) / 64;
+    float v[NQ], wx[NQ], wy[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int i = lane + 64 * q, ic = min(i, PS * PS - 1);
+      const int dy = ic / PS, dx = ic - dy * PS;
+      const int gy = cy + dy - PS / 2, gx = cx + dx - PS / 2;
+      const bool in = i < PS * PS && gy >= 0 && gy < h && gx >= 0 && gx < w;
+      const float raw = im[(size_t)clampi(gy, 0, h - 1) * w + clampi(gx, 0, w - 1)];
+      wx[q] = weights[ic];
+      wy[q] = weights[PS * PS + ic];
+      v[q] = in ? raw : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      m10 += wx[q] * v[q];
+      m01 += wy[q] * v[q];
+    }
+  } else {
+    for (int i = lane; i < area; i += 64) {
+      const int dy = i / ps, dx = i - dy * ps;
+      const int gy = cy + dy - half, gx = cx + dx - half;
+      const float v = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? im[(size_t)gy * w + gx] : 0.0f;   // zero padding
+      m10 += weights[i] * v;
+      m01 += weights[area + i] * v;
+    }
+  }
+  m10 = wave_sum(m10);
+  m01 = wave_sum(m01);
+  return atan2f(m01, m10);                                                                       // :170
+}
+
+template <int PS>
 __global__ __launch_bounds__(64) void angle_kp_kernel(const float *__restrict__ image, int h, int w,
                                                       const float *__restrict__ kpts, int k, int ps,
                                                       const float *__restrict__ weights,
@@ -75,28 +131,38 @@ __global__ __launch_bounds__(64) void angle_kp_kernel(const float *__restrict__ 
   const int lane = threadIdx.x;
   const int flat = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
   const int img = flat / k;
-  const float *im = image + (size_t)img * h * w;
-  // the reference samples the dense angle map at the clamped keypoint with grid_sample(nearest):
-  // same normalise / un-normalise / round-half-even arithmetic as the descriptor's centres
-  const float ky = fminf(fmaxf(kpts[(size_t)flat * 2 + 0], 0.0f), (float)(h - 1));   // bad.py:464-465
-  const float kx = fminf(fmaxf(kpts[(size_t)flat * 2 + 1], 0.0f), (float)(w - 1));
-  const float sy = (float)(2.0 / ((double)(h - 1) + 1e-8)), sx = (float)(2.0 / ((double)(w - 1) + 1e-8));
-  float ny = ((ky * sy - 1.0f + 1.0f) / 2.0f) * (float)(h - 1);
-  float nx = ((kx * sx - 1.0f + 1.0f) / 2.0f) * (float)(w - 1);
-  const int cy = (int)nearbyintf(fminf(fmaxf(ny, 0.0f), (float)(h - 1)));
-  const int cx = (int)nearbyintf(fminf(fmaxf(nx, 0.0f), (float)(w - 1)));
-  const int half = ps / 2;
-  float m10 = 0.0f, m01 = 0.0f;
-  for (int i = lane; i < ps * ps; i += 64) {
-    const int dy = i / ps, dx = i - dy * ps;
-    const int gy = cy + dy - half, gx = cx + dx - half;
-    const float v = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? im[(size_t)gy * w + gx] : 0.0f;   // zero padding
-    m10 += weights[i] * v;
-    m01 += weights[ps * ps + i] * v;
+  int cy, cx;
+  nearest_pixel(kpts, flat, h, w, cy, cx);
+  const float a = patch_angle<PS>(image + (size_t)img * h * w, h, w, cy, cx, ps, weights, lane);
+  if (lane == 0) theta[flat] = a;
+}
+
+// AKAZE.forward's orientation (akaze.py:436-451) at keypoints, in one launch: the mean of the orientations of the
+// scales that reach the maximum score at the keypoint's pixel -- `attain` (mi_akaze_scale_select) says which -- computed
+// only for those scales (typically one of three).  scale_images: num_scales maps (n,h,w), `scale_stride` floats apart.
+template <int PS>
+__global__ __launch_bounds__(64) void akaze_angle_kp_kernel(const float *__restrict__ scale_images, size_t scale_stride,
+                                                            int nscales, const uint8_t *__restrict__ attain, int h,
+                                                            int w, const float *__restrict__ kpts, int k, int ps,
+                                                            const float *__restrict__ weights,
+                                                            float *__restrict__ theta) {
+  const int lane = threadIdx.x;
+  const int flat = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int img = flat / k;
+  int cy, cx;
+  nearest_pixel(kpts, flat, h, w, cy, cx);
+  const size_t plane = (size_t)h * w;
+  unsigned a = attain[(size_t)img * plane + (size_t)cy * w + cx] & ((1u << nscales) - 1u);
+  a = __builtin_amdgcn_readfirstlane(a);                       // wave-uniform: the scale loop is scalar control flow
+  const float cnt = fmaxf((float)__popc(a), 1.0f);
+  float acc = 0.0f;
+  for (int s = 0; s < nscales; ++s) {
+    if (!((a >> s) & 1u)) continue;                            // theta_s * 0 / cnt adds nothing
+    const float t = patch_angle<PS>(scale_images + (size_t)s * scale_stride + (size_t)img * plane, h, w, cy, cx, ps,
+                                    weights, lane);
+    acc += t * (1.0f / cnt);
   }
-  m10 = wave_sum(m10);
-  m01 = wave_sum(m01);
-  if (lane == 0) theta[flat] = atan2f(m01, m10);
+  if (lane == 0) theta[flat] = acc;
 }
 
 }  // namespace
@@ -124,7 +190,30 @@ extern "C" int mi_angle_at_keypoints(const float *image, int n, int h, int w, co
   if (!image || !keypoints || !moment_kernels || !theta) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0 || k <= 0 || (long long)n * k > 0x7fffffffLL) return MI_E_SHAPE;
   if (patch_size <= 0 || (patch_size & 1) == 0 || patch_size > MAX_PS) return MI_E_PARAM;
-  hipLaunchKernelGGL(angle_kp_kernel, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, image, h, w,
-                     keypoints, k, patch_size, moment_kernels, theta);
+  if (patch_size == 15)
+    hipLaunchKernelGGL(angle_kp_kernel<15>, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, image, h, w,
+                       keypoints, k, patch_size, moment_kernels, theta);
+  else
+    hipLaunchKernelGGL(angle_kp_kernel<0>, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, image, h, w,
+                       keypoints, k, patch_size, moment_kernels, theta);
+  return mi_launch_status();
+}
+
+extern "C" int mi_akaze_orientation_select(const float *scale_images, size_t scale_stride, int num_scales,
+                                           const uint8_t *attain, int n, int h, int w, const float *keypoints, int k,
+                                           int patch_size, const float *moment_kernels, float *theta,
+                                           mi_stream_t stream) {
+  MI_ENTER();
+  if (!scale_images || !attain || !keypoints || !moment_kernels || !theta) return MI_E_NULL;
+  if (num_scales <= 0 || num_scales > 8 || n <= 0 || h <= 0 || w <= 0 || k <= 0 || (long long)n * k > 0x7fffffffLL)
+    return MI_E_SHAPE;
+  if (num_scales > 1 && scale_stride < (size_t)n * h * w) return MI_E_SHAPE;
+  if (patch_size <= 0 || (patch_size & 1) == 0 || patch_size > MAX_PS) return MI_E_PARAM;
+  if (patch_size == 15)
+    hipLaunchKernelGGL(akaze_angle_kp_kernel<15>, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, scale_images,
+                       scale_stride, num_scales, attain, h, w, keypoints, k, patch_size, moment_kernels, theta);
+  else
+    hipLaunchKernelGGL(akaze_angle_kp_kernel<0>, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, scale_images,
+                       scale_stride, num_scales, attain, h, w, keypoints, k, patch_size, moment_kernels, theta);
   return mi_launch_status();
 }

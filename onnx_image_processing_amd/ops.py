@@ -465,17 +465,17 @@ def akaze_diffuse(image: torch.Tensor, iterations: int, kappa: float, dt: float 
 
 
 def akaze_scale(image: torch.Tensor, iterations: int, kappa: float, dt: float, threshold: float, nms_size: int,
-                scores_out: torch.Tensor | None = None):
+                scores_out: torch.Tensor | None = None, image_out: torch.Tensor | None = None):
     """One AKAZE scale in one launch: (diffused image, Hessian score map) = (NonLinearDiffusion(image),
     HessianDetector(diffused)); `mi_akaze_scale`."""
     img = _images(image, "image")
     n, _, h, w = img.shape
-    out = torch.empty_like(img)
+    out = image_out if image_out is not None else torch.empty_like(img)
     scores = scores_out if scores_out is not None else torch.empty_like(img)
     fused = bool(N.load().mi_akaze_scale_fused(int(iterations), int(nms_size)))
     tmp = None if fused or iterations <= 1 else torch.empty_like(img)
     N.call("mi_akaze_scale", N.dev(img, F32, "image"), n, h, w, int(iterations), float(kappa), float(dt), float(threshold),
-           int(nms_size), out.data_ptr(), N.dev(scores, F32, "scores"), tmp.data_ptr() if tmp is not None else None,
+           int(nms_size), N.dev(out, F32, "image_out"), N.dev(scores, F32, "scores"), tmp.data_ptr() if tmp is not None else None,
            N.stream_ptr())
     return out, scores
 
@@ -499,7 +499,7 @@ def akaze_attain(scale_scores: torch.Tensor, scores: torch.Tensor) -> torch.Tens
 
 
 def akaze_scale_select(image: torch.Tensor, iterations: int, kappa: float, dt: float, threshold: float, nms_size: int,
-                       prev_scores: torch.Tensor | None):
+                       prev_scores: torch.Tensor | None, image_out: torch.Tensor | None = None):
     """The last AKAZE scale with the selection across scales folded in (`mi_akaze_scale_select`): (diffused image,
     best = max over prev_scores (S-1,N,1,H,W) and this scale's score map, attain (N,1,H,W) uint8: bit s = scale s
     reaches best)."""
@@ -510,13 +510,13 @@ def akaze_scale_select(image: torch.Tensor, iterations: int, kappa: float, dt: f
         raise RuntimeError(f"at most 8 scales, got {num_prev + 1}")
     if num_prev and tuple(prev_scores.shape[1:]) != (n, 1, h, w):
         raise RuntimeError(f"prev_scores must be (S-1,{n},1,{h},{w}), got {tuple(prev_scores.shape)}")
-    out = torch.empty_like(img)
+    out = image_out if image_out is not None else torch.empty_like(img)
     best = torch.empty_like(img)
     attain = torch.empty((n, 1, h, w), dtype=U8, device=img.device)
     fused = bool(N.load().mi_akaze_scale_fused(int(iterations), int(nms_size)))
     tmp = None if fused or iterations <= 1 else torch.empty_like(img)
     N.call("mi_akaze_scale_select", N.dev(img, F32, "image"), n, h, w, int(iterations), float(kappa), float(dt),
-           float(threshold), int(nms_size), out.data_ptr(),
+           float(threshold), int(nms_size), N.dev(out, F32, "image_out"),
            N.dev(prev_scores, F32, "prev_scores") if num_prev else None, num_prev, best.data_ptr(), attain.data_ptr(),
            tmp.data_ptr() if tmp is not None else None, N.stream_ptr())
     return out, best, attain
@@ -530,6 +530,20 @@ def akaze_orientation_from_attain(attain: torch.Tensor, scale_theta: torch.Tenso
     theta = torch.empty((n, k), dtype=F32, device=attain.device)
     N.call("mi_akaze_orientation_from_attain", N.dev(attain, U8, "attain"), N.dev(scale_theta, F32, "scale_theta"), s, n,
            h, w, N.dev(kp, F32, "keypoints"), k, theta.data_ptr(), N.stream_ptr())
+    return theta
+
+
+def akaze_orientation_select(scale_images: torch.Tensor, attain: torch.Tensor, keypoints: torch.Tensor,
+                             moment_kernels: torch.Tensor, patch_size: int) -> torch.Tensor:
+    """AKAZE.forward's orientation at keypoints in one launch (`mi_akaze_orientation_select`): scale_images (S,N,1,H,W)
+    stacked diffused images, attain (N,1,H,W) uint8 from akaze_scale_select."""
+    s, n, _, h, w = scale_images.shape
+    kp = keypoints.float().contiguous()
+    k = kp.shape[1]
+    theta = torch.empty((n, k), dtype=F32, device=attain.device)
+    N.call("mi_akaze_orientation_select", N.dev(scale_images, F32, "scale_images"), n * h * w, s,
+           N.dev(attain, U8, "attain"), n, h, w, N.dev(kp, F32, "keypoints"), k, int(patch_size),
+           N.dev(moment_kernels.float().contiguous(), F32, "moment_kernels"), theta.data_ptr(), N.stream_ptr())
     return theta
 
 

@@ -99,15 +99,18 @@ class AKAZE(nn.Module):
         self.detector = HessianDetector(threshold=threshold, nms_size=nms_size)
         self.orientation_estimator = OrientationEstimator(patch_size=orientation_patch_size, sigma=orientation_sigma)
 
-    def _scale(self, i: int, cur: torch.Tensor, scores_out: torch.Tensor):
+    def _scale(self, i: int, cur: torch.Tensor, scores_out: torch.Tensor, image_out: torch.Tensor | None = None):
         layer = self.diffusion_layers[i]
         if layer.num_iterations > 0 and ops.akaze_kappa_fused(layer.kappa):
             # one launch per scale: diffusion steps + Hessian + NMS (streaming rolling window / LDS tile)
             cur, _ = ops.akaze_scale(cur, layer.num_iterations, layer.kappa, layer.dt, self.detector.threshold,
-                                     self.detector.nms_size, scores_out=scores_out)
+                                     self.detector.nms_size, scores_out=scores_out, image_out=image_out)
         else:                                            # kappa outside the fused kernels' verified range: IEEE per-step kernels
             cur = ops.akaze_diffuse(cur, layer.num_iterations, layer.kappa, layer.dt)
             ops.akaze_hessian_scores(cur, self.detector.threshold, self.detector.nms_size, out=scores_out)
+            if image_out is not None:
+                image_out.copy_(cur)
+                cur = image_out
         return cur
 
     @torch.no_grad()
@@ -126,28 +129,33 @@ class AKAZE(nn.Module):
     @torch.no_grad()
     def detect_select(self, image: torch.Tensor):
         """detect() with the selection across scales folded into the last scale's launch (extension): returns
-        (scores, attain (N,1,H,W) uint8 -- bit s: scale s reaches the maximum --, scale_images).  Same scores as
-        detect(); the stacked per-scale maps' last plane and the separate max-over-scales pass are never written."""
+        (scores, attain (N,1,H,W) uint8 -- bit s: scale s reaches the maximum --, scale_images (S,N,1,H,W) stacked).
+        Same scores as detect(); the stacked per-scale maps' last plane and the separate max-over-scales pass are never
+        written."""
         img = ops._images(image, "image")
         n, _, h, w = img.shape
         last = self.diffusion_layers[-1]
         if self.num_scales > 8 or last.num_iterations <= 0 or not ops.akaze_kappa_fused(last.kappa):
             scores, scale_scores, scale_images = self.detect(image)
-            return scores, ops.akaze_attain(scale_scores, scores), scale_images
+            return scores, ops.akaze_attain(scale_scores, scores), torch.stack(scale_images)
         prev = torch.empty((self.num_scales - 1, n, 1, h, w), dtype=torch.float32, device=img.device)
-        scale_images = []
+        scale_images = torch.empty((self.num_scales, n, 1, h, w), dtype=torch.float32, device=img.device)
         cur = img
         for i in range(self.num_scales - 1):
-            cur = self._scale(i, cur, prev[i])
-            scale_images.append(cur)
-        cur, scores, attain = ops.akaze_scale_select(cur, last.num_iterations, last.kappa, last.dt, self.detector.threshold,
-                                                     self.detector.nms_size, prev if self.num_scales > 1 else None)
-        scale_images.append(cur)
+            cur = self._scale(i, cur, prev[i], scale_images[i])
+        _, scores, attain = ops.akaze_scale_select(cur, last.num_iterations, last.kappa, last.dt, self.detector.threshold,
+                                                   self.detector.nms_size, prev if self.num_scales > 1 else None,
+                                                   image_out=scale_images[-1])
         return scores, attain, scale_images
 
     @torch.no_grad()
     def orientation_at_keypoints(self, scale_scores: torch.Tensor, scale_images, keypoints: torch.Tensor):
-        """scale_scores: the stacked per-scale maps of detect() (float32) or the attain map of detect_select() (uint8)."""
+        """scale_scores: the stacked per-scale maps of detect() (float32) or the attain map of detect_select() (uint8;
+        with the stacked scale images of detect_select() this is ONE launch that evaluates the moments only for the scales
+        attain names)."""
+        if scale_scores.dtype == torch.uint8 and torch.is_tensor(scale_images) and scale_images.is_contiguous():
+            est = self.orientation_estimator
+            return ops.akaze_orientation_select(scale_images, scale_scores, keypoints, est.moment_kernels, est.patch_size)
         theta = torch.stack([self.orientation_estimator.at_keypoints(im, keypoints) for im in scale_images])
         if scale_scores.dtype == torch.uint8:
             return ops.akaze_orientation_from_attain(scale_scores, theta.contiguous(), keypoints)
