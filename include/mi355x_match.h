@@ -422,6 +422,16 @@ MI_API size_t mi_essential_matrix_workspace_bytes(int batch, int n, int m, int t
 MI_API int mi_essential_matrix(const float *p, int batch, int n, int m, const float *pts1, const float *pts2,
                         const uint8_t *valid1, const uint8_t *valid2, int top_k, int n_iter,
                         int n_iter_manifold, float *e, void *workspace, size_t workspace_bytes, mi_stream_t stream);
+/* The same head WITHOUT a materialised P, from the packed-descriptor Sinkhorn solution: dots / row_info / col_info /
+ * pitch as written by mi_cost_dots_bits, u (batch, n+1) / v (batch, m+1) the duals of mi_sinkhorn_dots (p = NULL there).
+ * Every entry P_ij = exp(z_ij + u_i + v_j) is rebuilt in registers with the solver's own final-pass expression, so E
+ * equals mi_essential_matrix on the P that mi_sinkhorn_dots would have written, bit for bit; 2 instead of 4 bytes per
+ * entry are read and the (n+1) x (m+1) matrix is neither written nor read back.  epsilon >= MI_DOTS_MIN_EPSILON. */
+MI_API int mi_essential_matrix_dots(const uint16_t *dots, const float *row_info, const float *col_info, int pitch,
+                             double epsilon, const float *u, const float *v, int batch, int n, int m,
+                             const float *pts1, const float *pts2, const uint8_t *valid1, const uint8_t *valid2,
+                             int top_k, int n_iter, int n_iter_manifold, float *e, void *workspace,
+                             size_t workspace_bytes, mi_stream_t stream);
 
 /* ---- detector/fast.py:198-239  FASTScore.forward (use_nms = False) ----------------------------------
  * score (n,1,h,w) = 1.0 where 9 contiguous pixels of the radius-3 circle (replicate padding) are all

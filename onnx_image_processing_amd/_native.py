@@ -72,6 +72,9 @@ SIGNATURES = {
     "mi_essential_matrix_workspace_bytes": [c_int, c_int, c_int, c_int],
     "mi_essential_matrix": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                             c_void_p, c_void_p, c_size_t, c_void_p],
+    "mi_essential_matrix_dots": [c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p, c_int, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                 c_void_p],
     "mi_fast_score": [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p],
     "mi_dog_responses": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mi_akaze_diffuse": [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p],

@@ -79,6 +79,37 @@ __device__ __forceinline__ void hartley_wave(const float *__restrict__ pts, cons
   }
 }
 
+// Where the assignment matrix comes from.  EmSrcP: a materialised P (b, n+1, m+1).  EmSrcDots (round 4): P is never
+// written -- every entry is rebuilt from the packed descriptors' uint16 dot products and the Sinkhorn duals with the very
+// expression the solver's final pass uses (sinkhorn_dots.hip: sk_exp_dots_kernel), so both sources give the head the
+// same bits; the band kernel then reads 2 instead of 4 bytes per entry and the 4-byte matrix is neither written nor
+// re-read (138 + 137 MB per 128 pairs at K = 512).
+struct EmSrcP {
+  const float *p;
+  struct Row {};
+  struct Col {};
+  __device__ __forceinline__ Row row(int, int, int) const { return Row(); }
+  __device__ __forceinline__ Col col(int, int, int) const { return Col(); }
+  __device__ __forceinline__ float at(int b, int n, int m, int i, int j, const Row &, const Col &) const {
+    return p[((size_t)b * (n + 1) + i) * (size_t)(m + 1) + j];
+  }
+};
+struct EmSrcDots {
+  const uint16_t *dots;          // (batch, n, pitch)
+  int pitch;
+  const float2 *row_info, *col_info;
+  const float *u, *v;            // (batch, n + 1), (batch, m + 1)
+  float neg_inv_eps;
+  struct Row { float2 ri; float u; };
+  struct Col { float2 ci; float v; };
+  __device__ __forceinline__ Row row(int b, int n, int i) const { return Row{row_info[(size_t)b * n + i], u[(size_t)b * (n + 1) + i]}; }
+  __device__ __forceinline__ Col col(int b, int m, int j) const { return Col{col_info[(size_t)b * m + j], v[(size_t)b * (m + 1) + j]}; }
+  __device__ __forceinline__ float at(int b, int n, int, int i, int j, const Row &r, const Col &c) const {
+    const float dot = (float)dots[((size_t)b * n + i) * pitch + j];
+    return mi_prob_exp((mi_z_from_dot(dot, r.ri, c.ci, neg_inv_eps) + r.u) + c.v);     // sinkhorn.py:145,206
+  }
+};
+
 // LDS state shared by the dense front, the sparse front and the solve
 struct EmShared {
   float thr_row[EM_MAXN], thr_col[EM_MAXN], w1[EM_MAXN], w2[EM_MAXN], v1s[EM_MAXN], v2s[EM_MAXN];
@@ -90,21 +121,20 @@ struct EmShared {
 
 // Dense front: thresholds, weights, Hartley parameters and the 81 normal-equation sums of pair b, by one 1024-thread
 // workgroup streaming P four times.  Leaves S.mflat / S.hart ready (a barrier has been passed).
-__device__ void em_dense_front(EmShared &S, const float *__restrict__ p, int b, int n, int m,
+template <typename SRC>
+__device__ void em_dense_front(EmShared &S, const SRC src, int b, int n, int m,
                                const float *__restrict__ pts1, const float *__restrict__ pts2,
                                const uint8_t *__restrict__ valid1, const uint8_t *__restrict__ valid2, int top_k) {
   float *thr_row = S.thr_row, *thr_col = S.thr_col, *w1 = S.w1, *w2 = S.w2, *v1s = S.v1s, *v2s = S.v2s, *f2x = S.f2x, *f2y = S.f2y;
   float (*mpart)[81] = S.mpart;
   float *mflat = S.mflat, *hart = S.hart;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const float *pb = p + (size_t)b * (n + 1) * (size_t)(m + 1);
-  const size_t pitch = (size_t)(m + 1);
   const float *q1 = pts1 + (size_t)b * n * 2, *q2 = pts2 + (size_t)b * m * 2;
 
   for (int i = t; i < n; i += EM_T) v1s[i] = valid1 ? (valid1[(size_t)b * n + i] ? 1.0f : 0.0f) : 1.0f;
   for (int j = t; j < m; j += EM_T) v2s[j] = valid2 ? (valid2[(size_t)b * m + j] ? 1.0f : 0.0f) : 1.0f;
   __syncthreads();
-  auto core = [&](int i, int j) { return (pb[(size_t)i * pitch + j] * v1s[i]) * v2s[j]; };
+  auto core = [&](int i, int j) { return (src.at(b, n, m, i, j, src.row(b, n, i), src.col(b, m, j)) * v1s[i]) * v2s[j]; };
 
   // ---- k-th largest per row (one wave per row) and per column (one thread per column)
   for (int i = wave; i < n; i += EM_W) {
@@ -277,14 +307,15 @@ __device__ void em_solve(const EmShared &S, int b, int n_iter, int n_iter_manifo
     for (int c = 0; c < 3; ++c) out[r * 3 + c] = (um[r][0] * s_avg) * vm[c][0] + (um[r][1] * s_avg) * vm[c][1];
 }
 
-__global__ __launch_bounds__(EM_T) void em_estimate_kernel(const float *__restrict__ p, int n, int m,
+template <typename SRC>
+__global__ __launch_bounds__(EM_T) void em_estimate_kernel(const SRC src, int n, int m,
                                                            const float *__restrict__ pts1,
                                                            const float *__restrict__ pts2,
                                                            const uint8_t *__restrict__ valid1,
                                                            const uint8_t *__restrict__ valid2, int top_k, int n_iter,
                                                            int n_iter_manifold, float *__restrict__ e_out) {
   __shared__ EmShared S;
-  em_dense_front(S, p, (int)blockIdx.x, n, m, pts1, pts2, valid1, valid2, top_k);
+  em_dense_front(S, src, (int)blockIdx.x, n, m, pts1, pts2, valid1, valid2, top_k);
   if (threadIdx.x == 0) em_solve(S, (int)blockIdx.x, n_iter, n_iter_manifold, e_out);
 }
 
@@ -307,8 +338,8 @@ __global__ __launch_bounds__(EM_T) void em_estimate_kernel(const float *__restri
 constexpr int EM_CAND = 8;          // candidates kept per row / contributions kept per column
 constexpr int EB_WAVES = 8, EB_RPW = 4, EB_ROWS = EB_WAVES * EB_RPW;   // band: 8 waves x 4 rows
 
-template <int K, int Q>             // K = top_k (1..4), Q = 64-column groups per row (8: m <= 512, 16: m <= 1024)
-__global__ __launch_bounds__(64 * EB_WAVES) void em_band_kernel(const float *__restrict__ p, int n, int m,
+template <typename SRC, int K, int Q>   // K = top_k (1..4), Q = 64-column groups per row (8: m <= 512, 16: m <= 1024)
+__global__ __launch_bounds__(64 * EB_WAVES) void em_band_kernel(const SRC src, int n, int m,
                                                                 const uint8_t *__restrict__ valid1,
                                                                 const uint8_t *__restrict__ valid2,
                                                                 float *__restrict__ thr_row, uint8_t *__restrict__ cand_cnt,
@@ -317,13 +348,13 @@ __global__ __launch_bounds__(64 * EB_WAVES) void em_band_kernel(const float *__r
   __shared__ float ctop_s[EB_WAVES][64 * Q][K];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.y, band = blockIdx.x, nb = gridDim.x;
-  const float *pb = p + (size_t)b * (n + 1) * (size_t)(m + 1);
-  const size_t pitch = (size_t)(m + 1);
   float v2[Q];
+  typename SRC::Col cols[Q];         // the columns' part of an entry (nothing for a materialised P)
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     const int j = lane + 64 * q;
     v2[q] = j < m ? (valid2 ? (valid2[(size_t)b * m + j] ? 1.0f : 0.0f) : 1.0f) : 0.0f;
+    cols[q] = src.col(b, m, min(j, m - 1));
   }
   float ctop[Q][K];                  // this wave's top K of every column it has seen (descending)
 #pragma unroll
@@ -334,11 +365,12 @@ __global__ __launch_bounds__(64 * EB_WAVES) void em_band_kernel(const float *__r
     const int i = band * EB_ROWS + wave * EB_RPW + r;
     if (i >= n) break;                                            // wave-uniform
     const float v1 = valid1 ? (valid1[(size_t)b * n + i] ? 1.0f : 0.0f) : 1.0f;
+    const typename SRC::Row rowc = src.row(b, n, i);
     float x[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       const int j = lane + 64 * q;
-      x[q] = j < m ? (pb[(size_t)i * pitch + j] * v1) * v2[q] : -INFINITY;      // core (:334-343); -inf past the matrix
+      x[q] = j < m ? (src.at(b, n, m, i, j, rowc, cols[q]) * v1) * v2[q] : -INFINITY;   // core (:334-343); -inf past the matrix
     }
     float top[K];
 #pragma unroll
@@ -403,8 +435,8 @@ __global__ __launch_bounds__(64 * EB_WAVES) void em_band_kernel(const float *__r
   }
 }
 
-template <int K>
-__global__ __launch_bounds__(EM_T) void em_sparse_kernel(const float *__restrict__ p, int n, int m,
+template <typename SRC, int K>
+__global__ __launch_bounds__(EM_T) void em_sparse_kernel(const SRC src, int n, int m,
                                                          const float *__restrict__ pts1, const float *__restrict__ pts2,
                                                          const uint8_t *__restrict__ valid1,
                                                          const uint8_t *__restrict__ valid2, int n_iter,
@@ -461,7 +493,7 @@ __global__ __launch_bounds__(EM_T) void em_sparse_kernel(const float *__restrict
   __syncthreads();
   if (s_dense) {                                                  // workgroup-uniform
     __syncthreads();
-    em_dense_front(S, p, b, n, m, pts1, pts2, valid1, valid2, K);
+    em_dense_front(S, src, b, n, m, pts1, pts2, valid1, valid2, K);
   } else {
     // column sums: a column's contributions arrive in any order; they are ADDED in ascending row order
     for (int j = t; j < m; j += EM_T) {
@@ -593,17 +625,15 @@ extern "C" size_t mi_essential_matrix_workspace_bytes(int batch, int n, int m, i
   return em_carve(nullptr, batch, n, m, top_k).total;
 }
 
-extern "C" int mi_essential_matrix(const float *p, int batch, int n, int m, const float *pts1, const float *pts2,
-                                   const uint8_t *valid1, const uint8_t *valid2, int top_k, int n_iter,
-                                   int n_iter_manifold, float *e, void *workspace, size_t workspace_bytes,
-                                   mi_stream_t stream) {
-  MI_ENTER();
-  if (!p || !pts1 || !pts2 || !e) return MI_E_NULL;
+template <typename SRC>
+static int em_launch(const SRC src, int batch, int n, int m, const float *pts1, const float *pts2, const uint8_t *valid1,
+                     const uint8_t *valid2, int top_k, int n_iter, int n_iter_manifold, float *e, void *workspace,
+                     size_t workspace_bytes, hipStream_t s) {
+  if (!pts1 || !pts2 || !e) return MI_E_NULL;
   if ((valid1 == nullptr) != (valid2 == nullptr)) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0) return MI_E_SHAPE;
   if (n > EM_MAXN || m > EM_MAXN) return MI_E_PARAM;
   if (top_k <= 0 || top_k > EM_MAXK || top_k > n || top_k > m || n_iter < 0 || n_iter_manifold < 0) return MI_E_PARAM;
-  hipStream_t s = (hipStream_t)stream;
   const size_t need = mi_essential_matrix_workspace_bytes(batch, n, m, top_k);
   if (workspace && need > 0) {
     // banded form: one pass over the matrix spread over the chip, then one workgroup per pair on the sparse weights
@@ -612,8 +642,8 @@ extern "C" int mi_essential_matrix(const float *p, int batch, int n, int m, cons
     const EmWork w = em_carve(workspace, batch, n, m, top_k);
     const int nb = ceil_div(n, EB_ROWS);
     const dim3 grid(nb, batch);
-#define EM_BAND(K, Q) hipLaunchKernelGGL((em_band_kernel<K, Q>), grid, dim3(64 * EB_WAVES), 0, s, p, n, m, valid1, valid2, w.thr_row, w.cand_cnt, w.cand_j, w.cand_x, w.col_part)
-#define EM_SPARSE(K) hipLaunchKernelGGL((em_sparse_kernel<K>), dim3(batch), dim3(EM_T), 0, s, p, n, m, pts1, pts2, valid1, valid2, n_iter, n_iter_manifold, w.thr_row, w.cand_cnt, w.cand_j, w.cand_x, w.col_part, nb, e)
+#define EM_BAND(K, Q) hipLaunchKernelGGL((em_band_kernel<SRC, K, Q>), grid, dim3(64 * EB_WAVES), 0, s, src, n, m, valid1, valid2, w.thr_row, w.cand_cnt, w.cand_j, w.cand_x, w.col_part)
+#define EM_SPARSE(K) hipLaunchKernelGGL((em_sparse_kernel<SRC, K>), dim3(batch), dim3(EM_T), 0, s, src, n, m, pts1, pts2, valid1, valid2, n_iter, n_iter_manifold, w.thr_row, w.cand_cnt, w.cand_j, w.cand_x, w.col_part, nb, e)
     const bool wide = m > 512;
     switch (top_k) {
       case 1: if (wide) EM_BAND(1, 16); else EM_BAND(1, 8); MI_CHECK_LAUNCH(); EM_SPARSE(1); break;
@@ -625,7 +655,40 @@ extern "C" int mi_essential_matrix(const float *p, int batch, int n, int m, cons
 #undef EM_SPARSE
     return mi_launch_status();
   }
-  hipLaunchKernelGGL(em_estimate_kernel, dim3(batch), dim3(EM_T), 0, s, p, n, m, pts1, pts2, valid1, valid2, top_k, n_iter,
-                     n_iter_manifold, e);
+  hipLaunchKernelGGL(em_estimate_kernel<SRC>, dim3(batch), dim3(EM_T), 0, s, src, n, m, pts1, pts2, valid1, valid2, top_k,
+                     n_iter, n_iter_manifold, e);
   return mi_launch_status();
+}
+
+extern "C" int mi_essential_matrix(const float *p, int batch, int n, int m, const float *pts1, const float *pts2,
+                                   const uint8_t *valid1, const uint8_t *valid2, int top_k, int n_iter,
+                                   int n_iter_manifold, float *e, void *workspace, size_t workspace_bytes,
+                                   mi_stream_t stream) {
+  MI_ENTER();
+  if (!p) return MI_E_NULL;
+  return em_launch(EmSrcP{p}, batch, n, m, pts1, pts2, valid1, valid2, top_k, n_iter, n_iter_manifold, e, workspace,
+                   workspace_bytes, (hipStream_t)stream);
+}
+
+// The head straight from the packed-descriptor Sinkhorn solution (mi_cost_dots_bits + mi_sinkhorn_dots with p = NULL):
+// see include/mi355x_match.h
+extern "C" int mi_essential_matrix_dots(const uint16_t *dots, const float *row_info, const float *col_info, int pitch,
+                                        double epsilon, const float *u, const float *v, int batch, int n, int m,
+                                        const float *pts1, const float *pts2, const uint8_t *valid1,
+                                        const uint8_t *valid2, int top_k, int n_iter, int n_iter_manifold, float *e,
+                                        void *workspace, size_t workspace_bytes, mi_stream_t stream) {
+  MI_ENTER();
+  if (!dots || !row_info || !col_info || !u || !v) return MI_E_NULL;
+  if (pitch < m || pitch % 8 != 0) return MI_E_ALIGN;
+  if (!(epsilon >= MI_DOTS_MIN_EPSILON)) return MI_E_PARAM;
+  EmSrcDots src;
+  src.dots = dots;
+  src.pitch = pitch;
+  src.row_info = reinterpret_cast<const float2 *>(row_info);
+  src.col_info = reinterpret_cast<const float2 *>(col_info);
+  src.u = u;
+  src.v = v;
+  src.neg_inv_eps = (float)(-1.0 / epsilon);
+  return em_launch(src, batch, n, m, pts1, pts2, valid1, valid2, top_k, n_iter, n_iter_manifold, e, workspace,
+                   workspace_bytes, (hipStream_t)stream);
 }

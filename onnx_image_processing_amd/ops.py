@@ -609,6 +609,32 @@ def essential_matrix(p: torch.Tensor, pts1_n: torch.Tensor, pts2_n: torch.Tensor
     return e
 
 
+def essential_matrix_dots(state, m: int, epsilon: float, u: torch.Tensor, v: torch.Tensor, pts1_n: torch.Tensor,
+                          pts2_n: torch.Tensor, valid1: torch.Tensor | None, valid2: torch.Tensor | None, top_k: int,
+                          n_iter: int, n_iter_manifold: int, banded: bool = True) -> torch.Tensor:
+    """essential_matrix() without a materialised P (`mi_essential_matrix_dots`): `state` = the (dots, row_info, col_info,
+    pitch, ...) tuple of sinkhorn_bits(return_state=True), u / v its duals.  Same E bit for bit as essential_matrix on
+    the P that solve would have written."""
+    dots, row_info, col_info, pitch = state[:4]
+    b, n = dots.shape[0], dots.shape[1]
+    q1, q2 = pts1_n.float().contiguous(), pts2_n.float().contiguous()
+    if tuple(q1.shape) != (b, n, 2) or tuple(q2.shape) != (b, m, 2):
+        raise RuntimeError(f"points must be ({b},{n},2) and ({b},{m},2), got {tuple(q1.shape)}, {tuple(q2.shape)}")
+    if (valid1 is None) != (valid2 is None):
+        raise RuntimeError("valid1 and valid2 must be given together")
+    v1 = valid1.to(torch.uint8).contiguous() if valid1 is not None else None
+    v2 = valid2.to(torch.uint8).contiguous() if valid2 is not None else None
+    e = torch.empty((b, 3, 3), dtype=F32, device=dots.device)
+    wbytes = int(N.load().mi_essential_matrix_workspace_bytes(b, n, m, int(top_k))) if banded else 0
+    work = torch.empty(((wbytes + 7) // 8,), dtype=torch.int64, device=dots.device) if wbytes else None
+    N.call("mi_essential_matrix_dots", dots.data_ptr(), row_info.data_ptr(), col_info.data_ptr(), int(pitch), float(epsilon),
+           N.dev(u, F32, "u"), N.dev(v, F32, "v"), b, n, m, N.dev(q1, F32, "pts1"), N.dev(q2, F32, "pts2"),
+           N.dev(v1, torch.uint8, "valid1") if v1 is not None else None,
+           N.dev(v2, torch.uint8, "valid2") if v2 is not None else None, int(top_k), int(n_iter), int(n_iter_manifold),
+           e.data_ptr(), work.data_ptr() if work is not None else None, wbytes, N.stream_ptr())
+    return e
+
+
 # ---- FAST / DoG detectors (detector/fast.py, detector/dog.py) -----------------------------------------
 
 def fast_score(image: torch.Tensor, threshold: float) -> torch.Tensor:

@@ -52,18 +52,52 @@ class _EssentialHead(nn.Module):
     def _normalised(self, kp: torch.Tensor) -> torch.Tensor:
         return ops.normalise_keypoints(kp, self.K_inv)                                        # (y,x) -> K^-1 [x, y, 1]
 
-    @torch.no_grad()
-    def forward(self, image1: torch.Tensor, image2: torch.Tensor):
+    def _solve(self, image1: torch.Tensor, image2: torch.Tensor, want_p: bool):
+        """-> (k1, k2, P or None, E (B,3,3), solution or None).  Hard-binarised descriptors with the L2 cost (the export-
+        CLI configuration) take the packed route: the head reads the uint16 dot products + the duals
+        (`mi_essential_matrix_dots`), P is written only when the caller wants it and never read back."""
+        from ..matching.sinkhorn import SinkhornSolution
         if image1.shape != image2.shape:
             raise RuntimeError(f"image shapes differ: {tuple(image1.shape)} vs {tuple(image2.shape)}")
         k1, s1, d1, packed = self._describe(image1)
         k2, s2, d2, _ = self._describe(image2)
-        if packed:
-            probs = self.matcher.forward_bits(d1, d2, self.descriptor.normalize_descriptors)
-        else:
-            probs = self.matcher(d1, d2)
-        e = self.estimator.estimate(probs, self._normalised(k1.float()), self._normalised(k2.float()), s1 > 0, s2 > 0)
+        q1, q2 = self._normalised(k1.float()), self._normalised(k2.float())
+        m = self.matcher
+        if packed and m.use_dot_storage and ops.dots_supported(d1.shape[0], d1.shape[1], d2.shape[1], m.epsilon) \
+                and self.estimator.top_k <= 8:
+            probs, u, v, state = ops.sinkhorn_bits(d1, d2, self.descriptor.normalize_descriptors, m.epsilon, m.unused_score,
+                                                   m.iterations, want_p=want_p, return_state=True)
+            sol = SinkhornSolution("dots", state, d2.shape[1], state[3], m.epsilon, u, v)
+            e = self.estimator.estimate_from_solution(sol, q1, q2, s1 > 0, s2 > 0)
+            return k1, k2, probs, e, sol
+        probs = m.forward_bits(d1, d2, self.descriptor.normalize_descriptors) if packed else m(d1, d2)
+        return k1, k2, probs, self.estimator.estimate(probs, q1, q2, s1 > 0, s2 > 0), None
+
+    @torch.no_grad()
+    def forward(self, image1: torch.Tensor, image2: torch.Tensor):
+        k1, k2, probs, e, _ = self._solve(image1, image2, want_p=True)
         return k1, k2, probs, (e[0] if e.shape[0] == 1 else e)
+
+    @torch.no_grad()
+    def essential(self, image1: torch.Tensor, image2: torch.Tensor):
+        """forward() without its third output (extension): (keypoints1, keypoints2, E (B,3,3)); on the packed route the
+        (B,K+1,K+1) matrix is never written."""
+        k1, k2, _, e, _ = self._solve(image1, image2, want_p=False)
+        return k1, k2, e
+
+    @torch.no_grad()
+    def match_and_essential(self, image1: torch.Tensor, image2: torch.Tensor, max_matches: int = 100,
+                            threshold: float = 0.1):
+        """What a visual-odometry host consumes per frame pair (reference sample/visual_odometry.py:520-613: E for the
+        pose, mutual matches for the inlier test), all from the Sinkhorn solution (extension): (matched_kpts1,
+        matched_kpts2, scores, valid, E (B,3,3)) = MutualNearestNeighborMatcher(forward()[2]) + forward()[3], without
+        P on the packed route."""
+        k1, k2, probs, e, sol = self._solve(image1, image2, want_p=False)
+        if sol is not None and ops.mnn_duals_supported(k1.shape[0], k1.shape[1], k2.shape[1]):
+            return (*sol.mutual_matches(k1, k2, max_matches, threshold), e)
+        if probs is None:
+            k1, k2, probs, e, _ = self._solve(image1, image2, want_p=True)
+        return (*ops.mnn_extract(probs, k1, k2, max_matches, threshold), e)
 
 
 class ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix(_EssentialHead):

@@ -39,6 +39,15 @@ class EssentialMatrixEstimator(nn.Module):
         return ops.essential_matrix(P, pts1_n, pts2_n, valid1, valid2, self.top_k, self.n_iter, self.n_iter_manifold)
 
     @torch.no_grad()
+    def estimate_from_solution(self, sol, pts1_n: torch.Tensor, pts2_n: torch.Tensor, valid1=None, valid2=None):
+        """estimate() on the P a packed-form SinkhornSolution defines (matching/sinkhorn.py: kind "dots"), without that P
+        being written (`mi_essential_matrix_dots`): same E bit for bit."""
+        if sol.kind != "dots":
+            raise RuntimeError("estimate_from_solution needs the packed dot-product form of the Sinkhorn solution")
+        return ops.essential_matrix_dots(sol.source, sol.m, sol.epsilon, sol.u, sol.v, pts1_n, pts2_n, valid1, valid2,
+                                         self.top_k, self.n_iter, self.n_iter_manifold)
+
+    @torch.no_grad()
     def forward(self, P: torch.Tensor) -> torch.Tensor:
         single = P.dim() == 2
         pb = P.unsqueeze(0) if single else P

@@ -1250,6 +1250,54 @@ def test_vo_model_480x640_k512_reference_fixture(mods):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("b,n,m,bits", [(3, 512, 512, 512), (2, 300, 77, 256), (1, 40, 56, 256), (2, 520, 700, 512)])
+def test_essential_matrix_from_the_sinkhorn_solution_equals_from_p(mods, b, n, m, bits):
+    """mi_essential_matrix_dots (the head on the uint16 dot products + the Sinkhorn duals, P never written) against
+    mi_essential_matrix on the P mi_sinkhorn_dots writes: every entry is rebuilt with the solver's own final-pass
+    expression, so E is identical BIT FOR BIT -- banded and dense form, with and without validity masks, n != m, m > 512."""
+    from onnx_image_processing_amd import ops
+    rng = np.random.default_rng(n * 3 + m)
+    b1 = rng.integers(0, 2 ** 32, size=(b, n, bits // 32), dtype=np.uint64).astype(np.uint32)
+    b2 = rng.integers(0, 2 ** 32, size=(b, m, bits // 32), dtype=np.uint64).astype(np.uint32)
+    k = min(n, m) * 3 // 4
+    b2[:, :k] = b1[:, :k]                                            # true correspondences
+    flip = rng.integers(0, bits // 32, size=(b, k))
+    for bi in range(b):
+        b2[bi, np.arange(k), flip[bi]] ^= np.uint32(1) << rng.integers(0, 32, size=k).astype(np.uint32)
+    t1, t2 = gpu(b1.view(np.int32)), gpu(b2.view(np.int32))
+    p, u, v, state = ops.sinkhorn_bits(t1, t2, True, 0.05, 1.0, 20, want_p=True, return_state=True)
+    q1 = gpu((rng.random((b, n, 2)) - 0.5).astype(np.float32))
+    q2 = q1[:, :m].clone() if m <= n else gpu((rng.random((b, m, 2)) - 0.5).astype(np.float32))
+    if m > n:
+        q2[:, :n] = q1
+    q2 = (q2 + 0.01).contiguous()
+    v1 = gpu(rng.random((b, n)) > 0.1)
+    v2 = gpu(rng.random((b, m)) > 0.1)
+    for top_k in (1, 3, 4):
+        for masks in ((None, None), (v1, v2)):
+            for banded in (True, False):
+                want = ops.essential_matrix(p, q1, q2, masks[0], masks[1], top_k, 30, 10, banded=banded)
+                got = ops.essential_matrix_dots(state, m, 0.05, u, v, q1, q2, masks[0], masks[1], top_k, 30, 10, banded=banded)
+                assert torch.isfinite(want).all() and torch.equal(got, want), (top_k, masks[0] is not None, banded)
+
+
+def test_vo_model_extensions_equal_forward(mods):
+    """_EssentialHead.essential / match_and_essential (extensions: E, or matches + E, straight from the Sinkhorn solution
+    with P never written) against forward() + MutualNearestNeighborMatcher, bit for bit, batch of 3."""
+    from onnx_image_processing_amd.pytorch_model.feature_detection import ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix
+    g = load_golden("angle_vo_480x640_k512")
+    a, b = synth_batch(9100, 3, 240, 320)
+    model = ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix(K=torch.from_numpy(g["cam_K"]), **{**cfg_of(g), "max_keypoints": 128}).to(DEV)
+    k1, k2, p, e = model(gpu(a), gpu(b))
+    x1, x2, e2 = model.essential(gpu(a), gpu(b))
+    assert torch.equal(x1, k1) and torch.equal(x2, k2) and torch.equal(e2, e)
+    out = model.match_and_essential(gpu(a), gpu(b), 50, 0.1)
+    want = mods["MutualNearestNeighborMatcher"](50, 0.1)(p, k1, k2)
+    for x, y in zip(out[:4], want):
+        assert torch.equal(x, y)
+    assert torch.equal(out[4], e) and int(want[3].sum()) > 30
+
+
 # ------------------------------------------------------------------ FAST / DoG detectors
 def test_fast_and_dog_detectors(mods):
     from onnx_image_processing_amd.pytorch_model.detector import DoGDetector, DoGDetectorWithScore, FASTScore
