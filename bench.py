@@ -547,7 +547,9 @@ def side_workload(args, rank, world, dev) -> None:
         cam = torch.tensor([[500.0, 0.0, 320.0], [0.0, 500.0, 240.0], [0.0, 0.0, 1.0]])
         base = ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix(K=cam, max_keypoints=k, **vcfg)
         what = ("ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix (the VO model: Shi-Tomasi(5) + keypoint angles + oriented "
-                "BAD(512, hard) + Sinkhorn(20, eps 0.05) + essential-matrix head), 640x480, K=512, Angle export-CLI values")
+                "BAD(512, hard) + Sinkhorn(20, eps 0.05) + essential-matrix head), 640x480, K=512, Angle export-CLI values; "
+                "per pair what sample/visual_odometry.py:520-613 consumes: E and the 100 best mutual matches "
+                "(match_and_essential: both straight from the Sinkhorn solution, P not written)")
         roof = ("mi_corner_response_balanced", "corner_tile_kernel<5,8> (block 5: the register-staged tile kernel)", 8.0, 1, "corner_tile_kernel<5,8>")
     else:
         h, w, k = H, W, K
@@ -568,8 +570,10 @@ def side_workload(args, rank, world, dev) -> None:
     if args.workload == "vo":
         model = base.to(dev)
 
-        def step():                                   # one record per pair: the 3 x 3 essential matrix (P stays on the GPU)
-            return gather(model(img1, img2)[3].reshape(B, 1, 9))
+        def step():                                   # per pair: 100 match records + the 3 x 3 essential matrix (two more rows)
+            mk1, mk2, sc, valid, e = model.match_and_essential(img1, img2, MNN["max_matches"], MNN["threshold"])
+            erows = torch.nn.functional.pad(e.reshape(B, 9), (0, 3)).reshape(B, 2, D.RECORD_FIELDS)
+            return gather(torch.cat([D.pack_records(mk1, mk2, sc, valid), erows], dim=1))
     else:
         model = MatchExtractionWrapper(base, max_matches=MNN["max_matches"], match_threshold=MNN["threshold"]).to(dev)
         model.fuse_extraction = not args.two_step
@@ -596,7 +600,8 @@ def side_workload(args, rank, world, dev) -> None:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": what, "pairs_per_gpu_per_step": B,
-                       **({"finite_essential_matrices": int(torch.isfinite(out).all(dim=(1, 2)).sum().item())}
+                       **({"finite_essential_matrices": int(torch.isfinite(out[:, -2:]).all(dim=(1, 2)).sum().item()),
+                           "mean_valid_matches_per_pair": float(out[:, :-2, 5].sum().item()) / (B * world)}
                           if args.workload == "vo" else
                           {"mean_valid_matches_per_pair": float(out[..., 5].sum().item()) / (B * world)})},
             "step_ms": step_stats(per_step), **facts,
@@ -660,22 +665,36 @@ def launch_ranks(n: int, argv: list[str]) -> int:
                    MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # rank 0's stdout is drained WHILE the ranks run (a reader thread): a rank blocked writing into a full pipe would
+    # never exit and this loop would poll forever
+    import threading
+    chunks: list[str] = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     rc = 0
     pending = set(range(n))
+    kill_at = None                                                   # after a failure: terminate, then kill what is left
     while pending:
         for r in sorted(pending):
             code = procs[r].poll()
             if code is None:
                 continue
             pending.discard(r)
-            if code != 0:
+            if code != 0 and kill_at is None:
                 print(f"[bench] rank {r} exited with code {code}", file=sys.stderr, flush=True)
                 rc = rc or code or 1
                 for q in pending:                                    # the exact children started above, by handle
                     procs[q].terminate()
+                kill_at = time.time() + 10.0
+        if pending and kill_at is not None and time.time() > kill_at:
+            for q in pending:                                        # a rank stuck in a collective ignores SIGTERM
+                print(f"[bench] rank {q} did not stop after SIGTERM: killing it", file=sys.stderr, flush=True)
+                procs[q].kill()
+            kill_at = time.time() + 3600.0
         if pending:
             time.sleep(0.05)
-    out = procs[0].stdout.read() if procs[0].stdout else ""
+    reader.join(timeout=10.0)
+    out = "".join(chunks)
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     if rc == 0 and len(lines) != 1:
         print(f"[bench] expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr, flush=True)
@@ -790,13 +809,28 @@ def main() -> None:
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if not os.path.exists(_native.LIB_PATH):                     # a checkout without the (git-ignored) build product
+        # rank 0 builds; build.py renames each finished library onto its path (the debug library first), so the product
+        # library's appearance means both are complete.  The other ranks wait for it -- there is no process group yet --
+        # and give up loudly when rank 0's build failed (its marker file) or takes longer than 15 minutes.
+        failed = _native.LIB_PATH + ".build_failed"
         if local == 0:
             from onnx_image_processing_amd.build import build
-            build(verbose=False)
-        for _ in range(3600):                                    # the other ranks wait for rank 0's build (no group yet)
-            if os.path.exists(_native.LIB_PATH):
-                break
-            time.sleep(0.5)
+            try:
+                if os.path.exists(failed):
+                    os.remove(failed)
+                build(verbose=False)
+            except Exception:
+                os.makedirs(os.path.dirname(failed), exist_ok=True)
+                open(failed, "w").close()
+                raise
+        else:
+            deadline = time.time() + 900
+            while not os.path.exists(_native.LIB_PATH):
+                if os.path.exists(failed):
+                    raise SystemExit("bench.py: rank 0's build of the HIP library failed")
+                if time.time() > deadline:
+                    raise SystemExit("bench.py: timed out waiting for rank 0 to build the HIP library")
+                time.sleep(0.5)
     _native.load()
     # The process group is joined AFTER the pipeline has run once (join_group below).  Measured on MI355X with a forced
     # group of one rank: with the RCCL communicator created first, every HIP stream this process creates afterwards --

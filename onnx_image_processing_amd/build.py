@@ -96,9 +96,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         list(ex.map(run, jobs))
-    for lib, members in ((LIB, objs), (DEBUG_LIB, debug_objs)):
+    # Link to a temporary name and rename onto the final path: a process that waits for the library to appear (bench.py's
+    # other ranks, a concurrent test run) must never dlopen a file the linker is still writing.  The debug library is
+    # linked FIRST, so that the product library's appearance means both are complete.
+    for lib, members in ((DEBUG_LIB, debug_objs), (LIB, objs)):
         if jobs or force or _newer(lib, members + link_deps):
-            run([hipcc, *LINK_FLAGS, *members, "-o", lib])
+            tmp = f"{lib}.{os.getpid()}.tmp"
+            try:
+                run([hipcc, *LINK_FLAGS, *members, "-o", tmp])
+                os.replace(tmp, lib)                     # atomic on one filesystem
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
     return LIB
 
 

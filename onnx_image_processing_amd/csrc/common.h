@@ -232,7 +232,7 @@ int mi_cost_dots_bits_zeroing(const uint32_t *bits1, const uint32_t *bits2, int 
                               int normalized, uint16_t *dots, int pitch, float *row_info, float *col_info,
                               void *zero_ptr, size_t zero_bytes, mi_stream_t stream);
 // mi_sinkhorn_dots' single-launch form polls tagged granules that must start out zero: by default it clears them with
-// a memset node of its own; a caller that has them cleared by an earlier kernel of the same call (the region this
+// a zeroing kernel of its own (mi_zero_async above; never hipMemsetAsync); a caller that has them cleared by an earlier kernel of the same call (the region this
 // returns; 0 bytes when the multi-launch form will run) passes prezeroed = 1.
 size_t mi_sinkhorn_dots_handoff_region(void *workspace, int batch, int n, int m, int flags, void **region);
 int mi_sinkhorn_dots_impl(const uint16_t *dots, const float *row_info, const float *col_info, int batch, int n, int m,

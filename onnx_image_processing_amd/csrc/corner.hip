@@ -769,7 +769,8 @@ extern "C" int mi_corner_response_u8(const uint8_t *image, int n, int h, int w, 
 }
 
 // The same two calls with a tile counter: MI_TILE_COUNTER_BYTES of device memory (4-byte aligned, any content: cleared
-// by a memset node ahead of the kernel), owned by one stream at a time.  With it, large batches hand the tiles of the
+// by a small zeroing KERNEL ahead of the stencil -- common.h: mi_zero_async; never hipMemsetAsync, whose captured node
+// zeroes on the first graph replay only: tools/graph_memset_probe.py), owned by one stream at a time.  With it, large batches hand the tiles of the
 // streaming kernel out dynamically (see the schedule note at corner_stream_kernel): same scores, the launch ends
 // when the work does instead of when the youngest workgroup's fixed share does.
 extern "C" int mi_corner_response_balanced(const void *image, int pixels_are_u8, int n, int h, int w, int block_size,

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void cost_bits_kernel(const uint32_t *__restri
                                                         size_t zero_count) {
   extern __shared__ uint32_t lds_u[];
   // side job for mi_match_pairs: clear the next stage's hand-off area (the single-launch Sinkhorn's granule tags),
-  // which saves that stage its own memset node on the one-pair-per-call path; zero_count 16-byte words, all
+  // which saves that stage its own zeroing kernel (common.h: mi_zero_async) on the one-pair-per-call path; zero_count 16-byte words, all
   // workgroups share them
   if (zero_count) {
     const size_t nthreads = (size_t)gridDim.x * gridDim.y * gridDim.z * 256;

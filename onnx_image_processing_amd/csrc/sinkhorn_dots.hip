@@ -461,8 +461,8 @@ __global__ __launch_bounds__(256) void sk_exp_dots_kernel(const uint16_t *__rest
 // overwritten.  The arithmetic (operation order included) is that of sk_band_dots_kernel / sk_vcombine_dots_kernel,
 // so the duals equal the multi-launch form's bit for bit (asserted in tests/test_gpu_parity.py).
 // Requirements: n, m <= 512 and all batch * nb workgroups resident at once (batch <= SKP_MAX_BATCH: 128 workgroups
-// of 512 threads; the host checks that the grid fits the device, persist_capacity); granule tags are zeroed by a memset
-// node ahead of the launch; every spin is bounded (SKP_SPIN_LIMIT polls of >= ~2 us each: about a second) and a
+// of 512 threads; the host checks that the grid fits the device, persist_capacity); granule tags are zeroed by a small
+// kernel (common.h: mi_zero_async -- not hipMemsetAsync, see there) ahead of the launch; every spin is bounded (SKP_SPIN_LIMIT polls of >= ~2 us each: about a second) and a
 // time-out is LOUD: the call's status word is set and the workgroup writes NaN into its pair's duals before it leaves
 // (P, scores and `valid` downstream are then visibly dead; mi_mnn_from_duals_dots also reads the status word).
 constexpr int SKP_MAX_BATCH = 8;
