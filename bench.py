@@ -25,6 +25,11 @@ Beside `value` the line carries (N = 1 only, all measured after the timed region
                 sample/image_matching.py:313-328): eager and hipGraph replay, submit -> results on the device
   cpu_baseline  the reference CPU path (oracle/torch_cpu.py, pinned to the reference's recorded outputs) on this
                 box's host cores with the reference harness's 5 + 10 protocol, plus the live match-set parity
+  side_workloads  BASELINE configs[2] (c3: 1920x1080, K=1024), configs[3] (c4: the AKAZE matcher) and the visual-odometry
+                model (vo), 128 pairs per step, ten steps each: value, roofline of the dominant bandwidth-type kernel,
+                per-call times and the workload's own reference CPU path (one pair per call); `--workload c3|c3dense|c4|vo`
+                gives each a full line of its own, `--workload vo --stream` the one-pair-per-call form per rank
+  sinkhorn_schedule  the stream schedule mi_sinkhorn_dots tuned itself to during the untimed steps
 """
 from __future__ import annotations
 
@@ -509,113 +514,195 @@ def measure_u8_and_streamed(model, a8: np.ndarray, b8: np.ndarray, steps: int) -
     return u8, out
 
 
-# ----------------------------------------------------------------------------------------------- configs[2] / [3]
-def side_workload(args, rank, world, dev) -> None:
-    """BASELINE configs[2]/[3] through the same modules: value, per-call times and the roofline of the dominant
-    bandwidth-type kernel; no cpu_baseline (the metric's configuration is the default line)."""
-    from onnx_image_processing_amd import _native, distributed as D
+# ----------------------------------------------------------------------------------------------- configs[2] / [3] / VO
+SIDE_WORKLOADS = ("c3", "c3dense", "c4", "vo")
+VO_CFG = dict(block_size=5, num_pairs=512, binarize=True, soft_binarize=False, sinkhorn_iterations=20, epsilon=0.05,
+              unused_score=1.0, distance_type="l2", nms_radius=5, score_threshold=0.0, normalize_descriptors=True)
+# export_akaze_sparse_bad_sinkhorn.py defaults: 256 pairs, no binarisation, NMS radius 3
+C4_CFG = dict(num_pairs=256, binarize=False, sinkhorn_iterations=20, epsilon=0.05, unused_score=1.0, distance_type="l2",
+              nms_radius=3, score_threshold=0.0, normalize_descriptors=True, sampling_mode="nearest")
+CAM_K = [[500.0, 0.0, 320.0], [0.0, 500.0, 240.0], [0.0, 0.0, 1.0]]
+
+
+def side_model(name: str):
+    """(module, h, w, k, description, (timed entry point, kernel label, bytes per pixel, launches counted, profile prefix))"""
     from onnx_image_processing_amd.pytorch_model.feature_detection import (AKAZESparseBADSinkhornMatcher,
-                                                                           MatchExtractionWrapper,
                                                                            ShiTomasiSparseBADSinkhornMatcher)
-    from onnx_image_processing_amd.synth import synth_batch
-    B = args.pairs_per_gpu
-    if args.workload == "c3":
-        h, w, k = 1080, 1920, 1024
-        base = ShiTomasiSparseBADSinkhornMatcher(max_keypoints=k, **CFG)
-        what = "Shi-Tomasi sparse pipeline, 1920x1080, K=1024 (BASELINE configs[2])"
-        roof = ("mi_corner_response_balanced", "corner_stream_kernel<3,4> (mi_corner_response_balanced)", 8.0, 1, "corner_stream_kernel<3,4,false>")
-    elif args.workload == "c3dense":
+    k1 = ("mi_corner_response_balanced", "corner_stream_kernel<3,4> (mi_corner_response_balanced)", 8.0, "corner_stream_kernel<3,4,false>")
+    if name == "c3":
+        return (ShiTomasiSparseBADSinkhornMatcher(max_keypoints=1024, **CFG), 1080, 1920, 1024,
+                "Shi-Tomasi sparse pipeline, 1920x1080, K=1024 (BASELINE configs[2])", k1)
+    if name == "c3dense":
         # BASELINE configs[2] in its "dense BAD cost matrix" reading: the reference's ShiTomasiBADSinkhornMatcher
         # (feature_detection/shi_tomasi_bad_sinkhorn.py:162-219) -- NMS / top-k WITHOUT border margin, descriptors = the dense
         # response map sampled at the keypoints (evaluated there exactly; the 4.2 GB map is never built), K x K cost on
         # the int8 MFMA path.  Pinned to the reference at 640x480 by tests/golden/dense_c3_480x640_k512.npz.
         from onnx_image_processing_amd.pytorch_model.feature_detection import ShiTomasiBADSinkhornMatcher
-        h, w, k = 1080, 1920, 1024
         dcfg = {kk: v for kk, v in CFG.items() if kk != "sampling_mode"}
-        base = ShiTomasiBADSinkhornMatcher(max_keypoints=k, **dcfg)
-        what = ("ShiTomasiBADSinkhornMatcher (dense-BAD variant: no border margin, responses at the keypoints), 1920x1080, "
-                "K=1024, P=512 hard bits (BASELINE configs[2], dense reading)")
-        roof = ("mi_corner_response_balanced", "corner_stream_kernel<3,4> (mi_corner_response_balanced)", 8.0, 1, "corner_stream_kernel<3,4,false>")
-    elif args.workload == "vo":
+        return (ShiTomasiBADSinkhornMatcher(max_keypoints=1024, **dcfg), 1080, 1920, 1024,
+                "ShiTomasiBADSinkhornMatcher (dense-BAD variant: no border margin, responses at the keypoints), 1920x1080, "
+                "K=1024, P=512 hard bits (BASELINE configs[2], dense reading)", k1)
+    if name == "vo":
         # the visual-odometry model (SURVEY.md section 8f-2 / f-3; sample/visual_odometry.py:520-545 runs it once per frame
         # pair): Shi-Tomasi(5) + angle at the keypoints + rotation-aware BAD + Sinkhorn + essential-matrix head, Angle
         # export-CLI values (SURVEY.md section 2.2), pinned to the reference by tests/golden/angle_vo_480x640_k512.npz
         from onnx_image_processing_amd.pytorch_model.feature_detection import ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix
-        h, w, k = H, W, K
-        vcfg = dict(block_size=5, num_pairs=512, binarize=True, soft_binarize=False, sinkhorn_iterations=20, epsilon=0.05,
-                    unused_score=1.0, distance_type="l2", nms_radius=5, score_threshold=0.0, normalize_descriptors=True)
-        cam = torch.tensor([[500.0, 0.0, 320.0], [0.0, 500.0, 240.0], [0.0, 0.0, 1.0]])
-        base = ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix(K=cam, max_keypoints=k, **vcfg)
-        what = ("ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix (the VO model: Shi-Tomasi(5) + keypoint angles + oriented "
+        return (ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix(K=torch.tensor(CAM_K), max_keypoints=K, **VO_CFG), H, W, K,
+                "ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix (the VO model: Shi-Tomasi(5) + keypoint angles + oriented "
                 "BAD(512, hard) + Sinkhorn(20, eps 0.05) + essential-matrix head), 640x480, K=512, Angle export-CLI values; "
                 "per pair what sample/visual_odometry.py:520-613 consumes: E and the 100 best mutual matches "
-                "(match_and_essential: both straight from the Sinkhorn solution, P not written)")
-        roof = ("mi_corner_response_balanced", "corner_tile_kernel<5,8> (block 5: the register-staged tile kernel)", 8.0, 1, "corner_tile_kernel<5,8>")
+                "(match_and_essential: both straight from the Sinkhorn solution, P not written)",
+                ("mi_corner_response_balanced", "corner_tile_kernel<5,8> (block 5: the register-staged tile kernel)", 8.0, "corner_tile_kernel<5,8>"))
+    # c4: one scale per launch: reads the previous scale's image, writes the diffused image and the scale's score map
+    return (AKAZESparseBADSinkhornMatcher(max_keypoints=K, **C4_CFG), H, W, K,
+            "AKAZE(3 scales x 3 steps) + oriented sparse BAD(256, raw) + Sinkhorn(20, eps 0.05), 640x480, K=512 "
+            "(BASELINE configs[3], AKAZE export-CLI values)",
+            ("mi_akaze_scale", "akaze_stream_kernel<3,2,-1> (mi_akaze_scale: 3 diffusion steps + Hessian + NMS per launch, rolling window)",
+             12.0, "akaze_stream_kernel<3,2,-1>"))
+
+
+def cpu_baseline_side(name: str, threads: int | None = None) -> dict:
+    """The reference CPU path of a side workload on this host's cores: its oracle/torch_cpu.py twin (pinned to the
+    reference's recorded outputs by tests/test_oracle_golden.py::test_torch_cpu_restatement_*), ONE pair per call -- the
+    reference's own usage (sample/image_matching.py:313-328) -- 1 warm-up + 3 timed calls (a bounded sample: 2-10 s)."""
+    from onnx_image_processing_amd.synth import synth_batch
+    from oracle.torch_cpu import TorchCpuAkazePath, TorchCpuPath, TorchCpuVoPath, time_protocol
+    t = np.load(os.path.join(ROOT, "onnx_image_processing_amd", "data", "bad_tables.npz"))
+    drop = ("num_pairs", "sampling_mode", "distance_type")
+    if name in ("c3", "c3dense"):
+        h, w = 1080, 1920
+        kw = {k: v for k, v in CFG.items() if k not in drop}
+        if name == "c3dense":
+            kw["border_margin"] = 0          # shi_tomasi_bad_sinkhorn.py:200-205; the twin's sparse box means stand in for the dense map
+        path = TorchCpuPath(t["box_512"], t["thr_512"], 1024, **kw)
+        twin = "TorchCpuPath" + (" (sparse box means in place of the dense response map: a LOWER bound of the reference's cost)" if name == "c3dense" else "")
+    elif name == "vo":
+        h, w = H, W
+        path = TorchCpuVoPath(t["box_512"], t["thr_512"], K, np.asarray(CAM_K, np.float32), **{k: v for k, v in VO_CFG.items() if k not in drop})
+        twin = "TorchCpuVoPath"
     else:
-        h, w, k = H, W, K
-        # export_akaze_sparse_bad_sinkhorn.py defaults (SURVEY.md section 2.2): 256 pairs, no binarisation, NMS radius 3
-        cfg = dict(num_pairs=256, binarize=False, sinkhorn_iterations=20, epsilon=0.05, unused_score=1.0,
-                   distance_type="l2", nms_radius=3, score_threshold=0.0, normalize_descriptors=True,
-                   sampling_mode="nearest")
-        base = AKAZESparseBADSinkhornMatcher(max_keypoints=k, **cfg)
-        what = ("AKAZE(3 scales x 3 steps) + oriented sparse BAD(256, raw) + Sinkhorn(20, eps 0.05), 640x480, K=512 "
-                "(BASELINE configs[3], AKAZE export-CLI values)")
-        # one scale per launch: reads the previous scale's image, writes the diffused image and the scale's score map
-        roof = ("mi_akaze_scale", "akaze_scale_kernel (mi_akaze_scale: 3 diffusion steps + Hessian + NMS per launch)", 12.0, 1, "akaze_scale_kernel<3,2>")
+        h, w = H, W
+        path = TorchCpuAkazePath(t["box_256"], t["thr_256"], K, **{k: v for k, v in C4_CFG.items() if k not in drop})
+        twin = "TorchCpuAkazePath"
+    a, b = synth_batch(1000, 1, h, w)
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    default_threads = torch.get_num_threads()
+    if threads:
+        torch.set_num_threads(int(threads))
+    try:
+        sec = time_protocol(lambda: path.match(ta, tb, **MNN), warmup=1, timed=3)
+        used = torch.get_num_threads()
+    finally:
+        torch.set_num_threads(default_threads)
+    return {"value": 1.0 / sec, "unit": "image-pairs/sec", "cores": int(used), "kind": "port",
+            "sample": f"oracle/torch_cpu.py {twin}, one {w}x{h} pair per call (seed 1000), 1 warm-up + 3 timed calls, mean",
+            "ms_per_call": sec * 1e3}
+
+
+def run_side(name: str, B: int, steps: int, warmup: int, rank: int, world: int, dev, two_step: bool = False,
+             forced: bool = False, extras: bool = True, stream: bool = False):
+    """One side workload through the same modules as the default line: returns the JSON line (rank 0; None elsewhere).
+    stream: the VO model as its host uses it (sample/visual_odometry.py:520-545) -- ONE frame pair per call per rank,
+    replayed as a hipGraph, the host synchronised after every call, the call's record (100 matches + E) gathered to
+    rank 0 pipelined by one call; `value` = calls per second over all ranks."""
+    from onnx_image_processing_amd import _native, distributed as D
+    from onnx_image_processing_amd.pytorch_model.feature_detection import MatchExtractionWrapper
+    from onnx_image_processing_amd.synth import synth_batch
+    base, h, w, k, what, roof = side_model(name)
     begin, _ = D.shard_range(B * world, rank, world)
     a, b = synth_batch(1000 + begin, B, h, w)
     img1, img2 = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
     del a, b
     gather = PipelinedGather()
-    if args.workload == "vo":
+    if name == "vo":
         model = base.to(dev)
 
-        def step():                                   # per pair: 100 match records + the 3 x 3 essential matrix (two more rows)
-            mk1, mk2, sc, valid, e = model.match_and_essential(img1, img2, MNN["max_matches"], MNN["threshold"])
-            erows = torch.nn.functional.pad(e.reshape(B, 9), (0, 3)).reshape(B, 2, D.RECORD_FIELDS)
-            return gather(torch.cat([D.pack_records(mk1, mk2, sc, valid), erows], dim=1))
+        def records(x, y):                            # per pair: 100 match records + the 3 x 3 essential matrix (two more rows)
+            mk1, mk2, sc, valid, e = model.match_and_essential(x, y, MNN["max_matches"], MNN["threshold"])
+            erows = torch.nn.functional.pad(e.reshape(-1, 9), (0, 3)).reshape(-1, 2, D.RECORD_FIELDS)
+            return torch.cat([D.pack_records(mk1, mk2, sc, valid), erows], dim=1)
     else:
         model = MatchExtractionWrapper(base, max_matches=MNN["max_matches"], match_threshold=MNN["threshold"]).to(dev)
-        model.fuse_extraction = not args.two_step
+        model.fuse_extraction = not two_step
+
+        def records(x, y):
+            return D.pack_records(*model(x, y))
+
+    per_step = B
+    if stream:
+        if name != "vo":
+            raise SystemExit("--stream is the VO model's one-pair-per-call pattern: use it with --workload vo")
+        from onnx_image_processing_amd.graph import GraphedModule
+        graphed = GraphedModule(records, img1[:1].contiguous(), img2[:1].contiguous())
+        per_step, cursor = 1, [0]
+
+        def compute():                                # the next resident frame pair through the replayed model, host-synchronised
+            i = cursor[0] % B
+            cursor[0] += 1
+            out = graphed(img1[i:i + 1], img2[i:i + 1])
+            torch.cuda.synchronize()
+            return out
 
         def step():
-            return gather(D.pack_records(*model(img1, img2)))
+            return gather(compute())
+    else:
+        def compute():
+            return records(img1, img2)
 
-    join_group(step, gather.drain, world, getattr(args, "_forced_group", False))
+        def step():
+            return gather(compute())
+
+    join_group(step, gather.drain, world, forced)
     _native.enable_timing(True, only={roof[0]})
-    elapsed_ms, per_step, out, own_ms = run_timed(step, args.steps, args.warmup, world, dev, torch.cuda.synchronize, gather.drain)
-    facts = world_facts(own_ms, args.steps, dev)
+    elapsed_ms, per_step_ms, out, own_ms = run_timed(step, steps, warmup, world, dev, torch.cuda.synchronize, gather.drain)
+    facts = world_facts(own_ms, steps, dev)
     timed = _native.timings_ms().get(roof[0], [])
-    timed = timed[-len(timed) * args.steps // (args.steps + args.warmup):] if timed else timed     # drop the warm-up calls
+    timed = timed[-len(timed) * steps // (steps + warmup):] if timed else timed     # drop the warm-up calls
     _native.enable_timing(True)
     for _ in range(3):
         step()
     gather.drain()
     per_call = _native.timings_ms()
     _native.enable_timing(False)
+    no_gather_ms = None
+    if stream:                                        # the same loop without the gather: what the per-call collective costs
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            compute()
+        no_gather_ms = (time.perf_counter() - t0) * 1e3 / steps
+    line = None
     if rank == 0:
-        ms = elapsed_ms / args.steps
+        ms = elapsed_ms / steps
+        cfg = {"workload": what + (" -- STREAM form: one pair per call per rank, hipGraph replay, host synchronised after every "
+                                   "call, the record gathered to rank 0 per call" if stream else ""),
+               "pairs_per_gpu_per_step": per_step}
+        if name == "vo":
+            cfg["finite_essential_matrices"] = int(torch.isfinite(out[:, -2:]).all(dim=(1, 2)).sum().item())
+            cfg["mean_valid_matches_per_pair"] = float(out[:, :-2, 5].sum().item()) / (per_step * world)
+        else:
+            cfg["mean_valid_matches_per_pair"] = float(out[..., 5].sum().item()) / (per_step * world)
         line = {
-            "metric": f"image-pairs/sec ({w}x{h}, K={k})", "value": B * world / (ms * 1e-3), "unit": "image-pairs/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": what, "pairs_per_gpu_per_step": B,
-                       **({"finite_essential_matrices": int(torch.isfinite(out[:, -2:]).all(dim=(1, 2)).sum().item()),
-                           "mean_valid_matches_per_pair": float(out[:, :-2, 5].sum().item()) / (B * world)}
-                          if args.workload == "vo" else
-                          {"mean_valid_matches_per_pair": float(out[..., 5].sum().item()) / (B * world)})},
-            "step_ms": step_stats(per_step), **facts,
+            "metric": f"image-pairs/sec ({w}x{h}, K={k})", "value": per_step * world / (ms * 1e-3), "unit": "image-pairs/sec",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": cfg,
+            "step_ms": step_stats(per_step_ms), **facts,
             "kernels": {kk: {"ms_per_step": float(np.sum(v)) / 3, "calls_per_step": len(v) / 3} for kk, v in per_call.items()}}
-        if timed:
-            nbytes = roof[2] * B * h * w * roof[3]
+        if stream:
+            line["stream"] = {"calls_per_sec_per_rank": [1e3 / x for x in facts["ms_per_step_per_rank"]],
+                              "ms_per_call_with_gather": ms, "ms_per_call_without_gather_rank0": no_gather_ms,
+                              "gather_cost_ms_per_call": ms - no_gather_ms,
+                              "record_bytes_per_call": (MNN["max_matches"] + 2) * D.RECORD_FIELDS * 4}
+        if timed and not stream:
+            nbytes = roof[2] * B * h * w
             t_ms = float(np.mean(timed))
-            traffic, tsrc = pmc_traffic(roof[4], B, args.workload)
-            if args.workload == "vo" and world == 1 and not args.no_extras:
+            traffic, tsrc = pmc_traffic(roof[3], B, name)
+            if name == "vo" and world == 1 and extras:
                 # the model's own use: ONE frame pair per call (sample/visual_odometry.py:520-545), host synchronised after each
                 from onnx_image_processing_amd.graph import GraphedModule
                 one = (img1[:1].contiguous(), img2[:1].contiguous())
 
-                def timed(fn, iters=100):
+                def timed_calls(fn, iters=100):
                     for _ in range(10):
                         fn()
                     torch.cuda.synchronize()
@@ -624,18 +711,31 @@ def side_workload(args, rank, world, dev) -> None:
                         fn()
                         torch.cuda.synchronize()
                     return (time.perf_counter() - t0) / iters * 1e3
-                eager = timed(lambda: model(*one))
+                eager = timed_calls(lambda: model(*one))
                 want = [t.clone() for t in model(*one)]
                 graphed = GraphedModule(model, *one)
-                graph_ms = timed(graphed.graph.replay)
-                if not all(torch.equal(g, w) for g, w in zip(graphed.static_outputs, want)):
+                graph_ms = timed_calls(graphed.graph.replay)
+                if not all(torch.equal(g, w_) for g, w_ in zip(graphed.static_outputs, want)):
                     raise RuntimeError("latency_one_pair: the replayed graph's outputs differ from the eager call's")
                 line["latency_one_pair"] = {"eager_ms": eager, "graph_ms": graph_ms, "graph_equals_eager": True,
-                                            "what": "one 640x480 pair per call through the VO model, host synchronised after every call"}
+                                            "what": "one 640x480 pair per call through the VO model (forward: P and E), host synchronised after every call"}
             line["roofline"] = {"kernel": roof[1], "bound": "hbm", "achieved": nbytes / (t_ms * 1e-3) / 1e9,
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "traffic": traffic, "traffic_source": tsrc, "bytes_per_launch": nbytes,
                                 "bytes_per_pixel": roof[2], "ms_per_launch": t_ms}
+    del img1, img2, model
+    return line
+
+
+def side_workload(args, rank, world, dev) -> None:
+    """`--workload c3|c3dense|c4|vo`: BASELINE configs[2]/[3] and the VO model as lines of their own (value, per-call
+    times, the roofline of the dominant bandwidth-type kernel, and -- N = 1 -- the reference CPU path timed beside it)."""
+    line = run_side(args.workload, args.pairs_per_gpu, args.steps, args.warmup, rank, world, dev, two_step=args.two_step,
+                    forced=getattr(args, "_forced_group", False), extras=not args.no_extras, stream=args.stream)
+    if rank == 0:
+        if world == 1 and args.cpu_pairs > 0 and not args.stream:
+            print(f"[bench] cpu_baseline ({args.workload})", file=sys.stderr, flush=True)
+            line["cpu_baseline"] = cpu_baseline_side(args.workload)
         emit(line)
     if world > 1:
         dist.barrier()
@@ -780,6 +880,10 @@ def main() -> None:
                     help="c2 (default, the metric's configuration); c3 = 1080x1920 K=1024 sparse pipeline; c3dense = the same "
                          "size through the dense-BAD matcher; c4 = AKAZE front end; vo = the visual-odometry model "
                          "(Shi-Tomasi+Angle matcher with the essential-matrix head)")
+    ap.add_argument("--stream", action="store_true",
+                    help="with --workload vo: ONE pair per call per rank (hipGraph replay, host synchronised after every call, "
+                         "the record gathered to rank 0 per call) -- BASELINE configs[4] as sample/visual_odometry.py runs it")
+    ap.add_argument("--no-side", action="store_true", help="skip the side_workloads object of the default line (c3, c4, vo)")
     ap.add_argument("--dry-run", action="store_true",
                     help="control flow only: stubbed compute on CPU over gloo (tests the N > 1 launcher; not a measurement)")
     args = ap.parse_args()
@@ -843,8 +947,12 @@ def main() -> None:
     B = args.pairs_per_gpu
     if args.workload != "c2":
         if args.steps == 500:
-            args.steps = 50
+            args.steps = 200 if args.stream else 50
+        if args.stream and args.pairs_per_gpu == 448:
+            args.pairs_per_gpu = 16                              # resident frame pairs the per-call loop cycles through
         return side_workload(args, rank, world, dev)
+    if args.stream:
+        raise SystemExit("--stream needs --workload vo")
     begin, _ = D.shard_range(B * world, rank, world)            # this rank's pairs in the global order
     a8, b8 = synth_batch_u8(1000 + begin, B, H, W)
     # float32 [0,255] (B,1,H,W): the reference's input form, resident in HBM before timing
@@ -866,8 +974,16 @@ def main() -> None:
     # HIP events around the roofline kernel's calls only (two per step) inside the timed region; the per-stage table
     # below comes from extra steps after it, so its 24 events per step do not sit in the measurement
     join_group(step, gather.drain, world, forced)
+    # mi_sinkhorn_dots tunes its stream schedule over the first 9 calls of a shape on a stream (3 schedules x 3 trials) and
+    # collects the times on the calls after them: enough untimed steps that no trial lands in the timed region, whatever
+    # --warmup says; the schedule it settled on is reported in the line (`sinkhorn_schedule`)
+    from onnx_image_processing_amd import ops as _ops
+    for _ in range(max(0, 14 - args.warmup - (2 if (world > 1 or forced) else 0))):
+        step()
+    gather.drain()
     _native.enable_timing(True, only=None if args.single_call else {"mi_corner_response_balanced"})
     elapsed_ms, per_step, out, own_ms = run_timed(step, args.steps, args.warmup, world, dev, torch.cuda.synchronize, gather.drain)
+    schedule = _ops.sinkhorn_schedule(B, K, K, CFG["sinkhorn_iterations"])
     facts = world_facts(own_ms, args.steps, dev)
     per_call = _native.timings_ms()
     _native.enable_timing(False)
@@ -912,6 +1028,9 @@ def main() -> None:
                        "mean_valid_matches_per_pair": float(out[..., 5].sum().item()) / pairs_per_step},
             "step_ms": step_stats(per_step),
             **facts,                                             # ranks_seen / backend / ms_per_step_per_rank: what ran
+            # the stream schedule mi_sinkhorn_dots measured fastest for this shape on this stream (include/mi355x_match.h:
+            # 0 = halves on {stream, helper}, 1 = on two helpers, 2 = unsplit; -1 = still undecided)
+            "sinkhorn_schedule": schedule,
             "kernels": kernels,
         }
         if not args.single_call:
@@ -934,11 +1053,14 @@ def main() -> None:
             if "mi_sinkhorn_dots" in stages:
                 t = float(np.mean(stages["mi_sinkhorn_dots"]))
                 nb = 2.0 * B * K * K * CFG["sinkhorn_iterations"]
+                sk_traffic, sk_src = pmc_traffic("sk_band_dots_kernel", B)
                 other["mi_sinkhorn_dots (20 iterations, 2 B/element/iteration)"] = {
                     "bytes_per_call": nb, "unit": "GB/s", "achieved": nb / (t * 1e-3) / 1e9, "bound": "hbm",
                     "peak": HBM_PEAK_GBS, "frac": nb / (t * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "row_kernel_traffic_per_launch": sk_traffic, "traffic_source": sk_src,
                     "note": "memory-bound: a 22 % cut of the row kernel's VALU instructions left the call time unchanged "
-                            "(same-box A/B, DESIGN.md K6); counter traffic 136 MB per 224-pair launch"}
+                            "(same-box A/B, DESIGN.md K6); row_kernel_traffic_per_launch = FETCH + WRITE counters of one "
+                            "sk_band_dots_kernel launch (one iteration of the launch's pairs) from the committed profile"}
             if "mi_cost_dots_bits" in stages:
                 t = float(np.mean(stages["mi_cost_dots_bits"]))
                 ops_ = 2.0 * B * K * K * NUM_PAIRS
@@ -960,6 +1082,23 @@ def main() -> None:
             if args.cpu_pairs > 0:
                 stage("cpu_baseline")
                 line["cpu_baseline"] = cpu_baseline(min(args.cpu_pairs, B), records, parallel=not args.no_host_parallel)
+            if not args.no_side:
+                # BASELINE configs[2] / [3] and the VO model, driver-visible: a few steps each AFTER everything above (never
+                # part of `value`), each with its own roofline object and the reference CPU path timed beside it
+                del img1, img2
+                torch.cuda.empty_cache()
+                threads = line.get("cpu_baseline", {}).get("cores")
+                side = {}
+                for name in ("c3", "c4", "vo"):
+                    stage(f"side workload {name}")
+                    sl = run_side(name, 128, 10, 12, 0, 1, dev, extras=False)
+                    side[name] = {"metric": sl["metric"], "value": sl["value"], "unit": sl["unit"], "ms_per_step": sl["ms_per_step"],
+                                  "steps": sl["steps"], "pairs_per_gpu_per_step": 128, "workload": sl["config"]["workload"],
+                                  "mean_valid_matches_per_pair": sl["config"].get("mean_valid_matches_per_pair"),
+                                  "roofline": sl.get("roofline"), "kernels": sl["kernels"]}
+                    if args.cpu_pairs > 0:
+                        side[name]["cpu_baseline"] = cpu_baseline_side(name, threads)
+                line["side_workloads"] = side
         emit(line)
     if dist.is_initialized():
         dist.barrier()

@@ -6,7 +6,9 @@ that box's host cores: the same AT
 the reference's modules (conv2d, max_pool2d, topk, grid_sample, bmm, logsumexp), restated here from the cited lines.
 It is pinned in the build container against the fixtures the imported reference produced
 (tests/test_oracle_golden.py::test_torch_cpu_restatement_*: keypoints and BAD bits exact, P to 1e-6), so what it
-times is what the reference would do.  The numpy oracle (numpy_oracle.py) stays the exact-arithmetic checker;
+times is what the reference would do.  Round 4 adds the twins of the side workloads bench.py also times: the AKAZE
+matcher (TorchCpuAkazePath, BASELINE configs[3]) and the visual-odometry model (TorchCpuVoPath), pinned to
+tests/golden/akaze_c4_480x640_k512.npz and angle_vo_480x640_k512.npz the same way.  The numpy oracle (numpy_oracle.py) stays the exact-arithmetic checker;
 this file is the *timing* twin.
 
 Citations are paths under the reference root.
@@ -153,6 +155,198 @@ class TorchCpuPath:
     def match(self, img1: torch.Tensor, img2: torch.Tensor, max_matches: int = 100, threshold: float = 0.1):
         k1, k2, p = self.forward(img1, img2)
         return self.mutual_matches(p, k1, k2, max_matches, threshold)
+
+
+def _moment_kernels(patch_size: int, sigma: float) -> torch.Tensor:
+    # detector/akaze.py:276-291 == orientation/angle_estimation.py:97-121: x * G and y * G on a (ps, ps) grid
+    half = patch_size // 2
+    c = torch.arange(-half, half + 1, dtype=torch.float32)
+    y, x = torch.meshgrid(c, c, indexing="ij")
+    g = torch.exp(-(x ** 2 + y ** 2) / (2 * sigma ** 2))
+    return torch.stack([x * g, y * g]).unsqueeze(1)
+
+
+def orientation_map(img: torch.Tensor, kernels: torch.Tensor) -> torch.Tensor:
+    """atan2(m01, m10) of the Gaussian-weighted first moments, zero padding (detector/akaze.py:310-313,
+    orientation/angle_estimation.py:155-170): (B,1,H,W) -> (B,1,H,W)."""
+    m = F.conv2d(img, kernels, padding=kernels.shape[-1] // 2)
+    return torch.atan2(m[:, 1:2], m[:, 0:1])
+
+
+class _OrientedPath(TorchCpuPath):
+    """TorchCpuPath with the rotation-aware descriptor branch (descriptor/bad.py:487-517): the pair offsets are rotated
+    by the orientation map sampled (nearest, border) at the keypoint before the box means are sampled."""
+
+    def describe(self, img: torch.Tensor, kp: torch.Tensor, orientation: torch.Tensor | None = None) -> torch.Tensor:
+        if orientation is None:
+            return super().describe(img, kp)
+        _, _, h, w = img.shape
+        valid = (kp[:, :, 0] >= 0).float()
+        ky = kp[:, :, 0].clamp(0.0, float(h - 1))
+        kx = kp[:, :, 1].clamp(0.0, float(w - 1))
+        sy, sx = 2.0 / (h - 1 + 1e-8), 2.0 / (w - 1 + 1e-8)
+        at = torch.stack([kx * sx - 1.0, ky * sy - 1.0], dim=-1).unsqueeze(2)                  # (B, K, 1, 2)
+        theta = F.grid_sample(orientation, at, mode="nearest", padding_mode="border", align_corners=True)
+        theta = theta.squeeze(1).squeeze(-1)                                                   # (B, K)
+        cs, sn = torch.cos(theta).unsqueeze(-1), torch.sin(theta).unsqueeze(-1)
+        bank = F.conv2d(F.pad(img, (self.rmax,) * 4, mode="replicate"), self.bank)
+        x1, x2, y1, y2 = [o.squeeze(0) for o in self.off]                                      # (1, P) each
+        sample = []
+        for ox, oy in ((x1, y1), (x2, y2)):
+            dy = ox * sn + oy * cs                                                             # bad.py:505-508
+            dx = ox * cs - oy * sn
+            py, px = ky.unsqueeze(-1) + dy, kx.unsqueeze(-1) + dx
+            grid = torch.stack([px * sx - 1.0, py * sy - 1.0], dim=-1)
+            got = F.grid_sample(bank, grid, mode="nearest", padding_mode="border", align_corners=True)
+            sample.append((got * self.sel).sum(dim=1))
+        centered = sample[0] - sample[1] - self.thr
+        if not self.binarize:
+            d = centered
+        elif self.soft:
+            d = torch.sigmoid(-centered * self.temperature)
+        else:
+            d = (centered <= 0).float()
+        d = d * valid.unsqueeze(-1)
+        return F.normalize(d, p=2, dim=-1) if self.normalize else d
+
+
+class TorchCpuAkazePath(_OrientedPath):
+    """AKAZE -> NMS/top-k -> rotation-aware SparseBAD -> Sinkhorn (-> mutual NN): feature_detection/
+    akaze_sparse_bad_sinkhorn.py:148-196 with the detector of detector/akaze.py (BASELINE configs[3])."""
+
+    def __init__(self, box, thr, max_keypoints, num_scales: int = 3, diffusion_iterations: int = 3, kappa: float = 0.05,
+                 threshold: float = 0.001, akaze_nms_size: int = 5, orientation_patch_size: int = 15,
+                 orientation_sigma: float = 2.5, **kw):
+        super().__init__(box, thr, max_keypoints, **kw)
+        self.num_scales, self.steps, self.kappa = int(num_scales), int(diffusion_iterations), float(kappa)
+        self.det_thr, self.det_nms = float(threshold), int(akaze_nms_size)
+        sx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]]) / 8.0           # akaze.py:50-63
+        self.grad = torch.stack([sx, sx.t()]).unsqueeze(1)
+        kxx = torch.tensor([[1.0, -2.0, 1.0], [2.0, -4.0, 2.0], [1.0, -2.0, 1.0]]) / 16.0          # akaze.py:153-169
+        kxy = torch.tensor([[1.0, 0.0, -1.0], [0.0, 0.0, 0.0], [-1.0, 0.0, 1.0]]) / 4.0
+        self.hess = torch.stack([kxx, kxx.t(), kxy]).unsqueeze(1)
+        self.moments = _moment_kernels(orientation_patch_size, orientation_sigma)
+
+    def diffuse(self, l: torch.Tensor) -> torch.Tensor:                                        # akaze.py:98-131
+        for _ in range(self.steps):
+            g = F.conv2d(l, self.grad, padding=1)
+            mag = torch.sqrt((g * g).sum(dim=1, keepdim=True) + 1e-8)
+            flux = (1.0 / (1.0 + (mag / self.kappa) ** 2)) * g
+            l = l + 0.25 * F.conv2d(flux, self.grad, padding=1, groups=2).sum(dim=1, keepdim=True)
+        return l
+
+    def hessian_scores(self, l: torch.Tensor) -> torch.Tensor:                                 # akaze.py:190-252
+        hh = F.conv2d(l, self.hess, padding=1)
+        resp = hh[:, 0:1] * hh[:, 1:2] - hh[:, 2:3] * hh[:, 2:3]
+        peak = (resp == F.max_pool2d(resp, self.det_nms, stride=1, padding=self.det_nms // 2)).float()
+        return torch.clamp(resp * (peak * (resp > self.det_thr).float()), min=0.0)
+
+    def detect(self, img: torch.Tensor):                                                       # akaze.py:420-451
+        l, sc, ori = img.float(), [], []
+        for _ in range(self.num_scales):
+            l = self.diffuse(l)
+            sc.append(self.hessian_scores(l))
+            ori.append(orientation_map(l, self.moments))
+        sc, ori = torch.stack(sc), torch.stack(ori)
+        best = sc.amax(dim=0)
+        sel = (sc == best.unsqueeze(0)).float()
+        sel = sel / sel.sum(dim=0, keepdim=True).clamp(min=1.0)
+        return best, (ori * sel).sum(dim=0)
+
+    @torch.no_grad()
+    def forward(self, img1: torch.Tensor, img2: torch.Tensor):
+        out = []
+        for im in (img1, img2):
+            scores, ori = self.detect(im)
+            kp, _ = self.keypoints(scores.squeeze(1))
+            out.append((kp, self.describe(im, kp, ori)))
+        return out[0][0], out[1][0], self.sinkhorn(out[0][1], out[1][1])
+
+
+class TorchCpuVoPath(_OrientedPath):
+    """The visual-odometry model: Shi-Tomasi + AngleEstimator -> NMS/top-k -> rotation-aware SparseBAD -> Sinkhorn ->
+    essential matrix from the actual keypoints (feature_detection/shi_tomasi_angle_sparse_bad_sinkhorn_essential_matrix.py
+    :184-271, :325-361; geometry/essential_matrix_estimator.py:150-300).  One pair per call, as the reference requires."""
+
+    def __init__(self, box, thr, max_keypoints, cam_k: np.ndarray, patch_size: int = 15, sigma: float = 2.5, top_k: int = 3,
+                 n_iter: int = 30, n_iter_manifold: int = 10, **kw):
+        super().__init__(box, thr, max_keypoints, **kw)
+        self.moments = _moment_kernels(patch_size, sigma)
+        self.k_inv = torch.linalg.inv(torch.from_numpy(np.asarray(cam_k, np.float32)))
+        self.top_k, self.n_iter, self.n_iter_manifold = int(top_k), int(n_iter), int(n_iter_manifold)
+
+    @staticmethod
+    def _hartley(pts: torch.Tensor, wts: torch.Tensor):                                        # estimator :250-300
+        w_sum = wts.sum() + 1e-8
+        c = (wts.unsqueeze(-1) * pts).sum(dim=0) / w_sum
+        mean_dist = torch.sqrt((wts * ((pts - c) ** 2).sum(dim=-1)).sum() / w_sum + 1e-8)
+        s = math.sqrt(2.0) / (mean_dist + 1e-8)
+        t = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+        t[0, 0] = t[1, 1] = s
+        t[0, 2], t[1, 2] = -s * c[0], -s * c[1]
+        return t, s, c
+
+    def _project(self, e: torch.Tensor) -> torch.Tensor:                                       # estimator :175-248
+        b = e.t() @ e
+        v1 = torch.ones(3) / math.sqrt(3.0)
+        for _ in range(self.n_iter_manifold):
+            v1 = b @ v1
+            v1 = v1 / (v1.norm() + 1e-8)
+        bs = torch.einsum("ii", b) * torch.eye(3) - b
+        v3 = torch.ones(3) / math.sqrt(3.0)
+        for _ in range(self.n_iter_manifold):
+            v3 = bs @ v3
+            v3 = v3 / (v3.norm() + 1e-8)
+        v2 = torch.linalg.cross(v3, v1)
+        v2 = v2 / (v2.norm() + 1e-8)
+        v = torch.stack([v1, v2, v3], dim=-1)
+        v = v @ torch.diag(torch.stack([torch.tensor(1.0), torch.tensor(1.0), torch.sign(torch.det(v))]))
+        s1, s2 = (e @ v[:, 0]).norm(), (e @ v[:, 1]).norm()
+        u1, u2 = e @ v[:, 0] / (s1 + 1e-8), e @ v[:, 1] / (s2 + 1e-8)
+        u = torch.stack([u1, u2, torch.linalg.cross(u1, u2)], dim=-1)
+        u = u @ torch.diag(torch.stack([torch.tensor(1.0), torch.tensor(1.0), torch.sign(torch.det(u))]))
+        sa = (s1 + s2) / 2.0
+        return u @ torch.diag(torch.stack([sa, sa, torch.tensor(0.0)])) @ v.t()
+
+    def essential(self, p: torch.Tensor, k1: torch.Tensor, k2: torch.Tensor, s1: torch.Tensor, s2: torch.Tensor):
+        """P (K+1,K+1), keypoints (K,2) as (y,x), keypoint scores (K,) -> E (3,3)   (composite :184-271, :334-360)"""
+        n, m = p.shape[0] - 1, p.shape[1] - 1
+        q1 = (torch.cat([k1[:, 1:2], k1[:, 0:1], torch.ones(n, 1)], dim=-1) @ self.k_inv.t())[:, :2]
+        q2 = (torch.cat([k2[:, 1:2], k2[:, 0:1], torch.ones(m, 1)], dim=-1) @ self.k_inv.t())[:, :2]
+        core = p[:n, :m] * (s1 > 0).float().unsqueeze(1) * (s2 > 0).float().unsqueeze(0)
+        k = self.top_k
+        keep = (core >= torch.topk(core, k, dim=1).values[:, k - 1:k]) & (core >= torch.topk(core, k, dim=0).values[k - 1:k, :])
+        wts = core * (keep & (core > 0.01)).float()
+        t1, sc1, c1 = self._hartley(q1, wts.sum(dim=1))
+        t2, sc2, c2 = self._hartley(q2, wts.sum(dim=0))
+        f1 = torch.cat([(q1 - c1) * sc1, torch.ones(n, 1)], dim=-1)
+        f2 = torch.cat([(q2 - c2) * sc2, torch.ones(m, 1)], dim=-1)
+        f1f = (f1.unsqueeze(-1) * f1.unsqueeze(-2)).reshape(n, 9)
+        f2f = (f2.unsqueeze(-1) * f2.unsqueeze(-2)).reshape(m, 9)
+        mm = (f1f.t() @ (wts @ f2f)).reshape(3, 3, 3, 3).permute(0, 2, 1, 3).reshape(9, 9)
+        ms = torch.einsum("ii", mm) * torch.eye(9) - mm                                        # estimator :150-173
+        v = torch.ones(9) / 3.0
+        for _ in range(self.n_iter):
+            v = ms @ v
+            v = v / (v.norm() + 1e-8)
+        return self._project(t2.t() @ v.reshape(3, 3) @ t1)
+
+    @torch.no_grad()
+    def forward(self, img1: torch.Tensor, img2: torch.Tensor):
+        """(1,1,H,W) x2 -> (keypoints1, keypoints2, P, E)"""
+        out = []
+        for im in (img1, img2):
+            f = im.float()
+            kp, ks = self.keypoints(self.scores(f))
+            out.append((kp, ks, self.describe(f, kp, orientation_map(f, self.moments))))
+        p = self.sinkhorn(out[0][2], out[1][2])
+        e = self.essential(p[0], out[0][0][0], out[1][0][0], out[0][1][0], out[1][1][0])
+        return out[0][0], out[1][0], p, e
+
+    @torch.no_grad()
+    def match(self, img1: torch.Tensor, img2: torch.Tensor, max_matches: int = 100, threshold: float = 0.1):
+        k1, k2, p, e = self.forward(img1, img2)
+        return (*self.mutual_matches(p, k1, k2, max_matches, threshold), e)
 
 
 def time_protocol(fn, warmup: int = 5, timed: int = 10) -> float:

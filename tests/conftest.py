@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_perf: a RATE comparison on a real MI355X (run with -m gpu_perf on a quiet box; "
+                                       "not part of -m gpu: a busy box must not fail a correctness suite)")
     # the library is a build product (git-ignored): compile it once if this checkout does not have it yet
     from onnx_image_processing_amd import _native
     if not os.path.exists(_native.LIB_PATH):

@@ -88,6 +88,9 @@ ALLOW = _Allow({
     "gpu_oriented_vs_oracle": 0, "gpu_angle_detector_vs_reference": 0, "gpu_dense_oriented_vs_reference": 0,
     "gpu_bilinear_int_vs_oracle": 0, "gpu_bilinear_int_vs_reference": 0, "gpu_bilinear_frac_vs_oracle": 0,
     "gpu_bilinear_frac_vs_reference": 0, "gpu_bilinear_ori_vs_oracle": 0, "gpu_bilinear_ori_vs_reference": 0,
+    # the 64 bench pairs against the reference's recorded match sets (test_bench_pairs_match_sets_equal_the_reference):
+    # pairs whose ONLY difference is a tie at the max_matches cut, each checked match by match; measured 3 (rounds 3, 4)
+    "gpu_bench_pairs_cut_ties": 3,
 })
 
 

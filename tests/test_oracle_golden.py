@@ -597,3 +597,51 @@ def test_oracle_vo_model_480x640_k512_vs_reference():
         assert ok, (key, worst)
     e = O.essential_matrix_keypoints(op[0], o1[0], o2[0], o1[0][:, 0] >= 0, o2[0][:, 0] >= 0, g["cam_K"])
     assert np.abs(e - g["E"]).max() <= 1e-4 * max(1.0, np.abs(g["E"]).max())
+
+
+def test_torch_cpu_restatement_akaze_matches_the_reference_output():
+    """oracle/torch_cpu.py: TorchCpuAkazePath (what bench.py times as the reference CPU path of BASELINE configs[3])
+    reproduces the recorded reference run of AKAZESparseBADSinkhornMatcher at 640x480, K = 512, AKAZE export-CLI values:
+    keypoints exact, P to 1e-6, the same MNN match set."""
+    import torch
+    from oracle.torch_cpu import TorchCpuAkazePath
+    g = load_golden("akaze_c4_480x640_k512")
+    cfg = cfg_of(g)
+    a, b = synth_batch(int(g["seed"]), 1, int(g["h"]), int(g["w"]))
+    box, thr = bad_tables(cfg["num_pairs"])
+    kw = {k: v for k, v in cfg.items() if k not in ("num_pairs", "sampling_mode", "distance_type")}
+    path = TorchCpuAkazePath(box, thr, int(g["k"]), **kw)
+    k1, k2, p = path.forward(torch.from_numpy(a), torch.from_numpy(b))
+    assert np.array_equal(k1.numpy(), g["k1"]) and np.array_equal(k2.numpy(), g["k2"])
+    assert np.abs(p.numpy() - g["P"]).max() <= 1e-6 * max(1.0, float(np.abs(g["P"]).max()))
+    mk1, mk2, sc, valid = path.mutual_matches(p, k1, k2, **cfg_of(g, "mnn_cfg"))
+    want = {(tuple(x), tuple(y)) for x, y, v in zip(g["mk1"][0], g["mk2"][0], g["mvalid"][0]) if v}
+    assert {(tuple(x), tuple(y)) for x, y, v in zip(mk1[0].numpy(), mk2[0].numpy(), valid[0].numpy()) if v} == want
+
+
+def test_torch_cpu_restatement_vo_model_matches_the_reference_output():
+    """oracle/torch_cpu.py: TorchCpuVoPath (the reference CPU path of the visual-odometry model that bench.py times
+    beside `--workload vo`) reproduces the recorded reference run of ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix
+    at 640x480, K = 512: keypoints exact, P through the recorded rows / maxima / dustbins to 1e-6, E to 1e-5 of max|E|,
+    the same MNN match set."""
+    import torch
+    from oracle.torch_cpu import TorchCpuVoPath
+    g = load_golden("angle_vo_480x640_k512")
+    cfg = cfg_of(g)
+    k = int(g["k"])
+    a, b = synth_batch(int(g["seed"]), 1, int(g["h"]), int(g["w"]))
+    box, thr = bad_tables(cfg["num_pairs"])
+    kw = {kk: v for kk, v in cfg.items() if kk not in ("num_pairs", "sampling_mode", "distance_type", "max_keypoints")}
+    path = TorchCpuVoPath(box, thr, k, g["cam_K"], **kw)
+    k1, k2, p, e = path.forward(torch.from_numpy(a), torch.from_numpy(b))
+    assert np.array_equal(k1.numpy(), g["k1"]) and np.array_equal(k2.numpy(), g["k2"])
+    pn = p.numpy()
+    core = pn[:, :k, :k]
+    assert np.array_equal(core.argmax(2), g["P_rowarg"]) and np.array_equal(core.argmax(1), g["P_colarg"])
+    for mine, key in ((core.max(2), "P_rowmax"), (core.max(1), "P_colmax"), (pn[:, :, k], "P_dustcol"), (pn[:, k, :], "P_dustrow"),
+                      (pn[:, :8], "P_rows_0_8")):
+        assert np.abs(mine - g[key]).max() <= 1e-6 * max(1.0, float(np.abs(g[key]).max())), key
+    assert np.abs(e.numpy() - g["E"]).max() <= 1e-5 * float(np.abs(g["E"]).max())
+    mk1, mk2, sc, valid = path.mutual_matches(p, k1, k2, **cfg_of(g, "mnn_cfg"))
+    want = {(tuple(x), tuple(y)) for x, y, v in zip(g["mk1"][0], g["mk2"][0], g["mvalid"][0]) if v}
+    assert {(tuple(x), tuple(y)) for x, y, v in zip(mk1[0].numpy(), mk2[0].numpy(), valid[0].numpy()) if v} == want
