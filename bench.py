@@ -883,6 +883,9 @@ def main() -> None:
     ap.add_argument("--stream", action="store_true",
                     help="with --workload vo: ONE pair per call per rank (hipGraph replay, host synchronised after every call, "
                          "the record gathered to rank 0 per call) -- BASELINE configs[4] as sample/visual_odometry.py runs it")
+    ap.add_argument("--pin-schedule", type=int, choices=[0, 1, 2], default=None,
+                    help="pin mi_sinkhorn_dots' stream schedule on the launch stream instead of letting it tune itself "
+                         "(profiling passes: every row-kernel launch then has the same size; mi_sinkhorn_dots_set_schedule)")
     ap.add_argument("--no-side", action="store_true", help="skip the side_workloads object of the default line (c3, c4, vo)")
     ap.add_argument("--dry-run", action="store_true",
                     help="control flow only: stubbed compute on CPU over gloo (tests the N > 1 launcher; not a measurement)")
@@ -936,6 +939,9 @@ def main() -> None:
                     raise SystemExit("bench.py: timed out waiting for rank 0 to build the HIP library")
                 time.sleep(0.5)
     _native.load()
+    if args.pin_schedule is not None:
+        from onnx_image_processing_amd import ops as _pin_ops
+        _pin_ops.set_sinkhorn_schedule(args.pin_schedule)
     # The process group is joined AFTER the pipeline has run once (join_group below).  Measured on MI355X with a forced
     # group of one rank: with the RCCL communicator created first, every HIP stream this process creates afterwards --
     # torch's, and the helper stream mi_sinkhorn_dots overlaps its two half-batches on -- lands on the hardware queues

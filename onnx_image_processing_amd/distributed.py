@@ -28,6 +28,11 @@ def init(backend: str | None = None, force: bool = False) -> tuple[int, int, int
     rank, world, local = env_world()
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:          # a forced group of one outside any launcher: any free port
+            import socket
+            with socket.socket() as sck:
+                sck.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sck.getsockname()[1])
         # the pool's host driver supports only dmabuf IPC: with the legacy mode RCCL's peer-buffer exchange fails in
         # hipIpcGetMemHandle ("invalid argument").  The image exports this already; set here for a bare environment.
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -49,7 +49,7 @@ def stats_csv(sub, base, out_name, header):
 
 
 stats_csv("stats", "stats", f"{tag}_bench_kernel_stats.csv",
-          "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --cpu-pairs 0 --no-extras   "
+          "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --cpu-pairs 0 --no-extras --pin-schedule 0 --no-side   "
           f"(1 x MI355X, {PAIRS} pairs/step)")
 stats_csv("latency", "latency", f"{tag}_latency_kernel_stats.csv",
           "# rocprofv3 --kernel-trace --stats -- python3 tools/latency_trace.py --single-call --graph --iters 50   "
@@ -87,7 +87,7 @@ def side_traffic(wl, pairs):
 for wl, pairs in (("c3", 128), ("c3dense", 128), ("c4", 128), ("vo", 128)):
     side_traffic(wl, pairs)
     stats_csv(wl + "stats", wl, f"{tag}_{wl}_kernel_stats.csv",
-              f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --pairs-per-gpu {pairs} --steps 5 --warmup 2")
+              f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {wl} --pairs-per-gpu {pairs} --steps 5 --warmup 2 --no-extras --cpu-pairs 0 --pin-schedule 0")
     src = os.path.join(SRC, wl + ".json")
     if os.path.exists(src):
         open(os.path.join(dst, f"{tag}_{wl}_bench.json"), "w").write(open(src).read().strip().splitlines()[-1] + "\n")
@@ -122,7 +122,7 @@ for which, counter, sub in (("fetch", "FETCH_SIZE", "pmc_FETCH_SIZE"), ("write",
             continue                                             # kernels that do not depend on the pixel type: keep the fp32 run's
         traffic[k][counter + "_KB_raw_per_launch"] = sum(v) / len(v)
         traffic[k]["launches"] = len(v)
-out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1` (and over "
+out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1 --pin-schedule 0` (the Sinkhorn stream schedule pinned: every row-kernel launch is a half batch; and over "
                "`--frames u8` for the kernels that read uint8 pixels) "
                f"({PAIRS} pairs = 2 x {PAIRS} images per step); per-launch averages; counters are KB; reads doubled per the gfx950 "
                "note in MI355X_MICROARCH.md (FETCH_SIZE reports half of wide coalesced reads)",
@@ -139,7 +139,7 @@ json.dump(out, open(os.path.join(dst, f"{tag}_bench_pmc_traffic.json"), "w"), in
 # MFMA counters of the cost kernel (north_star: "MFMA utilisation on the cost matrix"); three separate passes
 try:
     busy, cu, mops = pmc_rows("SQ_VALU_MFMA_BUSY_CYCLES"), pmc_rows("SQ_BUSY_CU_CYCLES"), pmc_rows("SQ_INSTS_VALU_MFMA_MOPS_I8")
-    mf = {"note": "rocprofv3 --pmc, one counter per pass over `bench.py --steps 3 --warmup 1 --no-extras`; per-launch sums over the "
+    mf = {"note": "rocprofv3 --pmc, one counter per pass over `bench.py --steps 3 --warmup 1 --no-extras --pin-schedule 0`; per-launch sums over the "
                   "chip.  SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CU_CYCLES * 4 SIMDs) is the fraction of the kernel's busy "
                   "SIMD-cycles with the MFMA pipe occupied; MOPS_I8 * 512 = integer multiply-add operations issued",
           "pairs_per_gpu": PAIRS, "kernels": {}}
@@ -170,7 +170,7 @@ try:
         if k.startswith("at::") or k.startswith("__amd") or "elementwise" in k or "Cat" in k or "reduce_kernel" in k:
             continue
         acc[k][row["counter_name"]].append(row["value"])
-    sq = {"note": "rocprofv3 --pmc, eight SQ counters in one pass over `bench.py --steps 3 --warmup 1 --no-extras`; per-launch "
+    sq = {"note": "rocprofv3 --pmc, eight SQ counters in one pass over `bench.py --steps 3 --warmup 1 --no-extras --pin-schedule 0`; per-launch "
                   "sums over the chip (SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles per wave) and their "
                   "fraction of the kernel's wave cycles: WAIT_ANY = parked on s_waitcnt / barrier, WAIT_INST_ANY = ready but "
                   "not issued, ACTIVE_INST_ANY = issuing; LDS_BANK_CONFLICT / LDS_IDX_ACTIVE = conflict share of the LDS array's "
