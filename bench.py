@@ -525,10 +525,11 @@ CAM_K = [[500.0, 0.0, 320.0], [0.0, 500.0, 240.0], [0.0, 0.0, 1.0]]
 
 
 def side_model(name: str):
-    """(module, h, w, k, description, (timed entry point, kernel label, bytes per pixel, launches counted, profile prefix))"""
+    """(module, h, w, k, description, (timed entry point, kernel label, bytes per pixel, profile prefix, images per launch
+    as a multiple of the pairs per step))"""
     from onnx_image_processing_amd.pytorch_model.feature_detection import (AKAZESparseBADSinkhornMatcher,
                                                                            ShiTomasiSparseBADSinkhornMatcher)
-    k1 = ("mi_corner_response_balanced", "corner_stream_kernel<3,4> (mi_corner_response_balanced)", 8.0, "corner_stream_kernel<3,4,false>")
+    k1 = ("mi_corner_response_balanced", "corner_stream_kernel<3,4> (mi_corner_response_balanced)", 8.0, "corner_stream_kernel<3,4,false>", 1)
     if name == "c3":
         return (ShiTomasiSparseBADSinkhornMatcher(max_keypoints=1024, **CFG), 1080, 1920, 1024,
                 "Shi-Tomasi sparse pipeline, 1920x1080, K=1024 (BASELINE configs[2])", k1)
@@ -552,13 +553,15 @@ def side_model(name: str):
                 "BAD(512, hard) + Sinkhorn(20, eps 0.05) + essential-matrix head), 640x480, K=512, Angle export-CLI values; "
                 "per pair what sample/visual_odometry.py:520-613 consumes: E and the 100 best mutual matches "
                 "(match_and_essential: both straight from the Sinkhorn solution, P not written)",
-                ("mi_corner_response_balanced", "corner_tile_kernel<5,8> (block 5: the register-staged tile kernel)", 8.0, "corner_tile_kernel<5,8>"))
-    # c4: one scale per launch: reads the previous scale's image, writes the diffused image and the scale's score map
+                ("mi_corner_response_balanced", "corner_tile_kernel<5,8> (block 5: the register-staged tile kernel)", 8.0, "corner_tile_kernel<5,8>", 1))
+    # c4: one scale per launch for BOTH images of every pair (2 B images): reads the previous scale's image, writes the
+    # diffused image and the scale's score map -- 12 B/px (the middle scale, mi_akaze_scale; the first reads two batches,
+    # the last folds the selection across scales in: 4 + 4 + 4 + 8 + 1 B/px)
     return (AKAZESparseBADSinkhornMatcher(max_keypoints=K, **C4_CFG), H, W, K,
             "AKAZE(3 scales x 3 steps) + oriented sparse BAD(256, raw) + Sinkhorn(20, eps 0.05), 640x480, K=512 "
             "(BASELINE configs[3], AKAZE export-CLI values)",
-            ("mi_akaze_scale", "akaze_stream_kernel<3,2,-1> (mi_akaze_scale: 3 diffusion steps + Hessian + NMS per launch, rolling window)",
-             12.0, "akaze_stream_kernel<3,2,-1>"))
+            ("mi_akaze_scale", "akaze_stream_kernel<3,2,-1> (mi_akaze_scale: 3 diffusion steps + Hessian + NMS per launch, rolling "
+                               "window; both images of every pair in one launch)", 12.0, "akaze_stream_kernel<3,2,-1>", 2))
 
 
 def cpu_baseline_side(name: str, threads: int | None = None) -> dict:
@@ -694,7 +697,7 @@ def run_side(name: str, B: int, steps: int, warmup: int, rank: int, world: int, 
                               "gather_cost_ms_per_call": ms - no_gather_ms,
                               "record_bytes_per_call": (MNN["max_matches"] + 2) * D.RECORD_FIELDS * 4}
         if timed and not stream:
-            nbytes = roof[2] * B * h * w
+            nbytes = roof[2] * B * roof[4] * h * w
             t_ms = float(np.mean(timed))
             traffic, tsrc = pmc_traffic(roof[3], B, name)
             if name == "vo" and world == 1 and extras:

@@ -370,6 +370,12 @@ MI_API int mi_akaze_diffuse(const float *l_in, int n, int h, int w, float kappa,
 MI_API int mi_akaze_scale_fused(int iterations, int nms_size);
 MI_API int mi_akaze_scale(const float *l_in, int n, int h, int w, int iterations, float kappa, float dt, float threshold,
                    int nms_size, float *l_out, float *scores, float *tmp, mi_stream_t stream);
+/* mi_akaze_scale for the FIRST scale of two equally shaped batches (image1 / image2 of a matcher) behind one launch:
+ * l_out and scores are (2 * per_set, h, w), batch a first; every later scale then runs on one batch of twice the size.
+ * tmp: per_set * h * w floats, as for mi_akaze_scale. */
+MI_API int mi_akaze_scale_sets(const float *l_in_a, const float *l_in_b, int per_set, int h, int w, int iterations,
+                        float kappa, float dt, float threshold, int nms_size, float *l_out, float *scores, float *tmp,
+                        mi_stream_t stream);
 /* The LAST scale with AKAZE.forward's selection across scales (akaze.py:436-451) folded in: l_out as mi_akaze_scale;
  * instead of this scale's score map, best (n,h,w) = max over the num_prev (<= 7) earlier scales' maps prev_scores
  * (num_prev,n,h,w) and this scale's, and attain (n,h,w) uint8: bit s set when earlier scale s reaches that maximum,

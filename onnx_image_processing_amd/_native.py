@@ -81,6 +81,8 @@ SIGNATURES = {
     "mi_akaze_scale_fused": [c_int, c_int],
     "mi_akaze_scale": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
                        c_void_p],
+    "mi_akaze_scale_sets": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p, c_void_p,
+                            c_void_p, c_void_p],
     "mi_akaze_scale_select": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_int, c_void_p, c_void_p,
                               c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "mi_akaze_orientation_from_attain": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,

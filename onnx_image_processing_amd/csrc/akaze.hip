@@ -487,8 +487,8 @@ extern "C" int mi_akaze_scale(const float *l_in, int n, int h, int w, int iterat
   hipStream_t s = (hipStream_t)stream;
   // the streaming rolling-window form (akaze_stream.hip): even widths, 8-byte aligned maps, nms_size 3 / 5
   if (MI_HOOK(akaze_impl, 0) == 0 && mi_akaze_stream_supported(h, w, iterations, nms_size, l_in, l_out, scores))
-    return mi_akaze_scale_stream(l_in, n, h, w, iterations, kappa, dt, threshold, nms_size, l_out, scores, 0, nullptr, 0,
-                                 nullptr, stream);
+    return mi_akaze_scale_stream(l_in, nullptr, n, n, h, w, iterations, kappa, dt, threshold, nms_size, l_out, scores, 0,
+                                 nullptr, 0, nullptr, stream);
   if (mi_akaze_scale_fused(iterations, nms_size)) {
     const int halo = 2 * iterations + 1 + nms_size / 2;
     const int tx = ceil_div(w, 64 - 2 * halo), ty = ceil_div(h, AS_H);
@@ -512,6 +512,28 @@ extern "C" int mi_akaze_scale(const float *l_in, int n, int h, int w, int iterat
     cur = dst;
   }
   return mi_akaze_hessian_scores(l_out, n, h, w, threshold, nms_size, scores, stream);
+}
+
+// ---- the FIRST scale of two equally shaped batches behind one launch (image1 / image2 of a matcher): l_out and scores
+// hold the 2 * per_set images stacked, so every later scale (and NMS / top-k) runs on one batch of twice the size --
+// the streaming kernel then cuts an image into half as many row chunks (half the warm-up rows per output row)
+extern "C" int mi_akaze_scale_sets(const float *l_in_a, const float *l_in_b, int per_set, int h, int w, int iterations,
+                                   float kappa, float dt, float threshold, int nms_size, float *l_out, float *scores,
+                                   float *tmp, mi_stream_t stream) {
+  MI_ENTER();
+  if (!l_in_a || !l_in_b || !l_out || !scores) return MI_E_NULL;
+  if (per_set <= 0 || h <= 0 || w <= 0 || per_set > 0x3fffffff) return MI_E_SHAPE;
+  if (iterations <= 0 || !mi_akaze_kappa_ok(kappa) || nms_size <= 0 || (nms_size & 1) == 0 || nms_size > 15) return MI_E_PARAM;
+  const size_t half = (size_t)per_set * h * w;
+  if (l_in_a == l_out || l_in_b == l_out + half) return MI_E_NULL;
+  if (MI_HOOK(akaze_impl, 0) == 0 && mi_akaze_stream_supported(h, w, iterations, nms_size, l_in_a, l_out, scores) &&
+      ((uintptr_t)l_in_b & 7u) == 0)
+    return mi_akaze_scale_stream(l_in_a, l_in_b, per_set, 2 * per_set, h, w, iterations, kappa, dt, threshold, nms_size, l_out,
+                                 scores, 0, nullptr, 0, nullptr, stream);
+  const int e = mi_akaze_scale(l_in_a, per_set, h, w, iterations, kappa, dt, threshold, nms_size, l_out, scores, tmp, stream);
+  if (e != MI_OK) return e;
+  return mi_akaze_scale(l_in_b, per_set, h, w, iterations, kappa, dt, threshold, nms_size, l_out + half, scores + half, tmp,
+                        stream);
 }
 
 // ---- the LAST scale with AKAZE.forward's selection across scales folded in (akaze.py:436-451) ---------------------
@@ -566,8 +588,8 @@ extern "C" int mi_akaze_scale_select(const float *l_in, int n, int h, int w, int
   if (iterations <= 0 || !mi_akaze_kappa_ok(kappa) || nms_size <= 0 || (nms_size & 1) == 0 || nms_size > 15) return MI_E_PARAM;
   if (MI_HOOK(akaze_impl, 0) == 0 && mi_akaze_stream_supported(h, w, iterations, nms_size, l_in, l_out, best) &&
       num_prev <= MI_AKAZE_STREAM_MAX_PREV && ((uintptr_t)prev_scores & 7u) == 0 && ((uintptr_t)attain & 1u) == 0)
-    return mi_akaze_scale_stream(l_in, n, h, w, iterations, kappa, dt, threshold, nms_size, l_out, best, 1, prev_scores,
-                                 num_prev, attain, stream);
+    return mi_akaze_scale_stream(l_in, nullptr, n, n, h, w, iterations, kappa, dt, threshold, nms_size, l_out, best, 1,
+                                 prev_scores, num_prev, attain, stream);
   // general parameters: this scale's map into `best`, then the selection in place
   const int e = mi_akaze_scale(l_in, n, h, w, iterations, kappa, dt, threshold, nms_size, l_out, best, tmp, stream);
   if (e != MI_OK) return e;

@@ -79,7 +79,8 @@ struct StreamState {
 };
 
 struct StreamArgs {
-  const float *lin;
+  const float *lin, *lin_b;      // images [0, per_set) from lin, the rest from lin_b (two batches behind one launch)
+  int per_set;
   float *lout, *scores;
   const float *prev_scores;      // select mode: (num_prev, n, h, w)
   uint8_t *attain;               // select mode: (n, h, w)
@@ -271,7 +272,8 @@ __global__ __launch_bounds__(64) void akaze_stream_kernel(StreamArgs a) {
   StreamCtx<ITERS, NH, NP> cx;
   const size_t plane = (size_t)a.h * a.w;
   const int pbytes = (int)(plane * 4);
-  cx.in = __builtin_amdgcn_make_buffer_rsrc((void *)(a.lin + (size_t)img * plane), 0, pbytes, RSRC_FLAGS);
+  const float *in_plane = img < a.per_set ? a.lin + (size_t)img * plane : a.lin_b + (size_t)(img - a.per_set) * plane;
+  cx.in = __builtin_amdgcn_make_buffer_rsrc((void *)in_plane, 0, pbytes, RSRC_FLAGS);
   cx.lout = __builtin_amdgcn_make_buffer_rsrc((void *)(a.lout + (size_t)img * plane), 0, pbytes, RSRC_FLAGS);
   cx.sout = __builtin_amdgcn_make_buffer_rsrc((void *)(a.scores + (size_t)img * plane), 0, pbytes, RSRC_FLAGS);
   if (NP >= 0) cx.att = __builtin_amdgcn_make_buffer_rsrc((void *)(a.attain + (size_t)img * plane), 0, (int)plane, RSRC_FLAGS);
@@ -355,17 +357,18 @@ int mi_akaze_stream_supported(int h, int w, int iterations, int nms_size, const 
 
 // mode 0: scores = this scale's score map.  mode 1: scores = max over prev_scores[0..num_prev) and this scale's map,
 // attain = which of them reach it (num_prev <= MI_AKAZE_STREAM_MAX_PREV: one kernel instance per count).  Returns MI_E_PARAM when the streaming form does not apply (caller falls back).
-int mi_akaze_scale_stream(const float *l_in, int n, int h, int w, int iterations, float kappa, float dt, float threshold,
+int mi_akaze_scale_stream(const float *l_in, const float *l_in_b, int per_set, int n, int h, int w, int iterations, float kappa, float dt, float threshold,
                           int nms_size, float *l_out, float *scores, int mode, const float *prev_scores, int num_prev,
                           uint8_t *attain, mi_stream_t stream) {
   if (!mi_akaze_stream_supported(h, w, iterations, nms_size, l_in, l_out, scores)) return MI_E_PARAM;
+  if (per_set < n && (!l_in_b || ((uintptr_t)l_in_b & 7u) != 0)) return MI_E_PARAM;
   if (mode == 1 && (num_prev < 0 || num_prev > MI_AKAZE_STREAM_MAX_PREV || !attain || (num_prev > 0 && !prev_scores) ||
                     ((uintptr_t)prev_scores & 7u) != 0 || ((uintptr_t)attain & 1u) != 0))
     return MI_E_PARAM;
   const int nh = nms_size / 2, halo = 2 * iterations + 1 + nh;
   const int outw = (ST_COLS - ((halo + 1) & ~1) - halo) & ~1;
   StreamArgs a;
-  a.lin = l_in; a.lout = l_out; a.scores = scores;
+  a.lin = l_in; a.lin_b = l_in_b; a.per_set = per_set; a.lout = l_out; a.scores = scores;
   a.prev_scores = prev_scores; a.attain = attain; a.prev_stride = (size_t)n * h * w;
   a.n = n; a.h = h; a.w = w;
   a.strips = ceil_div(w, outw);

@@ -214,7 +214,7 @@ static inline bool mi_akaze_kappa_ok(float kappa) { return kappa >= MI_AKAZE_KAP
 #define MI_AKAZE_STREAM_MAX_PREV 3
 int mi_akaze_stream_supported(int h, int w, int iterations, int nms_size, const void *l_in, const void *l_out,
                               const void *scores);
-int mi_akaze_scale_stream(const float *l_in, int n, int h, int w, int iterations, float kappa, float dt, float threshold,
+int mi_akaze_scale_stream(const float *l_in, const float *l_in_b, int per_set, int n, int h, int w, int iterations, float kappa, float dt, float threshold,
                           int nms_size, float *l_out, float *scores, int mode, const float *prev_scores, int num_prev,
                           uint8_t *attain, mi_stream_t stream);
 

@@ -480,6 +480,24 @@ def akaze_scale(image: torch.Tensor, iterations: int, kappa: float, dt: float, t
     return out, scores
 
 
+def akaze_scale_sets(image1: torch.Tensor, image2: torch.Tensor, iterations: int, kappa: float, dt: float, threshold: float,
+                     nms_size: int, scores_out: torch.Tensor, image_out: torch.Tensor):
+    """The first AKAZE scale of two equally shaped batches in one launch (`mi_akaze_scale_sets`): image_out / scores_out
+    (2N,1,H,W) receive batch 1 then batch 2."""
+    a, b = _images(image1, "image1"), _images(image2, "image2")
+    if a.shape != b.shape:
+        raise RuntimeError(f"image shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
+    n, _, h, w = a.shape
+    if tuple(image_out.shape) != (2 * n, 1, h, w) or tuple(scores_out.shape) != (2 * n, 1, h, w):
+        raise RuntimeError("image_out / scores_out must be (2N,1,H,W)")
+    fused = bool(N.load().mi_akaze_scale_fused(int(iterations), int(nms_size)))
+    tmp = None if fused or iterations <= 1 else torch.empty_like(a)
+    N.call("mi_akaze_scale_sets", N.dev(a, F32, "image1"), N.dev(b, F32, "image2"), n, h, w, int(iterations), float(kappa),
+           float(dt), float(threshold), int(nms_size), N.dev(image_out, F32, "image_out"), N.dev(scores_out, F32, "scores"),
+           tmp.data_ptr() if tmp is not None else None, N.stream_ptr())
+    return image_out, scores_out
+
+
 AKAZE_KAPPA_MIN, AKAZE_KAPPA_MAX = 1e-3, 1e6          # include/mi355x_match.h MI_AKAZE_KAPPA_MIN / _MAX
 
 

@@ -127,24 +127,39 @@ class AKAZE(nn.Module):
         return scores, scale_scores, scale_images
 
     @torch.no_grad()
-    def detect_select(self, image: torch.Tensor):
+    def detect_select(self, image: torch.Tensor, image2: torch.Tensor | None = None):
         """detect() with the selection across scales folded into the last scale's launch (extension): returns
         (scores, attain (N,1,H,W) uint8 -- bit s: scale s reaches the maximum --, scale_images (S,N,1,H,W) stacked).
         Same scores as detect(); the stacked per-scale maps' last plane and the separate max-over-scales pass are never
-        written."""
+        written.  image2 (a second batch of the same shape, a matcher's other image): both batches go through ONE
+        launch per scale -- every output is for the 2N images, image's first."""
         img = ops._images(image, "image")
         n, _, h, w = img.shape
+        img2 = ops._images(image2, "image2") if image2 is not None else None
+        if img2 is not None and img2.shape != img.shape:
+            raise RuntimeError(f"image shapes differ: {tuple(img.shape)} vs {tuple(img2.shape)}")
         last = self.diffusion_layers[-1]
-        if self.num_scales > 8 or last.num_iterations <= 0 or not ops.akaze_kappa_fused(last.kappa):
-            scores, scale_scores, scale_images = self.detect(image)
+        first = self.diffusion_layers[0]
+        if self.num_scales > 8 or last.num_iterations <= 0 or not ops.akaze_kappa_fused(last.kappa) or \
+                (img2 is not None and (first.num_iterations <= 0 or not ops.akaze_kappa_fused(first.kappa))):
+            both = img if img2 is None else torch.cat([img, img2])
+            scores, scale_scores, scale_images = self.detect(both)
             return scores, ops.akaze_attain(scale_scores, scores), torch.stack(scale_images)
-        prev = torch.empty((self.num_scales - 1, n, 1, h, w), dtype=torch.float32, device=img.device)
-        scale_images = torch.empty((self.num_scales, n, 1, h, w), dtype=torch.float32, device=img.device)
+        nn_ = n if img2 is None else 2 * n
+        prev = torch.empty((max(self.num_scales - 1, 1), nn_, 1, h, w), dtype=torch.float32, device=img.device)
+        scale_images = torch.empty((self.num_scales, nn_, 1, h, w), dtype=torch.float32, device=img.device)
         cur = img
-        for i in range(self.num_scales - 1):
+        start = 0
+        if img2 is not None and self.num_scales > 1:             # the first scale reads the two batches where they lie
+            cur, _ = ops.akaze_scale_sets(img, img2, first.num_iterations, first.kappa, first.dt, self.detector.threshold,
+                                          self.detector.nms_size, scores_out=prev[0], image_out=scale_images[0])
+            start = 1
+        elif img2 is not None:
+            cur = torch.cat([img, img2])
+        for i in range(start, self.num_scales - 1):
             cur = self._scale(i, cur, prev[i], scale_images[i])
         _, scores, attain = ops.akaze_scale_select(cur, last.num_iterations, last.kappa, last.dt, self.detector.threshold,
-                                                   self.detector.nms_size, prev if self.num_scales > 1 else None,
+                                                   self.detector.nms_size, prev[:self.num_scales - 1] if self.num_scales > 1 else None,
                                                    image_out=scale_images[-1])
         return scores, attain, scale_images
 

@@ -39,21 +39,27 @@ class AKAZESparseBADSinkhornMatcher(nn.Module):
         self.matcher = SinkhornMatcher(iterations=sinkhorn_iterations, epsilon=epsilon, unused_score=unused_score,
                                        distance_type=distance_type)
 
-    def _detect_describe(self, image):
+    def _detect_describe_pair(self, image1, image2):
+        """Both images' keypoints and descriptors.  Detection -- AKAZE scales, NMS / top-k, orientation -- runs on the two
+        batches as ONE batch of 2B images (the first scale reads them where they lie: no concatenation); the
+        descriptors are evaluated per image."""
         packed = self.descriptor.mode == N.MI_BAD_HARD and self.matcher.distance_type == "l2"
-        scores, scale_scores, scale_images = self.detector.detect_select(image)
+        b = image1.shape[0]
+        scores, attain, scale_images = self.detector.detect_select(image1, image2)
         kp, _ = detect_keypoints(scores.squeeze(1), self.nms_radius, self.max_keypoints, self.score_threshold,
                                  self.border_margin)
-        theta = self.detector.orientation_at_keypoints(scale_scores, scale_images, kp)
-        d = self.descriptor.forward_bits(image, kp, theta) if packed else self.descriptor(image, kp, theta)
-        return kp, d, packed
+        theta = self.detector.orientation_at_keypoints(attain, scale_images, kp)
+        out = []
+        for im, k, t in ((image1, kp[:b], theta[:b]), (image2, kp[b:], theta[b:])):
+            k, t = k.contiguous(), t.contiguous()
+            out.append((k, self.descriptor.forward_bits(im, k, t) if packed else self.descriptor(im, k, t)))
+        return out[0][0], out[0][1], out[1][0], out[1][1], packed
 
     @torch.no_grad()
     def forward(self, image1: torch.Tensor, image2: torch.Tensor):
         if image1.shape != image2.shape:
             raise RuntimeError(f"image shapes differ: {tuple(image1.shape)} vs {tuple(image2.shape)}")
-        k1, d1, packed = self._detect_describe(image1)
-        k2, d2, _ = self._detect_describe(image2)
+        k1, d1, k2, d2, packed = self._detect_describe_pair(image1, image2)
         if packed:
             probs = self.matcher.forward_bits(d1, d2, self.descriptor.normalize_descriptors)
         else:
@@ -65,8 +71,7 @@ class AKAZESparseBADSinkhornMatcher(nn.Module):
         """forward() up to the Sinkhorn duals (see MatchExtractionWrapper)."""
         if image1.shape != image2.shape:
             raise RuntimeError(f"image shapes differ: {tuple(image1.shape)} vs {tuple(image2.shape)}")
-        k1, d1, packed = self._detect_describe(image1)
-        k2, d2, _ = self._detect_describe(image2)
+        k1, d1, k2, d2, packed = self._detect_describe_pair(image1, image2)
         if packed:
             return k1, k2, self.matcher.solve_bits(d1, d2, self.descriptor.normalize_descriptors)
         return k1, k2, self.matcher.solve(d1, d2)

@@ -870,10 +870,20 @@ def test_akaze_select_in_the_last_scale_equals_combine(mods, shape, scales):
         assert torch.equal(m.orientation_at_keypoints(attain, ims2, gpu(kp)), want_theta)
         assert torch.equal(m.orientation_at_keypoints(attain, list(ims2), gpu(kp)), want_theta)
 
+    def check_pair():                                    # two batches behind one launch per scale == each batch on its own
+        img_b = torch.flip(img, dims=[3]).contiguous()
+        sa, aa, ia = m.detect_select(img)
+        sb, ab, ib = m.detect_select(img_b)
+        s2, a2, i2 = m.detect_select(img, img_b)
+        assert torch.equal(s2, torch.cat([sa, sb])) and torch.equal(a2, torch.cat([aa, ab]))
+        assert torch.equal(i2, torch.cat([ia, ib], dim=1))
+
     check()
+    check_pair()
     with N.debug_library() as lib:
         lib.mi_debug_set(12, 1)
         check()
+        check_pair()
 
 
 def test_akaze_fast_division_is_exact(mods):
