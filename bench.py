@@ -590,8 +590,9 @@ def cpu_baseline_side(name: str, threads: int | None = None) -> dict:
     a, b = synth_batch(1000, 1, h, w)
     ta, tb = torch.from_numpy(a), torch.from_numpy(b)
     default_threads = torch.get_num_threads()
-    if threads:
-        torch.set_num_threads(int(threads))
+    # the main cpu_baseline's sweep finds torch's intra-op sweet spot at ~32 threads on the pool's hosts (its default, one
+    # thread per logical CPU, is 2-3x slower): used here when the caller has no sweep result to hand over
+    torch.set_num_threads(int(threads) if threads else max(1, min(32, physical_cores())))
     try:
         sec = time_protocol(lambda: path.match(ta, tb, **MNN), warmup=1, timed=3)
         used = torch.get_num_threads()
