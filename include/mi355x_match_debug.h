@@ -33,7 +33,9 @@ extern "C" {
  * key 11: stream schedule of mi_sinkhorn_dots for >= 64 pairs: -1 = self-tuned per caller stream (default), 0 = halves
  * on {caller's stream, helper 0}, 1 = halves on {helper 0, helper 1}, 2 = unsplit (same duals bit for bit).
  * key 12: fused AKAZE scale (mi_akaze_scale / mi_akaze_scale_select), 0 = streaming rolling-window kernel where it
- * applies (default), 1 = LDS-tile kernel / per-step kernels (same maps bit for bit). */
+ * applies (default), 1 = LDS-tile kernel / per-step kernels (same maps bit for bit).
+ * key 13: mi_sparse_bad_oriented asked for packed bits only (nearest sampling, 256 / 512 pairs), 0 = the unrolled bits
+ * kernel (default), 1 = the generic kernel (same bits). */
 MI_API int mi_debug_set(int key, int value);
 /* top-k kernel phase time stamps (100 MHz clock) of workgroup 0 into `buffer` (8 x uint64, device memory); NULL = off */
 MI_API int mi_debug_topk_stamps(void *buffer);

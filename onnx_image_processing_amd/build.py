@@ -26,7 +26,7 @@ INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 
 SOURCES = ["corner.hip", "nms.hip", "topk.hip", "bad.hip", "bad_oriented.hip", "bad_dense.hip", "orient.hip", "cost.hip", "sinkhorn.hip", "sinkhorn_dots.hip", "mnn.hip", "akaze.hip", "akaze_stream.hip", "essential.hip", "detectors.hip", "match_pairs.hip"]
 # sources that read a hook of csrc/hooks.h: compiled a second time for the debug library; every other object is shared
-HOOKED = ["corner.hip", "topk.hip", "sinkhorn.hip", "sinkhorn_dots.hip", "akaze.hip"]
+HOOKED = ["corner.hip", "topk.hip", "sinkhorn.hip", "sinkhorn_dots.hip", "akaze.hip", "bad_oriented.hip"]
 DEBUG_ONLY = ["hooks.hip"]
 # -ffp-contract=off: the corner response must not fuse a*b+c (bit parity with the reference's
 # op-by-op fp32); IEEE sqrt/div are hipcc's defaults and are relied upon.
@@ -37,7 +37,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # at half rate on gfx950 and need extra moves to pair operands (+18 % VALU slots measured).
 # -save-temps=obj keeps corner's gfx950 assembly next to its object: tests/test_k1_isa.py lints the hand-scheduled
 # region of the ticket kernel in it (CPU only).
-EXTRA_FLAGS = {"corner.hip": ["-fno-slp-vectorize", "-save-temps=obj"], "akaze.hip": ["-fno-slp-vectorize"], "akaze_stream.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"corner.hip": ["-fno-slp-vectorize", "-save-temps=obj"], "akaze.hip": ["-fno-slp-vectorize"], "akaze_stream.hip": ["-fno-slp-vectorize"],
+               "bad_oriented.hip": ["-fno-slp-vectorize"]}
 # -Bsymbolic: calls between the library's own entry points bind inside the library (two builds of the same ABI can be
 # loaded into one process -- product and debug -- without one's calls landing in the other)
 LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic",

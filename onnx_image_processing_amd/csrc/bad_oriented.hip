@@ -12,8 +12,10 @@
 // interpolates the box means of the four neighbouring centres with ATen's grid_sampler weights; the
 // non-oriented bilinear case is this kernel with angle 0 (cos = 1, sin = 0: the offsets unchanged).
 #include "common.h"
+#include "hooks.h"
 
 #include <math.h>
+#include <stdint.h>
 
 namespace {
 
@@ -35,27 +37,40 @@ __device__ __forceinline__ int nearest_centre_o(float pos, float scale, int size
 // to the SAT = double instance), half the LDS, so twice the resident keypoints per CU.
 // DESC = false (packed bits only, what the matchers ask for): no float staging array -- 14.9 instead of 19 KB of LDS per
 // keypoint, i.e. 10 instead of 8 resident keypoints per CU; the kernel is bound by how many windows are in flight.
+struct OrientedArgs {
+  const float *image;
+  int h, w;
+  const float *kpts;
+  int k;
+  const float *theta_map, *theta_kp;
+  const uint32_t *geom;
+  const float *thr;
+  int num_pairs, mode;
+  float temperature;
+  int normalize;
+  float scale_y, scale_x;
+  int bilinear;
+  float *desc;
+  uint32_t *bits;
+  uint8_t *status;
+};
+
+// One keypoint (`flat`) by one wave; `sat` = (OW + 1)^2 table entries, `vals` = 1024 floats when DESC.
 template <typename SAT, bool DESC, int OW>
-__global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restrict__ image, int h, int w,
-                                                          const float *__restrict__ kpts, int k,
-                                                          const float *__restrict__ theta_map,
-                                                          const float *__restrict__ theta_kp,
-                                                          const uint32_t *__restrict__ geom,
-                                                          const float *__restrict__ thr, int num_pairs, int mode,
-                                                          float temperature, int normalize, float scale_y,
-                                                          float scale_x, int bilinear,
-                                                          float *__restrict__ desc,
-                                                          uint32_t *__restrict__ bits,
-                                                          uint8_t *__restrict__ status) {
+__device__ __forceinline__ void bad_oriented_body(const OrientedArgs &A, int flat, SAT *sat, float *vals) {
   constexpr bool INT = sizeof(SAT) == 4;
   constexpr int OOFF = OW / 2 - 1;  // window origin = floor(k) - OOFF
   constexpr int OSP = OW + 1;       // SAT edge
   constexpr int RB = OW / 4;        // rows / columns per batch of the in-LDS prefix pass
-  __shared__ SAT sat[OSP * OSP];
-  __shared__ float vals[DESC ? 1024 : 1];
+  const float *image = A.image, *kpts = A.kpts, *theta_map = A.theta_map, *theta_kp = A.theta_kp, *thr = A.thr;
+  const uint32_t *geom = A.geom;
+  const int h = A.h, w = A.w, k = A.k, num_pairs = A.num_pairs, mode = A.mode, normalize = A.normalize;
+  const int bilinear = A.bilinear;
+  const float temperature = A.temperature, scale_y = A.scale_y, scale_x = A.scale_x;
+  float *desc = A.desc;
+  uint32_t *bits = A.bits;
+  uint8_t *status = A.status;
   const int lane = threadIdx.x;
-  const int flat = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
-  if (!INT && status && status[flat]) return;                          // the integer instance did this keypoint
   const int img = flat / k;
   const float *im = image + (size_t)img * h * w;
   const float ky_raw = kpts[(size_t)flat * 2 + 0];
@@ -203,6 +218,221 @@ __global__ __launch_bounds__(64) void bad_oriented_kernel(const float *__restric
   }
 }
 
+template <typename SAT, bool DESC, int OW>
+__global__ __launch_bounds__(64) void bad_oriented_kernel(OrientedArgs A) {
+  __shared__ SAT sat[(OW + 1) * (OW + 1)];
+  __shared__ float vals[DESC ? 1024 : 1];
+  const int flat = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  if (sizeof(SAT) != 4 && A.status && A.status[flat]) return;          // the integer instance did this keypoint
+  bad_oriented_body<SAT, DESC, OW>(A, flat, sat, vals);
+}
+
+// What the integer instances flagged status = 0 (windows that are not uint8-valued): one wave reads 64 status bytes at
+// once and runs the fp64 body for the flagged ones -- n * k / 64 short waves instead of n * k waves that each load one
+// byte and leave (15.8 us per 65 k keypoints, twice per step).
+template <bool DESC, int OW>
+__global__ __launch_bounds__(64) void bad_oriented_rest_kernel(OrientedArgs A, int total) {
+  __shared__ double sat[(OW + 1) * (OW + 1)];
+  __shared__ float vals[DESC ? 1024 : 1];
+  const int base = (int)blockIdx.x * 64;
+  const int idx = base + (int)threadIdx.x;
+  unsigned long long todo = __ballot(idx < total && A.status[idx] == 0);
+  while (todo) {                                                        // wave-uniform
+    const int b = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    bad_oriented_body<double, DESC, OW>(A, base + b, sat, vals);
+    __syncthreads();
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The matchers' instance (round 4): nearest sampling, hard bits only, uint8-valued window, 64 * GROUPS pairs.
+// Same arithmetic as bad_oriented_kernel<int, false, OW> -- the position / centre expressions are the same
+// functions -- rebuilt around what bounded that kernel (178 us per 65 k keypoints): its pair loop was a rolled loop
+// with the mode switches inside and TWO dependent global loads (geometry word, threshold) per 64 pairs, each a full
+// round trip that four waves per SIMD cannot hide.  Here
+//   * every load of the wave -- the 48 (60) window rows, the GROUPS geometry words and thresholds -- is issued before
+//     the first is used; the angle's sine / cosine and the integer thresholds floor(t * area) are computed under them;
+//   * the pair phase is straight-line code for all GROUPS groups: 8 * GROUPS table reads in flight, one
+//     integer compare per pair (d <= floor(t * area) is d <= t * area for an integer d);
+//   * the table's rows are OW + 2 = even words long, so the row pass reads and writes 8 bytes per instruction
+//     (conflict-free: 50-word stride = every even bank once per 32 lanes) -- half the LDS instructions of the first pass;
+//   * "is this window uint8-valued" costs cvt, cvt_ubyte0, compare per pixel instead of two converts and three compares.
+// A keypoint whose window is not uint8-valued is flagged status = 0 and left to bad_oriented_rest_kernel.
+// clamp(x, 0, hi) for hi >= 0 as ONE v_med3_i32 (the compiler cannot assume hi >= 0 and emits min + compare + select)
+__device__ __forceinline__ int med3_0(int x, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(hi));
+  return r;
+}
+
+__device__ __forceinline__ void rotated_positions(uint32_t q, float ky, float kx, float sin_t, float cos_t, float &p1y,
+                                                  float &p1x, float &p2y, float &p2x, int &r) {
+  const float ox1 = (float)((int)(q & 31u) - 16), ox2 = (float)((int)((q >> 5) & 31u) - 16);
+  const float oy1 = (float)((int)((q >> 10) & 31u) - 16), oy2 = (float)((int)((q >> 15) & 31u) - 16);
+  r = (int)((q >> 20) & 15u);
+  // bad.py:505-517: rot_dy = ox*sin + oy*cos ; rot_dx = ox*cos - oy*sin ; pos = kp + rot
+  p1y = ky + (ox1 * sin_t + oy1 * cos_t);
+  p1x = kx + (ox1 * cos_t - oy1 * sin_t);
+  p2y = ky + (ox2 * sin_t + oy2 * cos_t);
+  p2x = kx + (ox2 * cos_t - oy2 * sin_t);
+}
+
+template <int OW, int GROUPS>
+__global__ __launch_bounds__(64) void bad_oriented_bits_kernel(const float *__restrict__ image, int h, int w,
+                                                               const float *__restrict__ kpts, int k,
+                                                               const float *__restrict__ theta_map,
+                                                               const float *__restrict__ theta_kp,
+                                                               const uint32_t *__restrict__ geom,
+                                                               const float *__restrict__ thr, float scale_y,
+                                                               float scale_x, uint32_t *__restrict__ bits,
+                                                               uint8_t *__restrict__ status) {
+  constexpr int OOFF = OW / 2 - 1;  // window origin = floor(k) - OOFF
+  constexpr int OSP = OW + 2;       // words per table row: [0] = the zero column, [1 .. OW] the sums, [OW + 1] padding
+  __shared__ __attribute__((aligned(16))) int sat[(OW + 1) * OSP];
+  const int lane = threadIdx.x;
+  const int flat = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int img = flat / k;
+  const float *im = image + (size_t)img * h * w;
+  const float ky_raw = kpts[(size_t)flat * 2 + 0];
+  const float kx_raw = kpts[(size_t)flat * 2 + 1];
+  uint4 *brow = reinterpret_cast<uint4 *>(bits + (size_t)flat * (2 * GROUPS));
+  if (!(ky_raw >= 0.0f)) {                                              // bad.py:461: an invalid keypoint's bits are 0
+    if (lane < GROUPS / 2) brow[lane] = make_uint4(0u, 0u, 0u, 0u);
+    if (lane == 0) status[flat] = 1;
+    return;
+  }
+  const float ky = fminf(fmaxf(ky_raw, 0.0f), (float)(h - 1));          // bad.py:464-465
+  const float kx = fminf(fmaxf(kx_raw, 0.0f), (float)(w - 1));
+  const int oy = (int)floorf(ky) - OOFF, ox = (int)floorf(kx) - OOFF;
+
+  // the window: lane c owns column c; all rows in flight at once
+  // (buffer loads: the row's byte offset is a SCALAR operand -- a handful of scalar instructions per row --
+  // where flat addressing spent seven vector instructions per row on clamp, 64-bit multiply and add)
+  float px[OW];
+  {
+    const int oys = __builtin_amdgcn_readfirstlane(oy), oxs = __builtin_amdgcn_readfirstlane(ox);
+    const __amdgpu_buffer_rsrc_t plane = __builtin_amdgcn_make_buffer_rsrc((void *)im, 0, h * w * 4, 0x00020000);
+    const int voff = clampi(oxs + (lane < OW ? lane : OW - 1), 0, w - 1) * 4;
+    const int rowbytes = w * 4;
+    if (oys >= 0 && oys + OW <= h) {                                    // (wave-uniform) all rows inside: one s_add per row
+      int soff = oys * rowbytes;
+#pragma unroll
+      for (int r = 0; r < OW; ++r) {
+        px[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(plane, voff, soff, 0));
+        soff += rowbytes;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < OW; ++r)
+        px[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(plane, voff, clampi(oys + r, 0, h - 1) * rowbytes, 0));
+    }
+  }
+  uint32_t q[GROUPS];
+  float t[GROUPS];
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) { q[g] = geom[g * 64 + lane]; t[g] = thr[g * 64 + lane]; }
+  float theta;
+  if (theta_map) {                                                      // bad.py:490-500
+    const int cy = nearest_centre_o(ky, scale_y, h), cx = nearest_centre_o(kx, scale_x, w);
+    theta = theta_map[((size_t)img * h + cy) * w + cx];
+  } else {
+    theta = theta_kp[flat];
+  }
+  for (int i = lane; i < OSP; i += 64) sat[i] = 0;                      // row 0
+  if (lane <= OW) sat[lane * OSP] = 0;                                  // column 0
+  const float cos_t = cosf(theta), sin_t = sinf(theta);                 // bad.py:502-503
+
+  // uint8-valued window: every pixel has the bits of (float)(uint8)pixel (-0.0 counts as differing: fp64 path).
+  // differs |= back ^ px as ONE v_bitop3 behind an asm: written in C the optimiser turns the or-chain into 48 compares
+  // that it collects behind the last load, with 48 more live registers (129: one more than four waves per SIMD have)
+  uint32_t differs = 0u;
+  if (lane < OW) {
+    int acc = 0;
+#pragma unroll
+    for (int r = 0; r < OW; ++r) {
+      // one s_waitcnt per eight rows instead of one per row (loads return in order: row r + 7 here means rows <= r + 7)
+      if (r % 8 == 0) asm volatile("" ::"v"(px[r + 7 < OW ? r + 7 : OW - 1]));
+      const int v = (int)px[r];
+      const float back = (float)(v & 0xff);
+      asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xf6" : "+v"(differs) : "v"(back), "v"(px[r]));   // a | (b ^ c)
+      acc += v;
+      sat[(r + 1) * OSP + (lane + 1)] = acc;
+    }
+  }
+  bool tame = true;                                                     // thresholds finite and |t| <= 1e30 (else: fp64 path)
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) tame = tame && (fabsf(t[g]) <= 1e30f);
+  const bool ok = __all(differs == 0u && tame);
+  if (lane == 0) status[flat] = ok ? 1 : 0;
+  if (!ok) return;                                                      // wave-uniform
+  __syncthreads();
+  if (lane < OW) {
+    int2 *row = reinterpret_cast<int2 *>(sat + (lane + 1) * OSP);
+    int acc = 0;
+    int2 v[OSP / 2];
+#pragma unroll
+    for (int c = 0; c < OSP / 2; ++c) v[c] = row[c];
+#pragma unroll
+    for (int c = 0; c < OSP / 2; ++c) {
+      acc += v[c].x;
+      v[c].x = acc;
+      acc += v[c].y;
+      v[c].y = acc;
+      row[c] = v[c];
+    }
+  }
+  __syncthreads();
+
+  // The pair phase, straight-line for all groups.  Same values as the generic kernel's, fewer instructions:
+  //   * centre = clamp(rint(x)) in integers (= rint(clamp(x)): the bounds are integers; NaN -> 0 both ways), with the
+  //     0.5 folded into the size factor (a power of two: the same product);
+  //   * the box is placed by its CENTRE, clamped so that it lies in the window -- a no-op under the window guarantee
+  //     (header comment), like the generic kernel's four edge clamps -- and its four corners are one address + three
+  //     per-pair constants;
+  //   * bit = (d <= t * area) for the integer d = s1 - s2, decided in fp32 with the product's exact residual:
+  //     p = fl(t * a), e = fma(t, a, -p) = t * a - p exactly; d - p is exact when d and p lie within a factor two of each
+  //     other, and otherwise its rounding cannot change its sign or bring it under |e| <= ulp(p) / 2: (d - p <= e) is
+  //     (d <= t * a).  (|t| <= 1e30, checked above, keeps p finite.)  Five fp64 instructions per 64 pairs less.
+  constexpr int ROWB = OSP * 4;
+  const float half_h = 0.5f * (float)(h - 1), half_w = 0.5f * (float)(w - 1);
+  uint32_t words[2 * GROUPS];
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) {
+    float p1y, p1x, p2y, p2x;
+    int r;
+    rotated_positions(q[g], ky, kx, sin_t, cos_t, p1y, p1x, p2y, p2x, r);
+    auto centre = [](float pos, float scale, float half, int size) {
+      const float x = ((pos * scale - 1.0f) + 1.0f) * half;            // = ((g + 1) / 2) * (size - 1) of nearest_centre_o
+      return med3_0(__float2int_rn(x), size - 1);
+    };
+    const int oyr = oy + r, oxr = ox + r, amax = OW - 1 - 2 * r;        // top-left corner of the box in window coordinates
+    const int r4 = (r << 3) | 4;                                        // (2r + 1) * 4 bytes
+    const int ro = __umul24(r4, OSP), ror = ro + r4;
+    auto box_sum = [&](int cy, int cx) {
+      const int a = med3_0(cy - oyr, amax), l = med3_0(cx - oxr, amax);
+      const char *base = reinterpret_cast<const char *>(sat) + (__umul24(a, ROWB) + (l << 2));
+      const int s_al = *reinterpret_cast<const int *>(base), s_ar = *reinterpret_cast<const int *>(base + r4);
+      const int s_bl = *reinterpret_cast<const int *>(base + ro), s_br = *reinterpret_cast<const int *>(base + ror);
+      return (s_br - s_ar) - (s_bl - s_al);
+    };
+    const int s1 = box_sum(centre(p1y, scale_y, half_h, h), centre(p1x, scale_x, half_w, w));
+    const int s2 = box_sum(centre(p2y, scale_y, half_h, h), centre(p2x, scale_x, half_w, w));
+    // bad.py:567,570: bit = (mean1 - mean2 - thr <= 0) = (s1 - s2 <= t * area)
+    const float area = (float)((2 * r + 1) * (2 * r + 1));
+    const float p = t[g] * area, e = __builtin_fmaf(t[g], area, -p);
+    const bool bitv = ((float)(s1 - s2) - p) <= e;
+    const unsigned long long word = __ballot(bitv);
+    words[2 * g] = (uint32_t)word;
+    words[2 * g + 1] = (uint32_t)(word >> 32);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < GROUPS / 2; ++i)
+      brow[i] = make_uint4(words[4 * i], words[4 * i + 1], words[4 * i + 2], words[4 * i + 3]);
+  }
+}
 }  // namespace
 
 extern "C" int mi_sparse_bad_oriented(const float *image, int n, int h, int w, const float *keypoints, int k,
@@ -222,10 +452,32 @@ extern "C" int mi_sparse_bad_oriented(const float *image, int n, int h, int w, c
   const float scale_x = (float)(2.0 / ((double)(w - 1) + 1e-8));
   if (!(max_reach >= 0.0f)) return MI_E_PARAM;
   const bool small = !bilinear && max_reach > 0.0f && max_reach <= 22.5f;   // see the window note at the top
-#define BO_LAUNCH(SAT, DESC, OWIN) hipLaunchKernelGGL((bad_oriented_kernel<SAT, DESC, OWIN>), dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, image, h, w, keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, num_pairs, mode, temperature, normalize, scale_y, scale_x, bilinear ? 1 : 0, desc, bits, status)
+  OrientedArgs A{image, h, w, keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, num_pairs, mode,
+                 temperature, normalize, scale_y, scale_x, bilinear ? 1 : 0, desc, bits, status};
+  const unsigned total = (unsigned)(n * k);
+  hipStream_t s = (hipStream_t)stream;
+#define BO_LAUNCH(SAT, DESC, OWIN) hipLaunchKernelGGL((bad_oriented_kernel<SAT, DESC, OWIN>), dim3(total), dim3(64), 0, s, A)
 #define BO_PICK(SAT) do { if (desc) { if (small) BO_LAUNCH(SAT, true, 48); else BO_LAUNCH(SAT, true, 60); } else { if (small) BO_LAUNCH(SAT, false, 48); else BO_LAUNCH(SAT, false, 60); } } while (0)
-  if (status) BO_PICK(int);                                             // integer tables first, the rest in fp64
-  BO_PICK(double);
+#define BO_REST(DESC, OWIN) hipLaunchKernelGGL((bad_oriented_rest_kernel<DESC, OWIN>), dim3((total + 63u) / 64u), dim3(64), 0, s, A, (int)total)
+#define BO_BITS(OWIN, G) hipLaunchKernelGGL((bad_oriented_bits_kernel<OWIN, G>), dim3(total), dim3(64), 0, s, image, h, w, keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, scale_y, scale_x, bits, status)
+  if (!status) {                                                        // no scratch for the two-pass form: fp64 for all
+    BO_PICK(double);
+    return mi_launch_status();
+  }
+  // integer tables first (uint8-valued windows), then the flagged rest in fp64
+  const bool matcher_form = MI_HOOK(bad_oriented_impl, 0) == 0 && !bilinear && mode == MI_BAD_HARD && bits && !desc &&
+                            (num_pairs == 512 || num_pairs == 256) && (reinterpret_cast<uintptr_t>(bits) & 15u) == 0 &&
+                            (long long)h * w * 4 < 0x7fffffffLL;
+  if (matcher_form) {
+    if (num_pairs == 512) { if (small) BO_BITS(48, 8); else BO_BITS(60, 8); }
+    else { if (small) BO_BITS(48, 4); else BO_BITS(60, 4); }
+  } else {
+    BO_PICK(int);
+  }
+  if (desc) { if (small) BO_REST(true, 48); else BO_REST(true, 60); }
+  else { if (small) BO_REST(false, 48); else BO_REST(false, 60); }
+#undef BO_BITS
+#undef BO_REST
 #undef BO_PICK
 #undef BO_LAUNCH
   return mi_launch_status();

@@ -84,6 +84,30 @@ def main():
         res["bad_bits"] = (ms, 0.0)
         ms = timeit(lambda: bad(img, kp), args.iters)
         res["bad_f32"] = (ms, 4.0 * n * K * 512 / ms / 1e6)
+    if "badori" in args.which:
+        # rotation-aware BAD on per-keypoint angles (the VO / AKAZE matchers' form): unrolled bits kernel (hook 13 = 0)
+        # against the generic kernel (1), same bits
+        g = torch.Generator(device="cpu").manual_seed(5)
+        ang = ((torch.rand((n, K), generator=g) * 2 - 1) * 3.14159).to(dev)
+        for bad_o, tag in ((bad, "512"), (SparseBAD(256, binarize=True, soft_binarize=False).to(dev), "256")):
+            ref_bits = None
+            for impl, name in ((1, "generic"), (0, "bits kernel")):
+                N.use_debug_library().mi_debug_set(13, impl)
+                got = bad_o.forward_bits(img, kp, ang)
+                assert ref_bits is None or torch.equal(got, ref_bits), name
+                ref_bits = got
+                ms = timeit(lambda: bad_o.forward_bits(img, kp, ang), args.iters)
+                res[f"bad_oriented_bits {tag} ({name})"] = (ms, 0.0)
+        N.use_debug_library().mi_debug_set(13, 0)
+        fr = img.clone()
+        fr[::2, :, 100:200, 100:300] += 0.25                        # half the images: windows that are not uint8-valued
+        for impl, name in ((1, "generic"), (0, "bits kernel")):
+            N.use_debug_library().mi_debug_set(13, impl)
+            got = bad.forward_bits(fr, kp, ang)
+            assert impl == 1 or torch.equal(got, ref_bits), "fp64 rest"
+            ref_bits = got
+            res[f"bad_oriented_bits 512, part fp64 ({name})"] = (timeit(lambda: bad.forward_bits(fr, kp, ang), args.iters), 0.0)
+        N.use_debug_library().mi_debug_set(13, 0)
     bits = bad.forward_bits(img, kp)
     b2 = torch.roll(bits, 1, 0)
     if "cost" in args.which:

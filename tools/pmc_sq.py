@@ -26,7 +26,7 @@ for path in dbs:
         row = dict(zip(cols, r))
         name = row["kernel_name"]
         if want in name:
-            acc[name.split("(")[0][-90:]][row["counter_name"]].append(row["value"])
+            acc[name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-90:]][row["counter_name"]].append(row["value"])
 for k, cs in acc.items():
     n = max(len(v) for v in cs.values())
     wave = sum(cs.get("SQ_WAVE_CYCLES", [0])) / max(1, len(cs.get("SQ_WAVE_CYCLES", [0])))
