@@ -93,6 +93,28 @@ struct EmSrcP {
   __device__ __forceinline__ float at(int b, int n, int m, int i, int j, const Row &, const Col &) const {
     return p[((size_t)b * (n + 1) + i) * (size_t)(m + 1) + j];
   }
+  // the same entry in two steps: the load, and what turns the loaded word into the entry (em_band_kernel issues the
+  // loads of all its rows before it uses the first)
+  // em_band_kernel's view: which column lane `lane` handles as its q-th (0 <= q < Q), a row's loads (issued for all
+  // the wave's rows before the first is used), and what turns a loaded word into the entry
+  // (the same column order as EmSrcDots: the candidates of a row are then listed, and their weights added, in the same
+  // order from both sources -- E from P and E from dots + duals stay identical bit for bit)
+  static __device__ __forceinline__ int column(int lane, int q) { return 2 * lane + 128 * (q >> 1) + (q & 1); }
+  template <int Q> struct RawRow { float w[Q]; };
+  template <int Q> __device__ __forceinline__ RawRow<Q> load_row(int b, int n, int m, int i, int lane) const {
+    RawRow<Q> r;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) r.w[q] = p[((size_t)b * (n + 1) + i) * (size_t)(m + 1) + min(column(lane, q), m - 1)];
+    return r;
+  }
+  // the row's / column's part of the core entry (P * valid1 * valid2, :334-343) as the band kernel keeps it
+  struct BandRow { float v1; };
+  struct BandCol { float v2; };
+  __device__ __forceinline__ BandRow band_row(int, int, int, bool valid) const { return BandRow{valid ? 1.0f : 0.0f}; }
+  __device__ __forceinline__ BandCol band_col(int, int, int, bool valid) const { return BandCol{valid ? 1.0f : 0.0f}; }
+  template <int Q> __device__ __forceinline__ float value(const RawRow<Q> &r, int q, const BandRow &br, const BandCol &bc) const {
+    return (r.w[q] * br.v1) * bc.v2;
+  }
 };
 struct EmSrcDots {
   const uint16_t *dots;          // (batch, n, pitch)
@@ -107,6 +129,36 @@ struct EmSrcDots {
   __device__ __forceinline__ float at(int b, int n, int, int i, int j, const Row &r, const Col &c) const {
     const float dot = (float)dots[((size_t)b * n + i) * pitch + j];
     return mi_prob_exp((mi_z_from_dot(dot, r.ri, c.ci, neg_inv_eps) + r.u) + c.v);     // sinkhorn.py:145,206
+  }
+  // a lane handles PAIRS of adjacent columns: one 4-byte load brings two dots (half the load instructions and half the
+  // registers of the prefetched rows); pitch % 8 == 0 and a 4-byte aligned base are checked by the entry point
+  static __device__ __forceinline__ int column(int lane, int q) { return 2 * lane + 128 * (q >> 1) + (q & 1); }
+  template <int Q> struct RawRow { uint32_t w[Q / 2]; };
+  template <int Q> __device__ __forceinline__ RawRow<Q> load_row(int b, int n, int, int i, int lane) const {
+    RawRow<Q> r;
+    const uint16_t *row = dots + ((size_t)b * n + i) * pitch;
+#pragma unroll
+    for (int h = 0; h < Q / 2; ++h) r.w[h] = *reinterpret_cast<const uint32_t *>(row + min(2 * lane + 128 * h, pitch - 2));
+    return r;
+  }
+  // an invalid row / column has its dual at -inf: the entry is exp(-inf) = 0 = P * 0, a valid one's is P * 1 = P -- the
+  // core entry (:334-343) without a validity factor per row and column in registers
+  typedef Row BandRow;
+  typedef Col BandCol;
+  __device__ __forceinline__ BandRow band_row(int b, int n, int i, bool valid) const {
+    Row r = row(b, n, i);
+    r.u = valid ? r.u : -INFINITY;
+    return r;
+  }
+  __device__ __forceinline__ BandCol band_col(int b, int m, int j, bool valid) const {
+    Col c = col(b, m, j);
+    c.v = valid ? c.v : -INFINITY;
+    return c;
+  }
+  template <int Q> __device__ __forceinline__ float value(const RawRow<Q> &rr, int q, const Row &r, const Col &c) const {
+    const uint32_t w = rr.w[q >> 1];
+    const float dot = (float)((q & 1) ? (w >> 16) : (w & 0xffffu));
+    return mi_prob_exp((mi_z_from_dot(dot, r.ri, c.ci, neg_inv_eps) + r.u) + c.v);
   }
 };
 
@@ -339,7 +391,7 @@ constexpr int EM_CAND = 8;          // candidates kept per row / contributions k
 constexpr int EB_WAVES = 8, EB_RPW = 4, EB_ROWS = EB_WAVES * EB_RPW;   // band: 8 waves x 4 rows
 
 template <typename SRC, int K, int Q>   // K = top_k (1..4), Q = 64-column groups per row (8: m <= 512, 16: m <= 1024)
-__global__ __launch_bounds__(64 * EB_WAVES) void em_band_kernel(const SRC src, int n, int m,
+__global__ __launch_bounds__(64 * EB_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) void em_band_kernel(const SRC src, int n, int m,
                                                                 const uint8_t *__restrict__ valid1,
                                                                 const uint8_t *__restrict__ valid2,
                                                                 float *__restrict__ thr_row, uint8_t *__restrict__ cand_cnt,
@@ -348,51 +400,79 @@ __global__ __launch_bounds__(64 * EB_WAVES) void em_band_kernel(const SRC src, i
   __shared__ float ctop_s[EB_WAVES][64 * Q][K];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.y, band = blockIdx.x, nb = gridDim.x;
-  float v2[Q];
-  typename SRC::Col cols[Q];         // the columns' part of an entry (nothing for a materialised P)
+  typename SRC::BandCol cols[Q];     // the columns' part of an entry; a column past the matrix counts as invalid (entry 0)
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
-    const int j = lane + 64 * q;
-    v2[q] = j < m ? (valid2 ? (valid2[(size_t)b * m + j] ? 1.0f : 0.0f) : 1.0f) : 0.0f;
-    cols[q] = src.col(b, m, min(j, m - 1));
+    const int j = SRC::column(lane, q);
+    const bool ok = j < m && (valid2 ? valid2[(size_t)b * m + min(j, m - 1)] != 0 : true);
+    cols[q] = src.band_col(b, m, min(j, m - 1), ok);
   }
   float ctop[Q][K];                  // this wave's top K of every column it has seen (descending)
 #pragma unroll
   for (int q = 0; q < Q; ++q)
 #pragma unroll
     for (int k = 0; k < K; ++k) ctop[q][k] = -INFINITY;
+  // every load of the wave's rows is issued here, before the first row is worked on: row by row the kernel was a chain
+  // of dependent round trips (the candidate stores of one row keep the compiler from hoisting the next row's loads)
+  typename SRC::template RawRow<Q> raws[EB_RPW];
+  typename SRC::BandRow rowcs[EB_RPW];
+#pragma unroll
+  for (int r = 0; r < EB_RPW; ++r) {
+    const int i = min(band * EB_ROWS + wave * EB_RPW + r, n - 1);
+    rowcs[r] = src.band_row(b, n, i, valid1 ? valid1[(size_t)b * n + i] != 0 : true);
+    raws[r] = src.template load_row<Q>(b, n, m, i, lane);
+  }
+#pragma unroll
   for (int r = 0; r < EB_RPW; ++r) {
     const int i = band * EB_ROWS + wave * EB_RPW + r;
     if (i >= n) break;                                            // wave-uniform
-    const float v1 = valid1 ? (valid1[(size_t)b * n + i] ? 1.0f : 0.0f) : 1.0f;
-    const typename SRC::Row rowc = src.row(b, n, i);
-    float x[Q];
+    float x[Q];                                                   // core entries (:334-343); 0 past the matrix
+#pragma unroll
+    for (int q = 0; q < Q; ++q) x[q] = src.template value<Q>(raws[r], q, rowcs[r], cols[q]);
+    // Only entries > 0.01 can carry weight (:345-358), and after 20 Sinkhorn iterations at eps = 0.05 a row has a
+    // handful of them, so the selection works on B = {x > 0.01} alone (round 4; the kernel spent two thirds of its
+    // instructions inserting zeros into sorted lists):
+    //   * the row's candidates {x >= k-th largest of the row, x > 0.01} are {x in B, x >= k-th largest of B}, and all
+    //     of B when |B| <= K -- the k-th largest (a wave-wide selection) is only formed when |B| > K;
+    //   * a column's threshold matters for entries of B only; the column's k-th largest is the k-th largest of its B
+    //     entries when it has K of them and passes every candidate otherwise, as -inf does: the column lists take B only;
+    //   * a 64-column group without an entry of B is skipped whole (wave-uniform).
+    // thr_row / col_part hold -inf where the full lists held values <= 0.01: the same candidates, weights and E.
+    unsigned long long big[Q];
+    uint32_t nbig = 0;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      const int j = lane + 64 * q;
-      x[q] = j < m ? (src.at(b, n, m, i, j, rowc, cols[q]) * v1) * v2[q] : -INFINITY;   // core (:334-343); -inf past the matrix
+      big[q] = __ballot(x[q] > 0.01f);
+      nbig += (uint32_t)__popcll(big[q]);
     }
+    const bool select = nbig > (uint32_t)K;                        // wave-uniform
     float top[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) top[k] = -INFINITY;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      float y = x[q];
+      if (big[q] == 0ull) continue;
+      const float xb = x[q] > 0.01f ? x[q] : -INFINITY;
+      if (select) {
+        float y = xb;
 #pragma unroll
-      for (int k = 0; k < K; ++k) { const float hi = fmaxf(top[k], y), lo = fminf(top[k], y); top[k] = hi; y = lo; }
-      float z = x[q];
+        for (int k = 0; k < K; ++k) { const float hi = fmaxf(top[k], y), lo = fminf(top[k], y); top[k] = hi; y = lo; }
+      }
+      float z = xb;
 #pragma unroll
       for (int k = 0; k < K; ++k) { const float hi = fmaxf(ctop[q][k], z), lo = fminf(ctop[q][k], z); ctop[q][k] = hi; z = lo; }
     }
     float kth = -INFINITY;
+    if (select) {
 #pragma unroll
-    for (int s = 0; s < K; ++s) {                                 // pop the wave-wide maximum K times (multiplicity kept)
-      kth = wave_max_dpp(top[0]);
-      const unsigned long long owners = __ballot(top[0] == kth);
-      if (lane == __ffsll((long long)owners) - 1) {
+      for (int s = 0; s < K; ++s) {                               // pop the wave-wide maximum K times (multiplicity kept)
+        kth = wave_max_dpp(top[0]);
+        const unsigned long long owners = __ballot(top[0] == kth);
+        if (lane == __ffsll((long long)owners) - 1) {
 #pragma unroll
-        for (int k = 0; k + 1 < K; ++k) top[k] = top[k + 1];
-        top[K - 1] = -INFINITY;
+          for (int k = 0; k + 1 < K; ++k) top[k] = top[k + 1];
+          top[K - 1] = -INFINITY;
+        }
       }
     }
     // candidates of the row: entries >= the k-th largest that can carry weight at all (> 0.01, :345-358)
@@ -400,11 +480,12 @@ __global__ __launch_bounds__(64 * EB_WAVES) void em_band_kernel(const SRC src, i
     const size_t cbase = ((size_t)b * n + i) * EM_CAND;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
+      if (big[q] == 0ull) continue;
       const bool c = x[q] >= kth && x[q] > 0.01f;
       const unsigned long long mk = __ballot(c);
       if (c) {
         const uint32_t slot = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-        if (slot < (uint32_t)EM_CAND) { cand_j[cbase + slot] = lane + 64 * q; cand_x[cbase + slot] = x[q]; }
+        if (slot < (uint32_t)EM_CAND) { cand_j[cbase + slot] = SRC::column(lane, q); cand_x[cbase + slot] = x[q]; }
       }
       cnt += (uint32_t)__popcll(mk);
     }
@@ -417,7 +498,7 @@ __global__ __launch_bounds__(64 * EB_WAVES) void em_band_kernel(const SRC src, i
 #pragma unroll
   for (int q = 0; q < Q; ++q)
 #pragma unroll
-    for (int k = 0; k < K; ++k) ctop_s[wave][lane + 64 * q][k] = ctop[q][k];
+    for (int k = 0; k < K; ++k) ctop_s[wave][SRC::column(lane, q)][k] = ctop[q][k];
   __syncthreads();
   for (int j = threadIdx.x; j < m; j += 64 * EB_WAVES) {
     float top[K];
@@ -427,6 +508,7 @@ __global__ __launch_bounds__(64 * EB_WAVES) void em_band_kernel(const SRC src, i
 #pragma unroll
       for (int k2 = 0; k2 < K; ++k2) {
         float y = ctop_s[w][j][k2];
+        if (y == -INFINITY) break;                                // descending lists, mostly empty
 #pragma unroll
         for (int k = 0; k < K; ++k) { const float hi = fmaxf(top[k], y), lo = fminf(top[k], y); top[k] = hi; y = lo; }
       }
@@ -679,7 +761,7 @@ extern "C" int mi_essential_matrix_dots(const uint16_t *dots, const float *row_i
                                         void *workspace, size_t workspace_bytes, mi_stream_t stream) {
   MI_ENTER();
   if (!dots || !row_info || !col_info || !u || !v) return MI_E_NULL;
-  if (pitch < m || pitch % 8 != 0) return MI_E_ALIGN;
+  if (pitch < m || pitch % 8 != 0 || (reinterpret_cast<uintptr_t>(dots) & 3u) != 0) return MI_E_ALIGN;
   if (!(epsilon >= MI_DOTS_MIN_EPSILON)) return MI_E_PARAM;
   EmSrcDots src;
   src.dots = dots;
