@@ -289,33 +289,48 @@ __device__ void em_dense_front(EmShared &S, const SRC src, int b, int n, int m,
   __syncthreads();
 }
 
-// The serial tail (one thread): 9x9 minimum eigenvector, denormalisation, manifold projection -> E of pair b
+// The tail, by ONE WAVE (round 4; it was one thread: 30 power iterations of a 9x9 matrix-vector product, a norm and nine
+// divisions in one lane's dependent chain -- about half of em_sparse_kernel's 51 us).  Lane a < 9 holds row a of the
+// shifted matrix and forms element a of the product; the nine elements go to every lane through v_readlane, every lane
+// adds their squares in the serial order, lane a divides its element, and the new vector is read back the same way:
+// per value the same operations in the same order as the one-thread form, a quarter of the instructions per iteration.
+// The two 3x3 power iterations of the manifold projection run side by side in lanes 0 and 1.  Everything else is
+// computed redundantly by all lanes; lane 0 writes E.
+__device__ __forceinline__ float lane_value(float x, int src_lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src_lane));
+}
 __device__ void em_solve(const EmShared &S, int b, int n_iter, int n_iter_manifold, float *__restrict__ e_out) {
   const float *mflat = S.mflat, *hart = S.hart;
+  const int lane = threadIdx.x & 63;
 
   // ---- 9x9 minimum eigenvector by shifted power iteration (:150-173)
-  float mm[9][9];
+  const int a = lane < 9 ? lane : 8;
+  float row[9];
   float lam = 0.0f;
-  for (int a = 0; a < 9; ++a)
-    for (int c = 0; c < 9; ++c) {
-      const int pp = a / 3, qq = a % 3, rr = c / 3, ss = c % 3;   // M_mat[3p+q][3r+s] = M_flat[3p+r][3q+s]  (:414)
-      mm[a][c] = mflat[(3 * pp + rr) * 9 + (3 * qq + ss)];
-    }
-  for (int a = 0; a < 9; ++a) lam += mm[a][a];
-  for (int a = 0; a < 9; ++a)
-    for (int c = 0; c < 9; ++c) mm[a][c] = (a == c ? lam : 0.0f) - mm[a][c];
-  float v[9], nv[9];
-  for (int a = 0; a < 9; ++a) v[a] = 1.0f / 3.0f;
+#pragma unroll
+  for (int d = 0; d < 9; ++d) {                                    // trace: M_mat[d][d] = M_flat[3p+p][3q+q]
+    const int pp = d / 3, qq = d % 3;
+    lam += mflat[(3 * pp + pp) * 9 + (3 * qq + qq)];
+  }
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    const int pp = a / 3, qq = a % 3, rr = c / 3, ss = c % 3;     // M_mat[3p+q][3r+s] = M_flat[3p+r][3q+s]  (:414)
+    row[c] = (a == c ? lam : 0.0f) - mflat[(3 * pp + rr) * 9 + (3 * qq + ss)];
+  }
+  float v[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) v[c] = 1.0f / 3.0f;
   for (int it = 0; it < n_iter; ++it) {
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) s += row[c] * v[c];
     float ss = 0.0f;
-    for (int a = 0; a < 9; ++a) {
-      float s = 0.0f;
-      for (int c = 0; c < 9; ++c) s += mm[a][c] * v[c];
-      nv[a] = s;
-      ss += s * s;
-    }
+#pragma unroll
+    for (int x = 0; x < 9; ++x) { const float sx = lane_value(s, x); ss += sx * sx; }
     const float nn = sqrtf(ss) + 1e-8f;
-    for (int a = 0; a < 9; ++a) v[a] = nv[a] / nn;
+    const float mine = s / nn;
+#pragma unroll
+    for (int x = 0; x < 9; ++x) v[x] = lane_value(mine, x);
   }
   // ---- denormalise: E = T2^T E_raw T1 (:424)
   const float t1[3][3] = {{hart[2], 0.0f, -hart[2] * hart[0]}, {0.0f, hart[2], -hart[2] * hart[1]}, {0.0f, 0.0f, 1.0f}};
@@ -334,8 +349,13 @@ __device__ void em_solve(const EmShared &S, int b, int n_iter, int n_iter_manifo
     for (int c = 0; c < 3; ++c) bs[r][c] = (r == c ? lam3 : 0.0f) - bm[r][c];
   const float inv_sqrt3 = 1.0f / sqrtf(3.0f);
   float va[3] = {inv_sqrt3, inv_sqrt3, inv_sqrt3}, vc[3] = {inv_sqrt3, inv_sqrt3, inv_sqrt3}, vb[3], w3[3];
-  for (int it = 0; it < n_iter_manifold; ++it) { matvec3(bm, va, w3); va[0] = w3[0]; va[1] = w3[1]; va[2] = w3[2]; unit3(va); }
-  for (int it = 0; it < n_iter_manifold; ++it) { matvec3(bs, vc, w3); vc[0] = w3[0]; vc[1] = w3[1]; vc[2] = w3[2]; unit3(vc); }
+  {
+    float bx[3][3], vx[3] = {inv_sqrt3, inv_sqrt3, inv_sqrt3};      // lane 0: bm -> va; every other lane: bs -> vc
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) bx[r][c] = lane == 0 ? bm[r][c] : bs[r][c];
+    for (int it = 0; it < n_iter_manifold; ++it) { matvec3(bx, vx, w3); vx[0] = w3[0]; vx[1] = w3[1]; vx[2] = w3[2]; unit3(vx); }
+    for (int r = 0; r < 3; ++r) { va[r] = lane_value(vx[r], 0); vc[r] = lane_value(vx[r], 1); }
+  }
   cross3(vc, va, vb);
   unit3(vb);
   float vm[3][3] = {{va[0], vb[0], vc[0]}, {va[1], vb[1], vc[1]}, {va[2], vb[2], vc[2]}};   // columns v1 v2 v3
@@ -355,8 +375,9 @@ __device__ void em_solve(const EmShared &S, int b, int n_iter, int n_iter_manifo
   for (int r = 0; r < 3; ++r) um[r][2] *= sgn_u;
   // E = U diag(s, s, 0) V^T
   float *out = e_out + (size_t)b * 9;
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) out[r * 3 + c] = (um[r][0] * s_avg) * vm[c][0] + (um[r][1] * s_avg) * vm[c][1];
+  if (lane == 0)
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) out[r * 3 + c] = (um[r][0] * s_avg) * vm[c][0] + (um[r][1] * s_avg) * vm[c][1];
 }
 
 template <typename SRC>
@@ -368,7 +389,7 @@ __global__ __launch_bounds__(EM_T) void em_estimate_kernel(const SRC src, int n,
                                                            int n_iter_manifold, float *__restrict__ e_out) {
   __shared__ EmShared S;
   em_dense_front(S, src, (int)blockIdx.x, n, m, pts1, pts2, valid1, valid2, top_k);
-  if (threadIdx.x == 0) em_solve(S, (int)blockIdx.x, n_iter, n_iter_manifold, e_out);
+  if (threadIdx.x < 64) em_solve(S, (int)blockIdx.x, n_iter, n_iter_manifold, e_out);   // wave 0
 }
 
 // ---- round 3: the same head spread over the chip --------------------------------------------------------------------
@@ -532,45 +553,79 @@ __global__ __launch_bounds__(EM_T) void em_sparse_kernel(const SRC src, int n, i
   __shared__ short ci[EM_MAXN][EM_CAND];        // ... and the rows they come from
   __shared__ int ccount[EM_MAXN];
   __shared__ float rmom[EM_MAXN][6];            // per row: sum_j w f2x^2, w f2x f2y, w f2x, w f2y^2, w f2y, w
+  __shared__ float2 p1s[EM_MAXN], p2s[EM_MAXN]; // the pair's points (read four times below)
   __shared__ int s_dense;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int b = blockIdx.x;
-  const float *q1 = pts1 + (size_t)b * n * 2, *q2 = pts2 + (size_t)b * m * 2;
+  // One workgroup per pair: the kernel's time is its chain of dependent memory round trips, not its arithmetic (128
+  // workgroups on 256 CUs).  So everything a thread will need from global memory is requested HERE, at once (round 4):
+  // its row's candidates (thread t = row t: n <= EM_T), the pair's points, and -- below, eight bands at a time -- the
+  // bands' column lists.
+  const bool has_row = t < n;
+  const size_t rbase = (size_t)b * n + (has_row ? t : 0);
+  const int cnt_raw = has_row ? (int)cand_cnt[rbase] : 0;
+  int cj[EM_CAND];
+  float cx[EM_CAND];
+  {
+    const int4 *pj = reinterpret_cast<const int4 *>(cand_j + rbase * EM_CAND);
+    const float4 *px = reinterpret_cast<const float4 *>(cand_x + rbase * EM_CAND);
+#pragma unroll
+    for (int c = 0; c < EM_CAND / 4; ++c) {
+      const int4 vj = pj[c];
+      const float4 vx = px[c];
+      cj[4 * c] = vj.x; cj[4 * c + 1] = vj.y; cj[4 * c + 2] = vj.z; cj[4 * c + 3] = vj.w;
+      cx[4 * c] = vx.x; cx[4 * c + 1] = vx.y; cx[4 * c + 2] = vx.z; cx[4 * c + 3] = vx.w;
+    }
+  }
+  if (t < n) p1s[t] = make_float2(pts1[((size_t)b * n + t) * 2], pts1[((size_t)b * n + t) * 2 + 1]);
+  if (t < m) p2s[t] = make_float2(pts2[((size_t)b * m + t) * 2], pts2[((size_t)b * m + t) * 2 + 1]);
+  const float *q1 = reinterpret_cast<const float *>(p1s), *q2 = reinterpret_cast<const float *>(p2s);
   if (t == 0) s_dense = 0;
   for (int j = t; j < m; j += EM_T) ccount[j] = 0;
-  __syncthreads();
-  // column thresholds: the k-th largest of the bands' top-K lists (their union holds the column's top K with multiplicity)
+  // column thresholds: the k-th largest of the bands' top-K lists (their union holds the column's top K with
+  // multiplicity; an empty slot is -inf)
   for (int j = t; j < m; j += EM_T) {
     float top[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) top[k] = -INFINITY;
-    for (int band = 0; band < nb; ++band)
+    for (int band0 = 0; band0 < nb; band0 += 8) {
+      float y[8][K];
 #pragma unroll
-      for (int k2 = 0; k2 < K; ++k2) {
-        float y = col_part[(((size_t)b * nb + band) * m + j) * K + k2];
+      for (int d = 0; d < 8; ++d)
 #pragma unroll
-        for (int k = 0; k < K; ++k) { const float hi = fmaxf(top[k], y), lo = fminf(top[k], y); top[k] = hi; y = lo; }
-      }
+        for (int k2 = 0; k2 < K; ++k2)
+          y[d][k2] = band0 + d < nb ? col_part[(((size_t)b * nb + band0 + d) * m + j) * K + k2] : -INFINITY;
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+#pragma unroll
+        for (int k2 = 0; k2 < K; ++k2) {
+          float z = y[d][k2];
+          if (z == -INFINITY) continue;
+#pragma unroll
+          for (int k = 0; k < K; ++k) { const float hi = fmaxf(top[k], z), lo = fminf(top[k], z); top[k] = hi; z = lo; }
+        }
+    }
     S.thr_col[j] = top[K - 1];
   }
-  for (int i = t; i < n; i += EM_T)
-    if (cand_cnt[(size_t)b * n + i] == 255) s_dense = 1;          // more tied candidates than kept: dense front
   __syncthreads();
+  if (cnt_raw == 255) s_dense = 1;                                // more tied candidates than kept: dense front
+  const int cnt = cnt_raw == 255 ? 0 : cnt_raw;
   // weights of the candidates; a row's sum; every weighted entry filed under its column
-  for (int i = t; i < n; i += EM_T) {
-    const int cnt = cand_cnt[(size_t)b * n + i] == 255 ? 0 : (int)cand_cnt[(size_t)b * n + i];
+  if (has_row) {
     float s = 0.0f;
-    for (int c = 0; c < cnt; ++c) {
-      const int j = cand_j[((size_t)b * n + i) * EM_CAND + c];
-      const float x = cand_x[((size_t)b * n + i) * EM_CAND + c];
-      const float w = x >= S.thr_col[j] ? x : 0.0f;              // (>= thr_row and > 0.01 hold for every candidate)
+#pragma unroll
+    for (int c = 0; c < EM_CAND; ++c) {
+      if (c >= cnt) break;
+      const int j = cj[c];
+      const float w = cx[c] >= S.thr_col[j] ? cx[c] : 0.0f;      // (>= thr_row and > 0.01 hold for every candidate)
+      cx[c] = w;                                                  // from here on: the weight
       s += w;
       if (w != 0.0f) {
         const int slot = atomicAdd(&ccount[j], 1);
-        if (slot < EM_CAND) { cw[j][slot] = w; ci[j][slot] = (short)i; } else s_dense = 1;
+        if (slot < EM_CAND) { cw[j][slot] = w; ci[j][slot] = (short)t; } else s_dense = 1;
       }
     }
-    S.w1[i] = s;
+    S.w1[t] = s;
   }
   __syncthreads();
   if (s_dense) {                                                  // workgroup-uniform
@@ -579,11 +634,11 @@ __global__ __launch_bounds__(EM_T) void em_sparse_kernel(const SRC src, int n, i
   } else {
     // column sums: a column's contributions arrive in any order; they are ADDED in ascending row order
     for (int j = t; j < m; j += EM_T) {
-      const int cnt = ccount[j];
+      const int ccnt = ccount[j];
       float wv[EM_CAND];
       short iv[EM_CAND];
 #pragma unroll
-      for (int c = 0; c < EM_CAND; ++c) { wv[c] = c < cnt ? cw[j][c] : 0.0f; iv[c] = c < cnt ? ci[j][c] : (short)0x7fff; }
+      for (int c = 0; c < EM_CAND; ++c) { wv[c] = c < ccnt ? cw[j][c] : 0.0f; iv[c] = c < ccnt ? ci[j][c] : (short)0x7fff; }
 #pragma unroll
       for (int a2 = 1; a2 < EM_CAND; ++a2)                        // insertion sort by row (<= 8 entries, registers)
 #pragma unroll
@@ -604,17 +659,17 @@ __global__ __launch_bounds__(EM_T) void em_sparse_kernel(const SRC src, int n, i
     }
     __syncthreads();
     // per-row moment sums over the row's weighted candidates (:401-414, inner factor W F2)
-    for (int i = t; i < n; i += EM_T) {
-      const int cnt = (int)cand_cnt[(size_t)b * n + i];
+    if (has_row) {
       float sxx = 0.0f, sxy = 0.0f, sx = 0.0f, syy = 0.0f, sy = 0.0f, s1 = 0.0f;
-      for (int c = 0; c < cnt; ++c) {
-        const int j = cand_j[((size_t)b * n + i) * EM_CAND + c];
-        const float xv = cand_x[((size_t)b * n + i) * EM_CAND + c];
-        const float w = xv >= S.thr_col[j] ? xv : 0.0f;
+#pragma unroll
+      for (int c = 0; c < EM_CAND; ++c) {
+        if (c >= cnt) break;
+        const int j = cj[c];
+        const float w = cx[c];
         const float x = S.f2x[j], y = S.f2y[j];
         sxx += w * (x * x); sxy += w * (x * y); sx += w * x; syy += w * (y * y); sy += w * y; s1 += w;
       }
-      rmom[i][0] = sxx; rmom[i][1] = sxy; rmom[i][2] = sx; rmom[i][3] = syy; rmom[i][4] = sy; rmom[i][5] = s1;
+      rmom[t][0] = sxx; rmom[t][1] = sxy; rmom[t][2] = sx; rmom[t][3] = syy; rmom[t][4] = sy; rmom[t][5] = s1;
     }
     __syncthreads();
     // outer factor F1^T (.): the dense kernel's wave / row partition and accumulation order
@@ -648,7 +703,7 @@ __global__ __launch_bounds__(EM_T) void em_sparse_kernel(const SRC src, int n, i
     }
     __syncthreads();
   }
-  if (t == 0) em_solve(S, b, n_iter, n_iter_manifold, e_out);
+  if (wave == 0) em_solve(S, b, n_iter, n_iter_manifold, e_out);
 }
 
 // workspace of the banded form, per pair: thr_row (n floats), candidate counts (n bytes, padded), candidates
