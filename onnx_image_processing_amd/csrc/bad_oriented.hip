@@ -279,7 +279,10 @@ __device__ __forceinline__ void rotated_positions(uint32_t q, float ky, float kx
   p2x = kx + (ox2 * cos_t - oy2 * sin_t);
 }
 
-template <int OW, int GROUPS>
+// DESC = false: packed bits of the hard mode (`bits`).  DESC = true: the float descriptor (`desc`) in any mode -- raw /
+// sigmoid / 0-1, normalised or not --, the pair value formed by the generic kernel's own expressions (fp64 mean minus
+// threshold) and kept in registers until the norm is known (the generic kernel stages it in LDS).
+template <int OW, int GROUPS, bool DESC>
 __global__ __launch_bounds__(64) void bad_oriented_bits_kernel(const float *__restrict__ image, int h, int w,
                                                                const float *__restrict__ kpts, int k,
                                                                const float *__restrict__ theta_map,
@@ -287,7 +290,8 @@ __global__ __launch_bounds__(64) void bad_oriented_bits_kernel(const float *__re
                                                                const uint32_t *__restrict__ geom,
                                                                const float *__restrict__ thr, float scale_y,
                                                                float scale_x, uint32_t *__restrict__ bits,
-                                                               uint8_t *__restrict__ status) {
+                                                               float *__restrict__ desc, int mode, float temperature,
+                                                               int normalize, uint8_t *__restrict__ status) {
   constexpr int OOFF = OW / 2 - 1;  // window origin = floor(k) - OOFF
   constexpr int OSP = OW + 2;       // words per table row: [0] = the zero column, [1 .. OW] the sums, [OW + 1] padding
   __shared__ __attribute__((aligned(16))) int sat[(OW + 1) * OSP];
@@ -297,9 +301,15 @@ __global__ __launch_bounds__(64) void bad_oriented_bits_kernel(const float *__re
   const float *im = image + (size_t)img * h * w;
   const float ky_raw = kpts[(size_t)flat * 2 + 0];
   const float kx_raw = kpts[(size_t)flat * 2 + 1];
-  uint4 *brow = reinterpret_cast<uint4 *>(bits + (size_t)flat * (2 * GROUPS));
-  if (!(ky_raw >= 0.0f)) {                                              // bad.py:461: an invalid keypoint's bits are 0
-    if (lane < GROUPS / 2) brow[lane] = make_uint4(0u, 0u, 0u, 0u);
+  uint4 *brow = DESC ? nullptr : reinterpret_cast<uint4 *>(bits + (size_t)flat * (2 * GROUPS));
+  float *drow = DESC ? desc + (size_t)flat * (64 * GROUPS) : nullptr;
+  if (!(ky_raw >= 0.0f)) {                                              // bad.py:461: an invalid keypoint's descriptor is 0
+    if (DESC) {
+#pragma unroll
+      for (int g = 0; g < GROUPS; ++g) drow[g * 64 + lane] = 0.0f;
+    } else if (lane < GROUPS / 2) {
+      brow[lane] = make_uint4(0u, 0u, 0u, 0u);
+    }
     if (lane == 0) status[flat] = 1;
     return;
   }
@@ -363,7 +373,7 @@ __global__ __launch_bounds__(64) void bad_oriented_bits_kernel(const float *__re
   }
   bool tame = true;                                                     // thresholds finite and |t| <= 1e30 (else: fp64 path)
 #pragma unroll
-  for (int g = 0; g < GROUPS; ++g) tame = tame && (fabsf(t[g]) <= 1e30f);
+  for (int g = 0; g < GROUPS; ++g) tame = tame && (DESC || fabsf(t[g]) <= 1e30f);   // (only the fp32 bit test needs it)
   const bool ok = __all(differs == 0u && tame);
   if (lane == 0) status[flat] = ok ? 1 : 0;
   if (!ok) return;                                                      // wave-uniform
@@ -397,7 +407,10 @@ __global__ __launch_bounds__(64) void bad_oriented_bits_kernel(const float *__re
   //     (d <= t * a).  (|t| <= 1e30, checked above, keeps p finite.)  Five fp64 instructions per 64 pairs less.
   constexpr int ROWB = OSP * 4;
   const float half_h = 0.5f * (float)(h - 1), half_w = 0.5f * (float)(w - 1);
-  uint32_t words[2 * GROUPS];
+  uint32_t words[DESC ? 1 : 2 * GROUPS];
+  float vals[DESC ? GROUPS : 1];
+  int pop = 0;
+  float sumsq = 0.0f;
 #pragma unroll
   for (int g = 0; g < GROUPS; ++g) {
     float p1y, p1x, p2y, p2x;
@@ -419,15 +432,41 @@ __global__ __launch_bounds__(64) void bad_oriented_bits_kernel(const float *__re
     };
     const int s1 = box_sum(centre(p1y, scale_y, half_h, h), centre(p1x, scale_x, half_w, w));
     const int s2 = box_sum(centre(p2y, scale_y, half_h, h), centre(p2x, scale_x, half_w, w));
-    // bad.py:567,570: bit = (mean1 - mean2 - thr <= 0) = (s1 - s2 <= t * area)
-    const float area = (float)((2 * r + 1) * (2 * r + 1));
-    const float p = t[g] * area, e = __builtin_fmaf(t[g], area, -p);
-    const bool bitv = ((float)(s1 - s2) - p) <= e;
-    const unsigned long long word = __ballot(bitv);
-    words[2 * g] = (uint32_t)word;
-    words[2 * g + 1] = (uint32_t)(word >> 32);
+    if constexpr (DESC) {
+      // the generic kernel's expressions (bad.py:559,565,567): fp64 mean difference minus threshold
+      const double area = (double)((2 * r + 1) * (2 * r + 1));
+      const double td = (double)t[g];
+      float v;
+      if (mode == MI_BAD_HARD) {
+        const bool bitv = (double)(s1 - s2) <= td * area;
+        pop += (int)__popcll(__ballot(bitv));
+        v = bitv ? 1.0f : 0.0f;
+      } else {
+        const float c = (float)((double)(s1 - s2) / area - td);
+        v = c;
+        if (mode == MI_BAD_SOFT) v = 1.0f / (1.0f + expf(c * temperature));
+        sumsq += v * v;
+      }
+      vals[g] = v;
+    } else {
+      // bad.py:567,570: bit = (mean1 - mean2 - thr <= 0) = (s1 - s2 <= t * area)
+      const float area = (float)((2 * r + 1) * (2 * r + 1));
+      const float p = t[g] * area, e = __builtin_fmaf(t[g], area, -p);
+      const bool bitv = ((float)(s1 - s2) - p) <= e;
+      const unsigned long long word = __ballot(bitv);
+      words[2 * g] = (uint32_t)word;
+      words[2 * g + 1] = (uint32_t)(word >> 32);
+    }
   }
-  if (lane == 0) {
+  if constexpr (DESC) {
+    float inv = 1.0f;
+    if (normalize) {                                                    // bad.py:573
+      const float ss = (mode == MI_BAD_HARD) ? (float)pop : wave_sum(sumsq);
+      inv = fmaxf(sqrtf(ss), 1e-12f);
+    }
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) drow[g * 64 + lane] = normalize ? vals[g] / inv : vals[g];
+  } else if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < GROUPS / 2; ++i)
       brow[i] = make_uint4(words[4 * i], words[4 * i + 1], words[4 * i + 2], words[4 * i + 3]);
@@ -459,24 +498,28 @@ extern "C" int mi_sparse_bad_oriented(const float *image, int n, int h, int w, c
 #define BO_LAUNCH(SAT, DESC, OWIN) hipLaunchKernelGGL((bad_oriented_kernel<SAT, DESC, OWIN>), dim3(total), dim3(64), 0, s, A)
 #define BO_PICK(SAT) do { if (desc) { if (small) BO_LAUNCH(SAT, true, 48); else BO_LAUNCH(SAT, true, 60); } else { if (small) BO_LAUNCH(SAT, false, 48); else BO_LAUNCH(SAT, false, 60); } } while (0)
 #define BO_REST(DESC, OWIN) hipLaunchKernelGGL((bad_oriented_rest_kernel<DESC, OWIN>), dim3((total + 63u) / 64u), dim3(64), 0, s, A, (int)total)
-#define BO_BITS(OWIN, G) hipLaunchKernelGGL((bad_oriented_bits_kernel<OWIN, G>), dim3(total), dim3(64), 0, s, image, h, w, keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, scale_y, scale_x, bits, status)
+#define BO_FAST(OWIN, G, D) hipLaunchKernelGGL((bad_oriented_bits_kernel<OWIN, G, D>), dim3(total), dim3(64), 0, s, image, h, w, keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, scale_y, scale_x, bits, desc, mode, temperature, normalize, status)
   if (!status) {                                                        // no scratch for the two-pass form: fp64 for all
     BO_PICK(double);
     return mi_launch_status();
   }
   // integer tables first (uint8-valued windows), then the flagged rest in fp64
-  const bool matcher_form = MI_HOOK(bad_oriented_impl, 0) == 0 && !bilinear && mode == MI_BAD_HARD && bits && !desc &&
-                            (num_pairs == 512 || num_pairs == 256) && (reinterpret_cast<uintptr_t>(bits) & 15u) == 0 &&
-                            (long long)h * w * 4 < 0x7fffffffLL;
-  if (matcher_form) {
-    if (num_pairs == 512) { if (small) BO_BITS(48, 8); else BO_BITS(60, 8); }
-    else { if (small) BO_BITS(48, 4); else BO_BITS(60, 4); }
+  const bool fast_form = MI_HOOK(bad_oriented_impl, 0) == 0 && !bilinear && (num_pairs == 512 || num_pairs == 256) &&
+                         (long long)h * w * 4 < 0x7fffffffLL;
+  const bool bits_form = fast_form && mode == MI_BAD_HARD && bits && !desc && (reinterpret_cast<uintptr_t>(bits) & 15u) == 0;
+  const bool desc_form = fast_form && desc && !bits;
+  if (bits_form) {
+    if (num_pairs == 512) { if (small) BO_FAST(48, 8, false); else BO_FAST(60, 8, false); }
+    else { if (small) BO_FAST(48, 4, false); else BO_FAST(60, 4, false); }
+  } else if (desc_form) {
+    if (num_pairs == 512) { if (small) BO_FAST(48, 8, true); else BO_FAST(60, 8, true); }
+    else { if (small) BO_FAST(48, 4, true); else BO_FAST(60, 4, true); }
   } else {
     BO_PICK(int);
   }
   if (desc) { if (small) BO_REST(true, 48); else BO_REST(true, 60); }
   else { if (small) BO_REST(false, 48); else BO_REST(false, 60); }
-#undef BO_BITS
+#undef BO_FAST
 #undef BO_REST
 #undef BO_PICK
 #undef BO_LAUNCH

@@ -99,6 +99,17 @@ def main():
                 ms = timeit(lambda: bad_o.forward_bits(img, kp, ang), args.iters)
                 res[f"bad_oriented_bits {tag} ({name})"] = (ms, 0.0)
         N.use_debug_library().mi_debug_set(13, 0)
+        for kw, tag in ((dict(binarize=False), "256 raw"), (dict(binarize=True, soft_binarize=True), "256 soft"),
+                        (dict(binarize=True, soft_binarize=False), "256 hard f32")):
+            bad_d = SparseBAD(256, **kw).to(dev)
+            ref_d = None
+            for impl, name in ((1, "generic"), (0, "fast kernel")):
+                N.use_debug_library().mi_debug_set(13, impl)
+                got = bad_d(img, kp, ang)
+                assert ref_d is None or torch.equal(got, ref_d), (tag, name, float((got - ref_d).abs().max()))
+                ref_d = got
+                res[f"bad_oriented_desc {tag} ({name})"] = (timeit(lambda: bad_d(img, kp, ang), args.iters), 0.0)
+        N.use_debug_library().mi_debug_set(13, 0)
         fr = img.clone()
         fr[::2, :, 100:200, 100:300] += 0.25                        # half the images: windows that are not uint8-valued
         for impl, name in ((1, "generic"), (0, "bits kernel")):
