@@ -646,6 +646,54 @@ def test_oriented_bad_small_window_equals_full_window(mods):
         ops.sparse_bad_oriented(imgs[0], gpu(kp), gpu(theta), m.pair_geom, m.pair_thr, N.MI_BAD_HARD, 10.0, True, max_reach=-1.0)
 
 
+def test_oriented_bad_fast_kernels_equal_the_generic_kernel(mods):
+    """The matchers' rotation-aware BAD kernel (all loads up front, straight-line pair phase, fp32 threshold test with
+    the product's exact residual; packed bits or float descriptors) against the generic kernel (debug key 13 = 1):
+    identical bits / floats for 256 and 512 pairs, every mode, both windows (48 with the table's reach stated, 60
+    without), per-keypoint angles and a dense angle map, keypoints on corners and borders, sub-pixel and invalid ones,
+    an image with NON-uint8-valued regions (those windows go to the fp64 rest kernel) and one that has none, a -0.0
+    pixel, and a threshold table with huge, infinite and NaN entries (the whole launch then takes the fp64 path)."""
+    from onnx_image_processing_amd import _native as N, ops
+    rng = np.random.default_rng(77)
+    a, _ = synth_batch(940, 3, 150, 200)
+    b = a.copy()
+    b[0, 0, 40:90, 50:120] += np.float32(0.5)
+    b[1, 0, 10, 10] = np.float32(-0.0)
+    b[2, 0, 100:, :] *= np.float32(1.001)
+    kn = 160
+    kp = np.stack([rng.integers(0, 150, (3, kn)), rng.integers(0, 200, (3, kn))], -1).astype(np.float32)
+    kp[0, :8] = [(0, 0), (149, 199), (0, 199), (149, 0), (60.5, 80.25), (-1, -1), (23, 23), (24, 176)]
+    kp[1, :4] = [(126, 24), (125.75, 175.5), (10, 10), (11, 11)]
+    theta = (rng.random((3, kn)).astype(np.float32) * 2 - 1) * np.float32(np.pi)
+    theta[:, 8:16] = np.float32(np.pi / 4) * np.array([1, 3, 5, 7, -1, -3, -5, -7], np.float32)
+    theta[2, 20] = np.float32(1e6)                                            # sine / cosine with the big-argument reduction
+    amap = (rng.random((3, 1, 150, 200)).astype(np.float32) * 2 - 1) * np.float32(np.pi)
+    for pairs in (256, 512):
+        m = mods["SparseBAD"](pairs, binarize=True, soft_binarize=False).to(DEV)
+        wild = m.pair_thr.clone()
+        wild[3], wild[70], wild[130], wild[200] = 3e38, float("inf"), float("nan"), -2e37
+        for img in (gpu(a), gpu(b)):
+            for ori in (gpu(theta), gpu(amap)):
+                for thr in (m.pair_thr, wild):
+                    for reach in (m.max_reach, 0.0):
+                        for mode, bits_only in ((N.MI_BAD_HARD, True), (N.MI_BAD_HARD, False), (N.MI_BAD_SOFT, False),
+                                                (N.MI_BAD_RAW, False)):
+                            for norm in (True, False):
+                                def run():
+                                    return ops.sparse_bad_oriented(img, gpu(kp), ori, m.pair_geom, thr, mode, 10.0, norm,
+                                                                   want_desc=not bits_only, want_bits=bits_only,
+                                                                   max_reach=reach)
+                                fast = run()
+                                with N.debug_library() as lib:
+                                    lib.mi_debug_set(13, 1)
+                                    want = run()
+                                what = (pairs, mode, bits_only, norm, reach, thr is wild)
+                                if bits_only:
+                                    assert torch.equal(fast[1], want[1]), what
+                                else:                                          # NaN thresholds: NaN descriptors, same places
+                                    assert torch.equal(torch.nan_to_num(fast[0], nan=7.0), torch.nan_to_num(want[0], nan=7.0)), what
+
+
 @pytest.mark.parametrize("name", ["hard", "soft"])
 def test_angle_pipeline_vs_oracle_and_golden(mods, name):
     from onnx_image_processing_amd.pytorch_model.feature_detection import ShiTomasiAngleSparseBADSinkhornMatcher
