@@ -155,17 +155,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     o_pre[g] = plan_offs[g * 64 + lane];
     t_pre[g] = plan_tint[g * 64 + lane];
   }
-  bool integral = true;
+  // uint8-valued window: every pixel has the bits of (float)(uint8)pixel (-0.0 counts as differing and takes the general
+  // kernel).  One convert and ONE v_bitop3 (differs |= back ^ px) per pixel behind an asm -- two converts, three compares
+  // and their scalar ANDs before (round 4; written in C the optimiser turns the or-chain back into compares)
+  uint32_t differs = 0u;
   int col[16];
   int acc = 0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int v = (int)px[r];
-    if constexpr (std::is_same<PIX, float>::value) integral = integral && ((float)v == px[r]) && (v >= 0) && (v <= 255);
+    if constexpr (std::is_same<PIX, float>::value) {
+      const float back = (float)(v & 0xff);
+      asm("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xf6" : "+v"(differs) : "v"(back), "v"(px[r]));   // a | (b ^ c)
+    }
     acc += v;
     col[r] = acc;
   }
-  if (std::is_same<PIX, float>::value && !__all(integral)) {
+  if (std::is_same<PIX, float>::value && !__all(differs == 0u)) {
     if (lane == 0) status[flat] = 0;
     return;
   }
