@@ -553,7 +553,7 @@ def side_model(name: str):
                 "BAD(512, hard) + Sinkhorn(20, eps 0.05) + essential-matrix head), 640x480, K=512, Angle export-CLI values; "
                 "per pair what sample/visual_odometry.py:520-613 consumes: E and the 100 best mutual matches "
                 "(match_and_essential: both straight from the Sinkhorn solution, P not written)",
-                ("mi_corner_response_balanced", "corner_tile_kernel<5,8> (block 5: the register-staged tile kernel)", 8.0, "corner_tile_kernel<5,8>", 1))
+                ("mi_corner_response_balanced", "corner_stream_kernel<5,4,float> (block 5: the streaming LDS-DMA kernel)", 8.0, "corner_stream_kernel<5,4,false>", 1))
     # c4: one scale per launch for BOTH images of every pair (2 B images): reads the previous scale's image, writes the
     # diffused image and the scale's score map -- 12 B/px (the middle scale, mi_akaze_scale; the first reads two batches,
     # the last folds the selection across scales in: 4 + 4 + 4 + 8 + 1 B/px)

@@ -15,7 +15,7 @@ import pytest
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 ASM = os.path.join(ROOT, "onnx_image_processing_amd", "lib", "obj", "corner-hip-amdgcn-amd-amdhsa-gfx950.s")
 TW, LPAD = 128, 4                                   # csrc/corner.hip: tile width, LDS padding per side
-INSTANCES = [(3, 4, 0), (3, 5, 0), (3, 8, 0), (3, 4, 1), (3, 5, 1), (3, 8, 1)]     # (block, rows per thread, uint8 pixels)
+INSTANCES = [(3, 4, 0), (3, 5, 0), (3, 8, 0), (3, 4, 1), (3, 5, 1), (3, 8, 1), (5, 4, 0), (5, 5, 0), (5, 8, 0), (7, 8, 0)]     # (block, rows per thread, uint8 pixels)
 
 
 @pytest.fixture(scope="module")

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--images", type=int, default=256)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--radius", type=int, default=5)
+    ap.add_argument("--block", type=int, default=3)
     args = ap.parse_args()
     dev = "cuda:0"
     n = args.images
@@ -50,7 +51,20 @@ def main():
     px = n * H * W
     res = {}
     score = ops.corner_response(img, 3)
-    if "corner" in args.which:
+    if "corner" in args.which and args.block != 3:
+        N.use_debug_library().mi_debug_set(1, 1)
+        ref5 = ops.corner_response(img, args.block)
+        for impl, rows, name in ((1, 8, "corner(tile)"), (0, 8, "corner(stream R=8)"), (0, 5, "corner(stream R=5)"),
+                                 (0, 4, "corner(stream R=4)")):
+            N.use_debug_library().mi_debug_set(1, impl)
+            N.use_debug_library().mi_debug_set(2, rows)
+            alt = ops.corner_response(img, args.block)
+            assert torch.equal(alt, ref5), name
+            ms = timeit(lambda: ops.corner_response(img, args.block), args.iters)
+            res[f"block {args.block} {name}"] = (ms, 8.0 * px / ms / 1e6)
+        N.use_debug_library().mi_debug_set(1, 0)
+        N.use_debug_library().mi_debug_set(2, 4)
+    if "corner" in args.which and args.block == 3:
         for impl, rows, name in ((1, 8, "corner(tile)"), (0, 8, "corner(stream R=8)"), (0, 5, "corner(stream R=5)"),
                                  (0, 4, "corner(stream R=4)")):
             N.use_debug_library().mi_debug_set(1, impl)
