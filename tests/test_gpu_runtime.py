@@ -417,6 +417,29 @@ def test_corner_ticket_schedule_equals_static(mods):
         del want, got
 
 
+@pytest.mark.parametrize("bs", [5, 7])
+def test_corner_blocks_5_and_7_streaming_kernel_equals_tile_kernel(mods, bs):
+    """Blocks 5 and 7 run the streaming LDS-DMA kernel since round 4 (same stencil as the register-staged tile kernel,
+    debug key 1 = 1): identical score maps on shapes with partial tiles, on a batch small enough for the static tile
+    schedule and on one large enough for tickets (repeated: the ticket hand-off is timing dependent), counter left zero."""
+    from onnx_image_processing_amd import _native as N, ops
+    for n, h, w, reps in ((3, 100, 200, 1), (1, 37, 64, 1), (150, 240, 384, 4)):
+        base = np.stack([synth_image(950 + i, h, w) for i in range(3)])[:, None].astype(np.float32)
+        x = gpu(np.tile(base, ((n + 2) // 3, 1, 1, 1))[:n])
+        with N.debug_library() as lib:
+            lib.mi_debug_set(1, 1)
+            want = ops.corner_response(x, bs)
+        ctr = torch.zeros(ops.TILE_COUNTER_BYTES // 4, dtype=torch.int32, device=DEV)
+        for _ in range(reps):
+            got = torch.full((n, 1, h, w), -1.0, dtype=torch.float32, device=DEV)
+            N.call("mi_corner_response_balanced", x.data_ptr(), 0, n, h, w, bs, got.data_ptr(), ctr.data_ptr(), N.stream_ptr())
+            assert torch.equal(got, want), (n, h, w)
+            assert int(ctr.abs().sum()) == 0
+        got = torch.empty((n, 1, h, w), dtype=torch.float32, device=DEV)
+        N.call("mi_corner_response", x.data_ptr(), n, h, w, bs, got.data_ptr(), N.stream_ptr())       # no counter: static
+        assert torch.equal(got, want)
+
+
 def test_corner_dirty_tile_counter_is_harmless(mods):
     """A counter block left dirty (a launch that died between its first draw and the last workgroup's reset) must not
     make later calls skip tiles: the launcher clears the block on the stream ahead of the kernel.
