@@ -601,6 +601,16 @@ def akaze_orientation_at_keypoints(scale_scores: torch.Tensor, scale_theta: torc
 
 # ---- essential-matrix head (geometry/essential_matrix_estimator.py) ---------------------------------
 
+def _validity_bytes(valid: torch.Tensor | None) -> torch.Tensor | None:
+    """A validity mask as the uint8 array the C ABI reads; a bool tensor is VIEWED (one byte per element, 0 / 1): no copy
+    kernel on the per-pair path."""
+    if valid is None:
+        return None
+    if valid.dtype == torch.bool:
+        return valid.contiguous().view(torch.uint8)
+    return (valid != 0).contiguous().view(torch.uint8)
+
+
 def essential_matrix(p: torch.Tensor, pts1_n: torch.Tensor, pts2_n: torch.Tensor, valid1: torch.Tensor | None,
                      valid2: torch.Tensor | None, top_k: int, n_iter: int, n_iter_manifold: int,
                      banded: bool = True) -> torch.Tensor:
@@ -615,8 +625,7 @@ def essential_matrix(p: torch.Tensor, pts1_n: torch.Tensor, pts2_n: torch.Tensor
         raise RuntimeError(f"points must be ({b},{n},2) and ({b},{m},2), got {tuple(q1.shape)}, {tuple(q2.shape)}")
     if (valid1 is None) != (valid2 is None):
         raise RuntimeError("valid1 and valid2 must be given together")
-    v1 = valid1.to(torch.uint8).contiguous() if valid1 is not None else None
-    v2 = valid2.to(torch.uint8).contiguous() if valid2 is not None else None
+    v1, v2 = _validity_bytes(valid1), _validity_bytes(valid2)
     e = torch.empty((b, 3, 3), dtype=F32, device=pp.device)
     wbytes = int(N.load().mi_essential_matrix_workspace_bytes(b, n, m, int(top_k))) if banded else 0
     work = torch.empty(((wbytes + 7) // 8,), dtype=torch.int64, device=pp.device) if wbytes else None
@@ -640,8 +649,7 @@ def essential_matrix_dots(state, m: int, epsilon: float, u: torch.Tensor, v: tor
         raise RuntimeError(f"points must be ({b},{n},2) and ({b},{m},2), got {tuple(q1.shape)}, {tuple(q2.shape)}")
     if (valid1 is None) != (valid2 is None):
         raise RuntimeError("valid1 and valid2 must be given together")
-    v1 = valid1.to(torch.uint8).contiguous() if valid1 is not None else None
-    v2 = valid2.to(torch.uint8).contiguous() if valid2 is not None else None
+    v1, v2 = _validity_bytes(valid1), _validity_bytes(valid2)
     e = torch.empty((b, 3, 3), dtype=F32, device=dots.device)
     wbytes = int(N.load().mi_essential_matrix_workspace_bytes(b, n, m, int(top_k))) if banded else 0
     work = torch.empty(((wbytes + 7) // 8,), dtype=torch.int64, device=dots.device) if wbytes else None
