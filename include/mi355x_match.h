@@ -12,7 +12,7 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued
  *     asynchronously and is ordered as if it ran on `stream` (after earlier work on it, before later
  *     work), nothing synchronises, nothing allocates device memory.  mi_sinkhorn_dots (and
- *     mi_match_pairs through it) overlaps the halves of a batch of >= 64 pairs on helper streams
+ *     mi_match_pairs through it; mi_sinkhorn with a workspace likewise) overlaps the halves of a batch of >= 64 pairs on helper streams
  *     joined back into `stream` by events; those helpers belong to the calling (device, stream) and
  *     are created on its first such call (mi_release_stream_resources frees them).  WHICH streams the
  *     halves run on is tuned per calling stream and per shape (batch, n, m, iterations): the first
@@ -96,7 +96,7 @@ enum {
 MI_API int mi_abi_version(void);
 MI_API const char *mi_error_string(int code);
 /* Frees the helper streams / events held for (current device, stream), see the conventions above.  Call it
- * before destroying a stream that was passed to mi_sinkhorn_dots / mi_match_pairs with >= 64 pairs; the
+ * before destroying a stream that was passed to mi_sinkhorn_dots / mi_sinkhorn / mi_match_pairs with >= 64 pairs; the
  * stream's helper work must have completed (synchronise the stream first). */
 MI_API int mi_release_stream_resources(mi_stream_t stream);
 /* The stream schedule in force for mi_sinkhorn_dots calls of this shape on (current device, stream): the pinned
@@ -259,7 +259,13 @@ MI_API int mi_cost_logscores_f32(const float *desc1, const float *desc2, int bat
  * workspace: mi_sinkhorn_workspace_bytes(batch, n, m) bytes, 16-byte aligned, enables the fused
  * iteration that reads Z once per iteration (per-band column partials); with workspace == NULL
  * (or m > 1024, for which the query returns 0) the two-pass form runs -- same results up to
- * fp32 summation order. */
+ * fp32 summation order.
+ * Streams: with a workspace and batch >= 64 the call runs as two half batches on the caller's stream and the library's
+ * per-stream helper streams, like mi_sinkhorn_dots and scheduled by the same self-tuner (its shapes are kept apart
+ * from that solver's: mi_sinkhorn_dots_schedule(stream, batch, n, m, iterations + (1 << 20)) reports this solver's
+ * decision); same duals whatever the schedule.  mi_sinkhorn_dots_set_schedule(stream, MI_SCHEDULE_UNSPLIT) keeps
+ * every launch of both solvers on the caller's stream; inside a stream capture nothing is tried (the decision in
+ * force, or unsplit). */
 MI_API size_t mi_sinkhorn_workspace_bytes(int batch, int n, int m);
 MI_API int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, float dustbin_logscore,
                 int iterations, float *u, float *v, float *p, void *workspace, size_t workspace_bytes,

@@ -239,3 +239,15 @@ int mi_sinkhorn_dots_impl(const uint16_t *dots, const float *row_info, const flo
                           int pitch, double epsilon, double unused_score, double sqnorm_bound, int iterations, float *u,
                           float *v, float *p, void *workspace, size_t workspace_bytes, int flags, int prezeroed,
                           mi_stream_t stream);
+
+// A >= 64-pair solve as two half batches on two streams (sinkhorn_dots.hip: the per-stream helper streams, events and
+// schedule tuner), for solvers outside that file: begin -> enqueue part q on f.stream[q] -> end.
+struct MiFork {
+  int parts;                 // 1: everything on the caller's stream; 2: two half batches
+  hipStream_t stream[2];
+  void *handle;
+  int trial_entry, trial, first_side;
+};
+int mi_fork_begin(hipStream_t s, int batch, int n, int m, int key, MiFork *f);
+int mi_fork_end(hipStream_t s, MiFork *f);
+

@@ -729,33 +729,48 @@ __global__ __launch_bounds__(256) void sk_vcombine_kernel(const float2 *__restri
   v[(size_t)b * (m + 1) + j] = ((j == m) ? log_n : 0.0f) - (logf(s) + mx);
 }
 
+// >= 64 pairs (round 4): two half batches on two streams, scheduled by mi_sinkhorn_dots' per-stream tuner under a shape
+// key of its own -- an iteration is a big row kernel and a tiny column kernel that depend on each other, and one half's
+// row kernel fills the other half's gap (sinkhorn_dots.hip, launch_dots).  The halves are independent problems: same
+// duals.  A caller opts out per stream with mi_sinkhorn_dots_set_schedule(stream, MI_SCHEDULE_UNSPLIT).
+constexpr int SK_F32_SHAPE_KEY = 1 << 20;      // added to `iterations` in the tuner's shape: never a dots shape
 template <int E4, int RW, int NW>
-void launch_fused(const float *z, int batch, int n, int m, int pitch, float dust, int iterations, float *u,
-                  float *v, float2 *part, float *vp, float log_m, float log_n, hipStream_t s) {
+int launch_fused(const float *z, int batch, int n, int m, int pitch, float dust, int iterations, float *u,
+                 float *v, float2 *part, float *vp, float log_m, float log_n, hipStream_t s) {
   const int nb = ceil_div(n, NW * RW);
   constexpr int NC = 256 * E4;
-  for (int it = 0; it < iterations; ++it) {
+  const int band_form = MI_HOOK(sinkhorn_log_partials, 0);
+  MiFork fk;
+  const int fe = mi_fork_begin(s, batch, n, m, iterations + SK_F32_SHAPE_KEY, &fk);
+  if (fe != MI_OK) return fe;
+  for (int it = 0; it < iterations; ++it) {     // iteration by iteration, so that no stream runs far ahead of the other
     const int vz = it == 0 ? 1 : 0;
-    const int band_form = MI_HOOK(sinkhorn_log_partials, 0);
-    if (band_form == 0) {
-      float *pf = reinterpret_cast<float *>(part);
-      hipLaunchKernelGGL((sk_band_p2_kernel<E4, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, z, n, m, pitch,
-                         dust, vp, NC + 4, u, pf, log_m, vz);
-      hipLaunchKernelGGL(sk_vcombine_p2_kernel, dim3(ceil_div(NC + 1, 256), batch), dim3(256), 0, s, pf, m, nb + 1, v,
-                         vp, NC + 4, NC, log_n, vz);
-    } else if (band_form == 1) {
-      hipLaunchKernelGGL((sk_band_kernel<E4, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, z, n, m, pitch, dust,
-                         v, u, part, log_m, vz);
-      hipLaunchKernelGGL(sk_vcombine_kernel, dim3(ceil_div(m + 1, 256), batch), dim3(256), 0, s, part, m, nb + 1,
-                         v, log_n);
-    } else {
-      float *pf = reinterpret_cast<float *>(part);
-      hipLaunchKernelGGL((sk_band_p_kernel<E4, RW, NW>), dim3(nb + 1, batch), dim3(64 * NW), 0, s, z, n, m, pitch,
-                         dust, v, u, pf, log_m, vz);
-      hipLaunchKernelGGL(sk_vcombine_p_kernel, dim3(ceil_div(m + 1, 256), batch), dim3(256), 0, s, pf, m, nb + 1, v,
-                         log_n, vz);
+    for (int q = 0; q < fk.parts; ++q) {
+      const int b0 = (int)((long long)batch * q / fk.parts), nbatch = (int)((long long)batch * (q + 1) / fk.parts) - b0;
+      hipStream_t st = fk.stream[q];
+      const float *z0 = z + (size_t)b0 * n * pitch;
+      float *u0 = u + (size_t)b0 * (n + 1), *v0 = v + (size_t)b0 * (m + 1), *vp0 = vp + (size_t)b0 * (NC + 4);
+      float2 *part0 = part + (size_t)b0 * (nb + 1) * (size_t)(m + 1);
+      float *pf = reinterpret_cast<float *>(part) + (size_t)b0 * (nb + 1) * (size_t)(m + 1);
+      if (band_form == 0) {
+        hipLaunchKernelGGL((sk_band_p2_kernel<E4, RW, NW>), dim3(nb + 1, nbatch), dim3(64 * NW), 0, st, z0, n, m, pitch,
+                           dust, vp0, NC + 4, u0, pf, log_m, vz);
+        hipLaunchKernelGGL(sk_vcombine_p2_kernel, dim3(ceil_div(NC + 1, 256), nbatch), dim3(256), 0, st, pf, m, nb + 1, v0,
+                           vp0, NC + 4, NC, log_n, vz);
+      } else if (band_form == 1) {
+        hipLaunchKernelGGL((sk_band_kernel<E4, RW, NW>), dim3(nb + 1, nbatch), dim3(64 * NW), 0, st, z0, n, m, pitch, dust,
+                           v0, u0, part0, log_m, vz);
+        hipLaunchKernelGGL(sk_vcombine_kernel, dim3(ceil_div(m + 1, 256), nbatch), dim3(256), 0, st, part0, m, nb + 1,
+                           v0, log_n);
+      } else {
+        hipLaunchKernelGGL((sk_band_p_kernel<E4, RW, NW>), dim3(nb + 1, nbatch), dim3(64 * NW), 0, st, z0, n, m, pitch,
+                           dust, v0, u0, pf, log_m, vz);
+        hipLaunchKernelGGL(sk_vcombine_p_kernel, dim3(ceil_div(m + 1, 256), nbatch), dim3(256), 0, st, pf, m, nb + 1, v0,
+                           log_n, vz);
+      }
     }
   }
+  return mi_fork_end(s, &fk);
 }
 
 int fused_rows_per_band(int m) {
@@ -796,9 +811,11 @@ extern "C" int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, f
     float *vp = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) +
                                           partials_bytes(batch, n, m, fused_rows_per_band(m)));
     const int e4 = ceil_div(m, 256);
-    if (e4 == 1) launch_fused<1, 4, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, vp, log_m, log_n, s);
-    else if (e4 == 2) launch_fused<2, 4, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, vp, log_m, log_n, s);
-    else launch_fused<4, 2, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, vp, log_m, log_n, s);
+    int fr;
+    if (e4 == 1) fr = launch_fused<1, 4, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, vp, log_m, log_n, s);
+    else if (e4 == 2) fr = launch_fused<2, 4, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, vp, log_m, log_n, s);
+    else fr = launch_fused<4, 2, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, vp, log_m, log_n, s);
+    if (fr != MI_OK) return fr;
     if (p) {
       hipLaunchKernelGGL(sk_exp_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, z, n, m, pitch,
                          dustbin_logscore, u, v, p);

@@ -1016,6 +1016,61 @@ int launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int ba
   return launched;
 }
 
+}  // namespace
+
+// The same two-half-batches-on-two-streams form for mi_sinkhorn (fp32 log-scores; sinkhorn.hip): begin decides the
+// schedule with THIS file's per-stream tuner (its own shapes: `key` tells the solvers apart) and records the fork, end
+// joins and closes the trial.  parts == 1: everything on the caller's stream.
+int mi_fork_begin(hipStream_t s, int batch, int n, int m, int key, MiFork *f) {
+  f->parts = 1;
+  f->stream[0] = f->stream[1] = s;
+  f->handle = nullptr;
+  f->trial_entry = f->trial = -1;
+  f->first_side = 1;
+  if (batch < 64) return MI_OK;
+  ForkJoin *fj = fork_join_for(s);
+  if (!fj) return MI_OK;
+  const int fixed = MI_HOOK(sinkhorn_schedule, -1);
+  mi::TunerShape shape;
+  shape.batch = batch; shape.n = n; shape.m = m; shape.iterations = key;
+  const int sched = fixed >= 0 ? fixed : fj->pick(s, shape, &f->trial_entry, &f->trial);
+  f->handle = fj;
+  if (sched == 2) return MI_OK;                                // unsplit (a trial of it is still timed)
+  f->first_side = sched == 1 ? 0 : 1;
+  bool forked = hipEventRecord(fj->fork, s) == hipSuccess;
+  for (int q = f->first_side; forked && q < 2; ++q)
+    forked = hipStreamWaitEvent(fj->side[q - f->first_side], fj->fork, 0) == hipSuccess;
+  if (!forked) {                                               // run unforked (a side stream that already waits is harmless)
+    (void)hipGetLastError();
+    return MI_OK;
+  }
+  f->parts = 2;
+  for (int q = 0; q < 2; ++q) f->stream[q] = q >= f->first_side ? fj->side[q - f->first_side] : s;
+  return MI_OK;
+}
+
+int mi_fork_end(hipStream_t s, MiFork *f) {
+  ForkJoin *fj = static_cast<ForkJoin *>(f->handle);
+  if (f->parts > 1) {
+    for (int q = f->first_side; q < 2; ++q) {                  // a failed join is an error: later work on `s` would not be ordered
+      hipError_t e = hipEventRecord(fj->join[q - f->first_side], fj->side[q - f->first_side]);
+      if (e == hipSuccess) e = hipStreamWaitEvent(s, fj->join[q - f->first_side], 0);
+      if (e != hipSuccess) {
+        if (f->trial >= 0) fj->abandon_trial(f->trial_entry, f->trial);
+        return (int)e;
+      }
+    }
+  }
+  const int launched = mi_launch_status();
+  if (fj && f->trial >= 0) {
+    if (launched == MI_OK) fj->close_trial(f->trial_entry, f->trial, s);
+    else fj->abandon_trial(f->trial_entry, f->trial);
+  }
+  return launched;
+}
+
+namespace {
+
 int dots_rows_per_band(int m) { return m <= 512 ? 32 : (m <= 1024 ? 16 : 0); }   // 8 rows per wave measured slower
 
 // workspace: band partials (one float per column per band), then the padded per-column arrays wp, tp

@@ -73,6 +73,52 @@ def test_sinkhorn_stream_schedules_agree(mods):
         ops.set_solver_flags(ops.MI_SOLVER_DEFAULT)
     with pytest.raises(ValueError):
         ops.set_solver_flags(4)
+
+
+@pytest.mark.parametrize("n,m", [(300, 280), (520, 700)])
+def test_fp32_sinkhorn_stream_schedules_agree(mods, n, m):
+    """mi_sinkhorn (fp32 log-scores: float descriptors, the reference's default configuration) for >= 64 pairs runs as
+    two half batches on two streams too since round 4, scheduled by the same per-stream tuner under a shape key of its
+    own: duals and P of every fixed schedule (debug key 11), of the tuner's trial calls and of its decision are identical,
+    the decision of the packed solver for the same (batch, n, m, iterations) is a different entry, a pin applies to
+    both solvers, and a replayed capture of the call (unsplit: its stream's tuner has not decided) gives the same P."""
+    from onnx_image_processing_amd import _native as N, ops
+    from onnx_image_processing_amd.graph import GraphedModule
+    rng = np.random.default_rng(n + m)
+    d1 = rng.standard_normal((70, n, 64)).astype(np.float32)
+    d2 = rng.standard_normal((70, m, 64)).astype(np.float32)
+    d2[:, :100] = d1[:, :100] + 0.05 * rng.standard_normal((70, 100, 64)).astype(np.float32)
+    d1 /= np.linalg.norm(d1, axis=-1, keepdims=True)
+    d2 /= np.linalg.norm(d2, axis=-1, keepdims=True)
+    z, pitch = ops.cost_logscores_f32(gpu(d1), gpu(d2), 0, 0.1)
+    iters = 9
+    run = lambda: [t.clone() for t in ops.sinkhorn(z, m, pitch, -10.0, iters, return_duals=True)]
+    with N.debug_library() as lib:
+        want = None
+        for sched in (2, 0, 1):
+            assert lib.mi_debug_set(11, sched) == 0
+            got = run()
+            want = want or got
+            for x, y in zip(got, want):
+                assert torch.equal(x, y), sched
+        assert lib.mi_debug_set(11, -1) == 0
+    assert bool(torch.isfinite(want[0]).all()) and float(want[0][:, :-1, :-1].max()) > 0.3
+    ops.set_sinkhorn_schedule(ops.MI_SCHEDULE_UNDECIDED)
+    for call in range(12):                                       # nine trial calls, then the decided schedule
+        for x, y in zip(run(), want):
+            assert torch.equal(x, y), call
+        torch.cuda.synchronize()
+    assert ops.sinkhorn_schedule(70, n, m, iters + (1 << 20)) in (0, 1, 2)        # this solver's own shape key ...
+    assert ops.sinkhorn_schedule(70, n, m, iters) == ops.MI_SCHEDULE_UNDECIDED    # ... not the packed solver's
+    for pin in (2, 1, 0):
+        ops.set_sinkhorn_schedule(pin)
+        for x, y in zip(run(), want):
+            assert torch.equal(x, y), pin
+    ops.set_sinkhorn_schedule(ops.MI_SCHEDULE_UNDECIDED)
+    # a capture on a stream whose tuner has not decided records the unsplit schedule (nothing is tried inside a capture)
+    graphed = GraphedModule(lambda zz: ops.sinkhorn(zz, m, pitch, -10.0, iters), z)
+    for _ in range(2):
+        assert torch.equal(graphed(z), want[0])
     assert torch.isfinite(want[0]).all()
 
 
