@@ -24,6 +24,7 @@ class _EssentialHead(nn.Module):
                    epsilon, unused_score, distance_type, nms_radius, score_threshold, normalize_descriptors,
                    sampling_mode, border_margin, top_k, n_iter, n_iter_manifold):
         self.max_keypoints = max_keypoints
+        self.joint_batch_limit = 8                # pairs per call up to which image1 / image2 share the front end's launches
         self.nms_radius = nms_radius
         self.score_threshold = score_threshold
         self.top_k = top_k
@@ -59,8 +60,16 @@ class _EssentialHead(nn.Module):
         from ..matching.sinkhorn import SinkhornSolution
         if image1.shape != image2.shape:
             raise RuntimeError(f"image shapes differ: {tuple(image1.shape)} vs {tuple(image2.shape)}")
-        k1, s1, d1, packed = self._describe(image1)
-        k2, s2, d2, _ = self._describe(image2)
+        b = image1.shape[0]
+        if b <= self.joint_batch_limit:
+            # few pairs per call (the visual-odometry host: ONE): both images through every front-end kernel as one
+            # batch of 2B -- half the launches / graph nodes of the per-call path for one small copy; the kernels treat
+            # images independently, so the halves are what the two separate calls give
+            kj, sj, dj, packed = self._describe(torch.cat([image1, image2], dim=0))
+            k1, k2, s1, s2, d1, d2 = kj[:b], kj[b:], sj[:b], sj[b:], dj[:b], dj[b:]
+        else:
+            k1, s1, d1, packed = self._describe(image1)
+            k2, s2, d2, _ = self._describe(image2)
         q1, q2 = self._normalised(k1.float()), self._normalised(k2.float())
         m = self.matcher
         if packed and m.use_dot_storage and ops.dots_supported(d1.shape[0], d1.shape[1], d2.shape[1], m.epsilon) \
