@@ -43,6 +43,7 @@ class ShiTomasiSparseBADSinkhornMatcher(nn.Module):
     ) -> None:
         super().__init__()
         self.max_keypoints = max_keypoints
+        self.joint_batch_limit = 8                # pairs per call up to which image1 / image2 share the front end's launches
         self.nms_radius = nms_radius
         self.score_threshold = score_threshold
         self.corner_detector = ShiTomasiScore(block_size=block_size, sobel_size=sobel_size)
@@ -66,6 +67,16 @@ class ShiTomasiSparseBADSinkhornMatcher(nn.Module):
         if image1.shape != image2.shape:
             raise RuntimeError(f"image shapes differ: {tuple(image1.shape)} vs {tuple(image2.shape)}")
         packed = self.descriptor.mode == N.MI_BAD_HARD and self.matcher.distance_type == "l2"
+        b = image1.shape[0]
+        if b <= self.joint_batch_limit and image1.dtype == image2.dtype:
+            # few pairs per call (the reference harness: ONE, sample/image_matching.py:313-328): both images through
+            # every front-end kernel as one batch of 2B -- half the launches / graph nodes for one small copy; the
+            # kernels treat images independently, so the halves are what the separate calls give
+            image = torch.cat([image1, image2], dim=0)
+            scores = self.corner_detector(image).squeeze(1)
+            kp, _ = detect_keypoints(scores, self.nms_radius, self.max_keypoints, self.score_threshold, self.border_margin)
+            d = self.descriptor.forward_bits(image, kp) if packed else self.descriptor(image, kp)
+            return [kp[:b], kp[b:]], [d[:b], d[b:]], packed
         kpts, descs = [], []
         for image in (image1, image2):                                       # no concatenation: images stay in place
             scores = self.corner_detector(image).squeeze(1)
