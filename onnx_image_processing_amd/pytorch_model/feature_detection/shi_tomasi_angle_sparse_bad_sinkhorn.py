@@ -18,6 +18,7 @@ class _AngleMatcherBase(nn.Module):
     def _init_common(self, max_keypoints, block_size, patch_size, sigma, num_pairs, binarize, soft_binarize,
                      temperature, nms_radius, score_threshold, normalize_descriptors, sampling_mode, border_margin):
         self.max_keypoints = max_keypoints
+        self.joint_batch_limit = 8                # pairs per call up to which image1 / image2 share the front end's launches
         self.nms_radius = nms_radius
         self.score_threshold = score_threshold
         self.detector = ShiTomasiWithAngle(block_size=block_size, patch_size=patch_size, sigma=sigma)
@@ -35,11 +36,21 @@ class _AngleMatcherBase(nn.Module):
         d = self.descriptor.forward_bits(image, kp, theta) if packed else self.descriptor(image, kp, theta)
         return kp, d, packed
 
-    def _match(self, image1, image2):
+    def _detect_describe_pair(self, image1, image2):
+        """-> (k1, d1, k2, d2, packed).  Few pairs per call: both images through every front-end kernel as one batch of
+        2B (half the launches / graph nodes for one small copy; the kernels treat images independently)."""
         if image1.shape != image2.shape:
             raise RuntimeError(f"image shapes differ: {tuple(image1.shape)} vs {tuple(image2.shape)}")
+        b = image1.shape[0]
+        if b <= self.joint_batch_limit and image1.dtype == image2.dtype:
+            kp, d, packed = self._detect_describe(torch.cat([image1, image2], dim=0))
+            return kp[:b], d[:b], kp[b:], d[b:], packed
         k1, d1, packed = self._detect_describe(image1)
         k2, d2, _ = self._detect_describe(image2)
+        return k1, d1, k2, d2, packed
+
+    def _match(self, image1, image2):
+        k1, d1, k2, d2, packed = self._detect_describe_pair(image1, image2)
         if packed:
             out = self.matcher.forward_bits(d1, d2, self.descriptor.normalize_descriptors)
         else:
@@ -70,10 +81,7 @@ class ShiTomasiAngleSparseBADSinkhornMatcher(_AngleMatcherBase):
     @torch.no_grad()
     def match_solution(self, image1: torch.Tensor, image2: torch.Tensor):
         """forward() up to the Sinkhorn duals (see MatchExtractionWrapper)."""
-        if image1.shape != image2.shape:
-            raise RuntimeError(f"image shapes differ: {tuple(image1.shape)} vs {tuple(image2.shape)}")
-        k1, d1, packed = self._detect_describe(image1)
-        k2, d2, _ = self._detect_describe(image2)
+        k1, d1, k2, d2, packed = self._detect_describe_pair(image1, image2)
         if packed:
             return k1, k2, self.matcher.solve_bits(d1, d2, self.descriptor.normalize_descriptors)
         return k1, k2, self.matcher.solve(d1, d2)
