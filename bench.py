@@ -451,18 +451,18 @@ def measure_u8_and_streamed(model, a8: np.ndarray, b8: np.ndarray, steps: int) -
     for _ in range(3):
         step(0)
     torch.cuda.synchronize()
-    _native.enable_timing(True, only={"mi_corner_response_balanced"})
+    _native.enable_timing(True, only={"mi_corner_response_pair"})
     t0 = time.perf_counter()
     for i in range(steps):
         rec = step(i & 1)
     torch.cuda.synchronize()
     resident_ms = (time.perf_counter() - t0) * 1e3 / steps
-    k1 = _native.timings_ms()["mi_corner_response_balanced"]
+    k1 = _native.timings_ms()["mi_corner_response_pair"]
     _native.enable_timing(False)
     u8 = {"value": B / (resident_ms * 1e-3), "unit": "image-pairs/sec", "ms_per_step": resident_ms, "steps": steps,
-          "what": "the default workload on uint8 frames resident in HBM (mi_corner_response_balanced / mi_sparse_bad_u8)",
+          "what": "the default workload on uint8 frames resident in HBM (mi_corner_response_pair / mi_sparse_bad_pair on uint8 pixels)",
           "mean_valid_matches_per_pair": float(rec[..., 5].sum().item()) / B,
-          "roofline": k1_roofline(float(np.mean(k1)), 5.0, B, "corner_stream_kernel<3,5,uint8> (mi_corner_response_balanced)",
+          "roofline": k1_roofline(float(np.mean(k1)), 5.0, 2 * B, "corner_stream_kernel<3,5,uint8> (mi_corner_response_pair: both images of every pair in one launch)",
                                   "corner_stream_kernel<3,5,true>", B)}
 
     main = torch.cuda.current_stream()
@@ -529,7 +529,7 @@ def side_model(name: str):
     as a multiple of the pairs per step))"""
     from onnx_image_processing_amd.pytorch_model.feature_detection import (AKAZESparseBADSinkhornMatcher,
                                                                            ShiTomasiSparseBADSinkhornMatcher)
-    k1 = ("mi_corner_response_balanced", "corner_stream_kernel<3,4> (mi_corner_response_balanced)", 8.0, "corner_stream_kernel<3,4,false>", 1)
+    k1 = ("mi_corner_response_pair", "corner_stream_kernel<3,4> (mi_corner_response_pair: both images of every pair in one launch)", 8.0, "corner_stream_kernel<3,4,false>", 2)
     if name == "c3":
         return (ShiTomasiSparseBADSinkhornMatcher(max_keypoints=1024, **CFG), 1080, 1920, 1024,
                 "Shi-Tomasi sparse pipeline, 1920x1080, K=1024 (BASELINE configs[2])", k1)
@@ -553,7 +553,7 @@ def side_model(name: str):
                 "BAD(512, hard) + Sinkhorn(20, eps 0.05) + essential-matrix head), 640x480, K=512, Angle export-CLI values; "
                 "per pair what sample/visual_odometry.py:520-613 consumes: E and the 100 best mutual matches "
                 "(match_and_essential: both straight from the Sinkhorn solution, P not written)",
-                ("mi_corner_response_balanced", "corner_stream_kernel<5,4,float> (block 5: the streaming LDS-DMA kernel)", 8.0, "corner_stream_kernel<5,4,false>", 1))
+                ("mi_corner_response_pair", "corner_stream_kernel<5,4,float> (block 5: the streaming LDS-DMA kernel; both images of every pair in one launch)", 8.0, "corner_stream_kernel<5,4,false>", 2))
     # c4: one scale per launch for BOTH images of every pair (2 B images): reads the previous scale's image, writes the
     # diffused image and the scale's score map -- 12 B/px (the middle scale, mi_akaze_scale; the first reads two batches,
     # the last folds the selection across scales in: 4 + 4 + 4 + 8 + 1 B/px)
@@ -991,7 +991,7 @@ def main() -> None:
     for _ in range(max(0, 14 - args.warmup - (2 if (world > 1 or forced) else 0))):
         step()
     gather.drain()
-    _native.enable_timing(True, only=None if args.single_call else {"mi_corner_response_balanced"})
+    _native.enable_timing(True, only=None if args.single_call else {"mi_corner_response_pair"})
     elapsed_ms, per_step, out, own_ms = run_timed(step, args.steps, args.warmup, world, dev, torch.cuda.synchronize, gather.drain)
     schedule = _ops.sinkhorn_schedule(B, K, K, CFG["sinkhorn_iterations"])
     facts = world_facts(own_ms, args.steps, dev)
@@ -1044,22 +1044,22 @@ def main() -> None:
             "kernels": kernels,
         }
         if not args.single_call:
-            # K1 corner response: 8 algorithmic bytes per pixel (4 read + 4 written); one launch covers one image of
-            # every pair of this rank, two launches per step
-            k1 = per_call["mi_corner_response_balanced"][2 * args.warmup:]
+            # K1 corner response: 8 algorithmic bytes per pixel (4 read + 4 written); one launch covers BOTH images of
+            # every pair of this rank (mi_corner_response_pair: 2 B images), one launch per step
+            k1 = per_call["mi_corner_response_pair"][args.warmup:]
             if u8_main:
-                line["roofline"] = k1_roofline(float(np.mean(k1)), 5.0, B, "corner_stream_kernel<3,5,uint8> (mi_corner_response_balanced)",
+                line["roofline"] = k1_roofline(float(np.mean(k1)), 5.0, 2 * B, "corner_stream_kernel<3,5,uint8> (mi_corner_response_pair: both images of every pair in one launch)",
                                                "corner_stream_kernel<3,5,true>", B)
             else:
-                line["roofline"] = k1_roofline(float(np.mean(k1)), 8.0, B, "corner_stream_kernel<3,4,float> (mi_corner_response_balanced)",
+                line["roofline"] = k1_roofline(float(np.mean(k1)), 8.0, 2 * B, "corner_stream_kernel<3,4,float> (mi_corner_response_pair: both images of every pair in one launch)",
                                                "corner_stream_kernel<3,4,false>", B)
             # informational: the other stages by their algorithmic bytes / operations
             other = {}
             if "mi_nms_candidates" in stages:
                 t = float(np.mean(stages["mi_nms_candidates"]))
-                other["mi_nms_candidates"] = {"bytes_per_call": 4.0 * B * H * W, "unit": "GB/s",
-                                              "achieved": 4.0 * B * H * W / (t * 1e-3) / 1e9, "bound": "hbm",
-                                              "peak": HBM_PEAK_GBS, "frac": 4.0 * B * H * W / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                other["mi_nms_candidates"] = {"bytes_per_call": 4.0 * 2 * B * H * W, "unit": "GB/s",      # one call: 2 B score maps
+                                              "achieved": 4.0 * 2 * B * H * W / (t * 1e-3) / 1e9, "bound": "hbm",
+                                              "peak": HBM_PEAK_GBS, "frac": 4.0 * 2 * B * H * W / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
             if "mi_sinkhorn_dots" in stages:
                 t = float(np.mean(stages["mi_sinkhorn_dots"]))
                 nb = 2.0 * B * K * K * CFG["sinkhorn_iterations"]

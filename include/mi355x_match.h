@@ -135,6 +135,12 @@ MI_API int mi_convert_u8_f32(const uint8_t *src, long long count, float *dst, mi
 #define MI_TILE_COUNTER_BYTES 16640
 MI_API int mi_corner_response_balanced(const void *image, int pixels_are_u8, int n, int h, int w, int block_size, float *score,
                                 uint32_t *tile_counter, mi_stream_t stream);
+/* image1 / image2 of a matcher (two equally shaped batches of per_set images) behind ONE launch, like mi_match_pairs
+ * does inside: score is (2 * per_set, h, w), batch a first; NMS and top-k then run on one batch of twice the size.
+ * The same per-image results as two calls; half the launches and one tail instead of two (the _pair entries below:
+ * mi_sparse_bad_pair, mi_angle_at_keypoints_pair, mi_sparse_bad_oriented_pair; AKAZE: mi_akaze_scale_sets). */
+MI_API int mi_corner_response_pair(const void *image_a, const void *image_b, int pixels_are_u8, int per_set, int h, int w,
+                            int block_size, float *score, uint32_t *tile_counter, mi_stream_t stream);
 
 /* ---- utils/keypoint_utils.py:12-44  apply_nms_maxpool ---------------------------------------
  * mask = 1.0f where score >= max over the (2r+1)^2 window (outside image = -inf) - 1e-7. */
@@ -191,6 +197,12 @@ MI_API int mi_sparse_bad_u8(const uint8_t *image, int n, int h, int w, const flo
                      const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
                      float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
                      uint8_t *status, mi_stream_t stream);
+/* mi_sparse_bad / _u8 for image1 / image2 behind one launch (see mi_corner_response_pair): keypoints (2 * per_set, k, 2),
+ * status (2 * per_set * k) and the outputs hold batch a first. */
+MI_API int mi_sparse_bad_pair(const void *image_a, const void *image_b, int pixels_are_u8, int per_set, int h, int w,
+                       const float *keypoints, int k, const uint32_t *pair_geom, const float *pair_thr, int num_pairs,
+                       int mode, float temperature, int normalize, float *desc, uint32_t *bits, const void *plan,
+                       uint8_t *status, mi_stream_t stream);
 
 /* ---- descriptor/bad.py:62-110,189-218  BADDescriptor.forward (dense, non-oriented) ------------
  * out (n, num_pairs, h, w): the BAD response at every pixel, raw / sigmoid(-c*T) / (c <= 0),
@@ -217,6 +229,11 @@ MI_API int mi_angle_map(const float *image, int n, int h, int w, int patch_size,
                  float *angle, mi_stream_t stream);
 MI_API int mi_angle_at_keypoints(const float *image, int n, int h, int w, const float *keypoints, int k,
                           int patch_size, const float *moment_kernels, float *theta, mi_stream_t stream);
+/* mi_angle_at_keypoints for image1 / image2 behind one launch (see mi_corner_response_pair): keypoints (2 * per_set, k, 2),
+ * theta (2 * per_set, k), batch a first. */
+MI_API int mi_angle_at_keypoints_pair(const float *image_a, const float *image_b, int per_set, int h, int w,
+                               const float *keypoints, int k, int patch_size, const float *moment_kernels, float *theta,
+                               mi_stream_t stream);
 
 /* ---- descriptor/bad.py:487-517  SparseBAD.forward, oriented branch; and sampling_mode "bilinear" --
  * Pair offsets rotated by the keypoint's angle, which comes either from a dense orientation map
@@ -235,6 +252,13 @@ MI_API int mi_sparse_bad_oriented(const float *image, int n, int h, int w, const
                            const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
                            float temperature, int normalize, int bilinear, float max_reach, float *desc,
                            uint32_t *bits, uint8_t *status, mi_stream_t stream);
+/* mi_sparse_bad_oriented with per-keypoint angles for image1 / image2 behind one launch (see mi_corner_response_pair):
+ * keypoints (2 * per_set, k, 2), keypoint_angles (2 * per_set, k), status and the outputs hold batch a first. */
+MI_API int mi_sparse_bad_oriented_pair(const float *image_a, const float *image_b, int per_set, int h, int w,
+                                const float *keypoints, int k, const float *keypoint_angles, const uint32_t *pair_geom,
+                                const float *pair_thr, int num_pairs, int mode, float temperature, int normalize,
+                                int bilinear, float max_reach, float *desc, uint32_t *bits, uint8_t *status,
+                                mi_stream_t stream);
 
 /* ---- matching/sinkhorn.py:79-110,178  cost matrix -> core log-score matrix --------------------
  * z[b, i, j] = -cost(desc1[b,i], desc2[b,j]) / epsilon for i < n, j < m; row pitch `pitch` floats

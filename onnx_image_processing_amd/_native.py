@@ -27,6 +27,7 @@ SIGNATURES = {
     "mi_corner_response_u8": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mi_convert_u8_f32": [c_void_p, ctypes.c_longlong, c_void_p, c_void_p],
     "mi_corner_response_balanced": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "mi_corner_response_pair": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mi_nms_mask": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "mi_candidate_layout": [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)],
     "mi_nms_candidates": [c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p],
@@ -38,6 +39,8 @@ SIGNATURES = {
                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mi_sparse_bad_u8": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mi_sparse_bad_pair": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                           c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mi_bad_dense": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p],
     "mi_bad_dense_oriented": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
                               c_void_p],
@@ -46,6 +49,10 @@ SIGNATURES = {
     "mi_angle_at_keypoints": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mi_sparse_bad_oriented": [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_int, c_int, c_float, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mi_angle_at_keypoints_pair": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                   c_void_p],
+    "mi_sparse_bad_oriented_pair": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_int, c_float, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "mi_cost_logscores_bits": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p],
     "mi_cost_logscores_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p],
     "mi_sinkhorn_workspace_bytes": [c_int, c_int, c_int],

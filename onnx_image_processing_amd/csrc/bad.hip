@@ -589,6 +589,19 @@ extern "C" int mi_sparse_bad(const float *image, int n, int h, int w, const floa
                                   normalize, desc, bits, plan, status, stream);
 }
 
+// image1 / image2 of a matcher behind one launch: keypoints (2 * per_set, k, 2) and the outputs hold batch a first
+extern "C" int mi_sparse_bad_pair(const void *image_a, const void *image_b, int pixels_are_u8, int per_set, int h, int w,
+                                  const float *keypoints, int k, const uint32_t *pair_geom, const float *pair_thr,
+                                  int num_pairs, int mode, float temperature, int normalize, float *desc, uint32_t *bits,
+                                  const void *plan, uint8_t *status, mi_stream_t stream) {
+  MI_ENTER();
+  if (!image_b) return MI_E_NULL;
+  if (per_set <= 0 || per_set > 0x3fffffff) return MI_E_SHAPE;
+  return mi_sparse_bad_sets(MiSets{image_a, image_b, per_set}, pixels_are_u8 ? 1 : 0, 2 * per_set, h, w,
+                            mi_one_set(keypoints, 2 * per_set), k, pair_geom, pair_thr, num_pairs, mode, temperature,
+                            normalize, desc, bits, plan, status, stream);
+}
+
 // u8 ingest: the same descriptors from uint8 pixels (a uint8 frame is what the camera delivers; the reference converts
 // it to float32 on the host first, sample/visual_odometry.py:65-92)
 extern "C" int mi_sparse_bad_u8(const uint8_t *image, int n, int h, int w, const float *keypoints, int k,

@@ -38,7 +38,7 @@ __device__ __forceinline__ int nearest_centre_o(float pos, float scale, int size
 // DESC = false (packed bits only, what the matchers ask for): no float staging array -- 14.9 instead of 19 KB of LDS per
 // keypoint, i.e. 10 instead of 8 resident keypoints per CU; the kernel is bound by how many windows are in flight.
 struct OrientedArgs {
-  const float *image;
+  MiSets images;
   int h, w;
   const float *kpts;
   int k;
@@ -62,7 +62,7 @@ __device__ __forceinline__ void bad_oriented_body(const OrientedArgs &A, int fla
   constexpr int OOFF = OW / 2 - 1;  // window origin = floor(k) - OOFF
   constexpr int OSP = OW + 1;       // SAT edge
   constexpr int RB = OW / 4;        // rows / columns per batch of the in-LDS prefix pass
-  const float *image = A.image, *kpts = A.kpts, *theta_map = A.theta_map, *theta_kp = A.theta_kp, *thr = A.thr;
+  const float *kpts = A.kpts, *theta_map = A.theta_map, *theta_kp = A.theta_kp, *thr = A.thr;
   const uint32_t *geom = A.geom;
   const int h = A.h, w = A.w, k = A.k, num_pairs = A.num_pairs, mode = A.mode, normalize = A.normalize;
   const int bilinear = A.bilinear;
@@ -72,7 +72,7 @@ __device__ __forceinline__ void bad_oriented_body(const OrientedArgs &A, int fla
   uint8_t *status = A.status;
   const int lane = threadIdx.x;
   const int img = flat / k;
-  const float *im = image + (size_t)img * h * w;
+  const float *im = mi_set_item<float>(A.images, img, (size_t)h * w);
   const float ky_raw = kpts[(size_t)flat * 2 + 0];
   const float kx_raw = kpts[(size_t)flat * 2 + 1];
   const bool valid = ky_raw >= 0.0f;                                   // bad.py:461
@@ -283,7 +283,7 @@ __device__ __forceinline__ void rotated_positions(uint32_t q, float ky, float kx
 // sigmoid / 0-1, normalised or not --, the pair value formed by the generic kernel's own expressions (fp64 mean minus
 // threshold) and kept in registers until the norm is known (the generic kernel stages it in LDS).
 template <int OW, int GROUPS, bool DESC>
-__global__ __launch_bounds__(64) void bad_oriented_bits_kernel(const float *__restrict__ image, int h, int w,
+__global__ __launch_bounds__(64) void bad_oriented_bits_kernel(MiSets images, int h, int w,
                                                                const float *__restrict__ kpts, int k,
                                                                const float *__restrict__ theta_map,
                                                                const float *__restrict__ theta_kp,
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64) void bad_oriented_bits_kernel(const float *__re
   const int lane = threadIdx.x;
   const int flat = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
   const int img = flat / k;
-  const float *im = image + (size_t)img * h * w;
+  const float *im = mi_set_item<float>(images, img, (size_t)h * w);
   const float ky_raw = kpts[(size_t)flat * 2 + 0];
   const float kx_raw = kpts[(size_t)flat * 2 + 1];
   uint4 *brow = DESC ? nullptr : reinterpret_cast<uint4 *>(bits + (size_t)flat * (2 * GROUPS));
@@ -474,14 +474,15 @@ __global__ __launch_bounds__(64) void bad_oriented_bits_kernel(const float *__re
 }
 }  // namespace
 
-extern "C" int mi_sparse_bad_oriented(const float *image, int n, int h, int w, const float *keypoints, int k,
+static int sparse_bad_oriented_launch(MiSets images, int n, int h, int w, const float *keypoints, int k,
                                       const float *orientation_map, const float *keypoint_angles,
                                       const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
                                       float temperature, int normalize, int bilinear, float max_reach, float *desc,
                                       uint32_t *bits, uint8_t *status, mi_stream_t stream) {
-  MI_ENTER();
-  if (!image || !keypoints || !pair_geom || !pair_thr) return MI_E_NULL;
+  const float *image = static_cast<const float *>(images.a);
+  if (!image || (images.per_set < n && !images.b) || !keypoints || !pair_geom || !pair_thr) return MI_E_NULL;
   if (!orientation_map == !keypoint_angles) return MI_E_NULL;          // exactly one angle source
+  if (orientation_map && images.per_set < n) return MI_E_PARAM;         // a dense angle map belongs to ONE image batch
   if (!desc && !bits) return MI_E_NULL;
   if (n <= 0 || h <= 0 || w <= 0 || k <= 0 || (long long)n * k > 0x7fffffffLL) return MI_E_SHAPE;
   if (num_pairs <= 0 || num_pairs % 64 != 0 || num_pairs > 1024) return MI_E_PARAM;
@@ -491,14 +492,14 @@ extern "C" int mi_sparse_bad_oriented(const float *image, int n, int h, int w, c
   const float scale_x = (float)(2.0 / ((double)(w - 1) + 1e-8));
   if (!(max_reach >= 0.0f)) return MI_E_PARAM;
   const bool small = !bilinear && max_reach > 0.0f && max_reach <= 22.5f;   // see the window note at the top
-  OrientedArgs A{image, h, w, keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, num_pairs, mode,
+  OrientedArgs A{images, h, w, keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, num_pairs, mode,
                  temperature, normalize, scale_y, scale_x, bilinear ? 1 : 0, desc, bits, status};
   const unsigned total = (unsigned)(n * k);
   hipStream_t s = (hipStream_t)stream;
 #define BO_LAUNCH(SAT, DESC, OWIN) hipLaunchKernelGGL((bad_oriented_kernel<SAT, DESC, OWIN>), dim3(total), dim3(64), 0, s, A)
 #define BO_PICK(SAT) do { if (desc) { if (small) BO_LAUNCH(SAT, true, 48); else BO_LAUNCH(SAT, true, 60); } else { if (small) BO_LAUNCH(SAT, false, 48); else BO_LAUNCH(SAT, false, 60); } } while (0)
 #define BO_REST(DESC, OWIN) hipLaunchKernelGGL((bad_oriented_rest_kernel<DESC, OWIN>), dim3((total + 63u) / 64u), dim3(64), 0, s, A, (int)total)
-#define BO_FAST(OWIN, G, D) hipLaunchKernelGGL((bad_oriented_bits_kernel<OWIN, G, D>), dim3(total), dim3(64), 0, s, image, h, w, keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, scale_y, scale_x, bits, desc, mode, temperature, normalize, status)
+#define BO_FAST(OWIN, G, D) hipLaunchKernelGGL((bad_oriented_bits_kernel<OWIN, G, D>), dim3(total), dim3(64), 0, s, images, h, w, keypoints, k, orientation_map, keypoint_angles, pair_geom, pair_thr, scale_y, scale_x, bits, desc, mode, temperature, normalize, status)
   if (!status) {                                                        // no scratch for the two-pass form: fp64 for all
     BO_PICK(double);
     return mi_launch_status();
@@ -524,4 +525,28 @@ extern "C" int mi_sparse_bad_oriented(const float *image, int n, int h, int w, c
 #undef BO_PICK
 #undef BO_LAUNCH
   return mi_launch_status();
+}
+
+extern "C" int mi_sparse_bad_oriented(const float *image, int n, int h, int w, const float *keypoints, int k,
+                                      const float *orientation_map, const float *keypoint_angles,
+                                      const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
+                                      float temperature, int normalize, int bilinear, float max_reach, float *desc,
+                                      uint32_t *bits, uint8_t *status, mi_stream_t stream) {
+  MI_ENTER();
+  return sparse_bad_oriented_launch(mi_one_set(image, n), n, h, w, keypoints, k, orientation_map, keypoint_angles, pair_geom,
+                                    pair_thr, num_pairs, mode, temperature, normalize, bilinear, max_reach, desc, bits,
+                                    status, stream);
+}
+
+extern "C" int mi_sparse_bad_oriented_pair(const float *image_a, const float *image_b, int per_set, int h, int w,
+                                           const float *keypoints, int k, const float *keypoint_angles,
+                                           const uint32_t *pair_geom, const float *pair_thr, int num_pairs, int mode,
+                                           float temperature, int normalize, int bilinear, float max_reach, float *desc,
+                                           uint32_t *bits, uint8_t *status, mi_stream_t stream) {
+  MI_ENTER();
+  if (!image_b) return MI_E_NULL;
+  if (per_set <= 0 || per_set > 0x3fffffff) return MI_E_SHAPE;
+  return sparse_bad_oriented_launch(MiSets{image_a, image_b, per_set}, 2 * per_set, h, w, keypoints, k, nullptr,
+                                    keypoint_angles, pair_geom, pair_thr, num_pairs, mode, temperature, normalize, bilinear,
+                                    max_reach, desc, bits, status, stream);
 }

@@ -789,3 +789,14 @@ extern "C" int mi_corner_response_balanced(const void *image, int pixels_are_u8,
   return mi_corner_response_sets(mi_one_set(image, n), pixels_are_u8 ? 1 : 0, n, h, w, block_size, score, tile_counter,
                                  stream);
 }
+
+// image1 / image2 of a matcher behind one launch: score is (2 * per_set, h, w), batch a first
+extern "C" int mi_corner_response_pair(const void *image_a, const void *image_b, int pixels_are_u8, int per_set, int h,
+                                       int w, int block_size, float *score, uint32_t *tile_counter, mi_stream_t stream) {
+  MI_ENTER();
+  if (!image_b) return MI_E_NULL;
+  if (per_set <= 0 || per_set > 0x3fffffff) return MI_E_SHAPE;
+  if (tile_counter && ((uintptr_t)tile_counter % 4) != 0) return MI_E_ALIGN;
+  return mi_corner_response_sets(MiSets{image_a, image_b, per_set}, pixels_are_u8 ? 1 : 0, 2 * per_set, h, w, block_size,
+                                 score, tile_counter, stream);
+}

@@ -124,7 +124,7 @@ __device__ __forceinline__ float patch_angle(const float *__restrict__ im, int h
 }
 
 template <int PS>
-__global__ __launch_bounds__(64) void angle_kp_kernel(const float *__restrict__ image, int h, int w,
+__global__ __launch_bounds__(64) void angle_kp_kernel(MiSets images, int h, int w,
                                                       const float *__restrict__ kpts, int k, int ps,
                                                       const float *__restrict__ weights,
                                                       float *__restrict__ theta) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64) void angle_kp_kernel(const float *__restrict__ 
   const int img = flat / k;
   int cy, cx;
   nearest_pixel(kpts, flat, h, w, cy, cx);
-  const float a = patch_angle<PS>(image + (size_t)img * h * w, h, w, cy, cx, ps, weights, lane);
+  const float a = patch_angle<PS>(mi_set_item<float>(images, img, (size_t)h * w), h, w, cy, cx, ps, weights, lane);
   if (lane == 0) theta[flat] = a;
 }
 
@@ -183,20 +183,34 @@ extern "C" int mi_angle_map(const float *image, int n, int h, int w, int patch_s
   return mi_launch_status();
 }
 
+static int angle_at_keypoints_launch(MiSets images, int n, int h, int w, const float *keypoints, int k, int patch_size,
+                                     const float *moment_kernels, float *theta, mi_stream_t stream) {
+  if (!images.a || (images.per_set < n && !images.b) || !keypoints || !moment_kernels || !theta) return MI_E_NULL;
+  if (n <= 0 || h <= 0 || w <= 0 || k <= 0 || (long long)n * k > 0x7fffffffLL) return MI_E_SHAPE;
+  if (patch_size <= 0 || (patch_size & 1) == 0 || patch_size > MAX_PS) return MI_E_PARAM;
+  if (patch_size == 15)
+    hipLaunchKernelGGL(angle_kp_kernel<15>, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, images, h, w,
+                       keypoints, k, patch_size, moment_kernels, theta);
+  else
+    hipLaunchKernelGGL(angle_kp_kernel<0>, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, images, h, w,
+                       keypoints, k, patch_size, moment_kernels, theta);
+  return mi_launch_status();
+}
+
 extern "C" int mi_angle_at_keypoints(const float *image, int n, int h, int w, const float *keypoints, int k,
                                      int patch_size, const float *moment_kernels, float *theta,
                                      mi_stream_t stream) {
   MI_ENTER();
-  if (!image || !keypoints || !moment_kernels || !theta) return MI_E_NULL;
-  if (n <= 0 || h <= 0 || w <= 0 || k <= 0 || (long long)n * k > 0x7fffffffLL) return MI_E_SHAPE;
-  if (patch_size <= 0 || (patch_size & 1) == 0 || patch_size > MAX_PS) return MI_E_PARAM;
-  if (patch_size == 15)
-    hipLaunchKernelGGL(angle_kp_kernel<15>, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, image, h, w,
-                       keypoints, k, patch_size, moment_kernels, theta);
-  else
-    hipLaunchKernelGGL(angle_kp_kernel<0>, dim3((unsigned)(n * k)), dim3(64), 0, (hipStream_t)stream, image, h, w,
-                       keypoints, k, patch_size, moment_kernels, theta);
-  return mi_launch_status();
+  return angle_at_keypoints_launch(mi_one_set(image, n), n, h, w, keypoints, k, patch_size, moment_kernels, theta, stream);
+}
+
+extern "C" int mi_angle_at_keypoints_pair(const float *image_a, const float *image_b, int per_set, int h, int w,
+                                          const float *keypoints, int k, int patch_size, const float *moment_kernels,
+                                          float *theta, mi_stream_t stream) {
+  MI_ENTER();
+  if (!image_b || per_set <= 0 || per_set > 0x3fffffff) return image_b ? MI_E_SHAPE : MI_E_NULL;
+  return angle_at_keypoints_launch(MiSets{image_a, image_b, per_set}, 2 * per_set, h, w, keypoints, k, patch_size,
+                                   moment_kernels, theta, stream);
 }
 
 extern "C" int mi_akaze_orientation_select(const float *scale_images, size_t scale_stride, int num_scales,

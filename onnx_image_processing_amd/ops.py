@@ -26,9 +26,37 @@ def convert_u8(image: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _images(image: torch.Tensor, what: str, keep_u8: bool = False) -> torch.Tensor:
+class ImagePair:
+    """image1 / image2 of a matcher (two equally shaped (B,1,H,W) batches) as ONE batch of 2B images, batch a first, for
+    the front-end entry points that take two base pointers (`mi_corner_response_pair`, `mi_sparse_bad_pair`,
+    `mi_angle_at_keypoints_pair`, `mi_sparse_bad_oriented_pair`): nothing is concatenated, every stage is one launch
+    for both images, and what follows (NMS, top-k, ...) runs on ordinary (2B, ...) tensors.  Accepted wherever those four
+    ops take `image`."""
+
+    def __init__(self, a: torch.Tensor, b: torch.Tensor):
+        if a.shape != b.shape or a.dtype != b.dtype or a.device != b.device:
+            raise RuntimeError(f"image batches differ: {tuple(a.shape)} {a.dtype} {a.device} vs {tuple(b.shape)} {b.dtype} {b.device}")
+        self.a, self.b = a, b
+
+    @property
+    def device(self):
+        return self.a.device
+
+    @property
+    def dtype(self):
+        return self.a.dtype
+
+    @property
+    def shape(self):
+        return torch.Size((2 * self.a.shape[0],) + tuple(self.a.shape[1:]))
+
+
+def _images(image, what: str, keep_u8: bool = False):
     """(N,1,H,W) image batch as a contiguous float32 tensor.  uint8 frames (the u8 ingest path): kept as they are for
-    the entry points that have a uint8 form (keep_u8), converted on the device for the others."""
+    the entry points that have a uint8 form (keep_u8), converted on the device for the others.  An ImagePair comes
+    back as an ImagePair of two such tensors."""
+    if isinstance(image, ImagePair):
+        return ImagePair(_images(image.a, what, keep_u8), _images(image.b, what, keep_u8))
     if image.dim() != 4 or image.shape[1] != 1:
         raise RuntimeError(f"{what} must have shape (N, 1, H, W), got {tuple(image.shape)}")
     if image.dtype == U8:
@@ -77,6 +105,10 @@ def corner_response(image: torch.Tensor, block_size: int) -> torch.Tensor:
     # K1's ticket counters: a fresh block per call from the caching allocator (stream-ordered: no sharing between
     # streams, nothing cached per stream); the library clears it on the stream before the kernel draws from it
     ctr = torch.empty(TILE_COUNTER_BYTES // 4, dtype=torch.int32, device=img.device)
+    if isinstance(img, ImagePair):
+        N.call("mi_corner_response_pair", N.dev(img.a, U8 if u8 else F32, "image"), N.dev(img.b, U8 if u8 else F32, "image"),
+               int(u8), n // 2, h, w, int(block_size), N.dev(out, F32, "score"), ctr.data_ptr(), N.stream_ptr())
+        return out
     N.call("mi_corner_response_balanced", N.dev(img, U8 if u8 else F32, "image"), int(u8), n, h, w, int(block_size),
            N.dev(out, F32, "score"), ctr.data_ptr(), N.stream_ptr())
     return out
@@ -167,6 +199,15 @@ def sparse_bad(image: torch.Tensor, keypoints: torch.Tensor, pair_geom: torch.Te
     desc = torch.empty((n, k, p), dtype=F32, device=img.device) if want_desc else None
     bits = torch.empty((n, k, p // 32), dtype=torch.int32, device=img.device) if want_bits else None
     u8 = img.dtype == U8
+    if isinstance(img, ImagePair):
+        N.call("mi_sparse_bad_pair", N.dev(img.a, U8 if u8 else F32, "image"), N.dev(img.b, U8 if u8 else F32, "image"),
+               int(u8), n // 2, h, w, N.dev(kp, F32, "keypoints"), k,
+               N.dev(pair_geom, torch.int32, "pair_geom"), N.dev(pair_thr, F32, "pair_thr"), p, int(mode),
+               float(temperature), int(bool(normalize)), desc.data_ptr() if want_desc else None,
+               bits.data_ptr() if want_bits else None, plan.data_ptr() if plan is not None else None,
+               torch.empty((n * k,), dtype=torch.uint8, device=img.device).data_ptr() if plan is not None else None,
+               N.stream_ptr())
+        return desc, bits
     N.call("mi_sparse_bad_u8" if u8 else "mi_sparse_bad", N.dev(img, U8 if u8 else F32, "image"), n, h, w,
            N.dev(kp, F32, "keypoints"), k,
            N.dev(pair_geom, torch.int32, "pair_geom"), N.dev(pair_thr, F32, "pair_thr"), p, int(mode),
@@ -230,6 +271,11 @@ def angle_at_keypoints(image: torch.Tensor, keypoints: torch.Tensor, moment_kern
     n, _, h, w = img.shape
     kp = keypoints.float().contiguous()
     theta = torch.empty((n, kp.shape[1]), dtype=F32, device=img.device)
+    if isinstance(img, ImagePair):
+        N.call("mi_angle_at_keypoints_pair", N.dev(img.a, F32, "image"), N.dev(img.b, F32, "image"), n // 2, h, w,
+               N.dev(kp, F32, "keypoints"), kp.shape[1], int(patch_size),
+               N.dev(moment_kernels.contiguous(), F32, "moment_kernels"), theta.data_ptr(), N.stream_ptr())
+        return theta
     N.call("mi_angle_at_keypoints", N.dev(img, F32, "image"), n, h, w, N.dev(kp, F32, "keypoints"), kp.shape[1],
            int(patch_size), N.dev(moment_kernels.contiguous(), F32, "moment_kernels"), theta.data_ptr(),
            N.stream_ptr())
@@ -260,6 +306,15 @@ def sparse_bad_oriented(image: torch.Tensor, keypoints: torch.Tensor, orientatio
     desc = torch.empty((n, k, p), dtype=F32, device=img.device) if want_desc else None
     bits = torch.empty((n, k, p // 32), dtype=torch.int32, device=img.device) if want_bits else None
     status = torch.empty((n, k), dtype=torch.uint8, device=img.device)      # int32-table fast path bookkeeping
+    if isinstance(img, ImagePair):
+        if akp is None:
+            raise RuntimeError("an ImagePair takes per-keypoint angles (2B, K), not a dense orientation map")
+        N.call("mi_sparse_bad_oriented_pair", N.dev(img.a, F32, "image"), N.dev(img.b, F32, "image"), n // 2, h, w,
+               N.dev(kp, F32, "keypoints"), k, akp, N.dev(pair_geom, torch.int32, "pair_geom"),
+               N.dev(pair_thr, F32, "pair_thr"), p, int(mode), float(temperature), int(bool(normalize)),
+               int(bool(bilinear)), float(max_reach), desc.data_ptr() if want_desc else None,
+               bits.data_ptr() if want_bits else None, status.data_ptr(), N.stream_ptr())
+        return desc, bits
     N.call("mi_sparse_bad_oriented", N.dev(img, F32, "image"), n, h, w, N.dev(kp, F32, "keypoints"), k, amap, akp,
            N.dev(pair_geom, torch.int32, "pair_geom"), N.dev(pair_thr, F32, "pair_thr"), p, int(mode),
            float(temperature), int(bool(normalize)), int(bool(bilinear)), float(max_reach),

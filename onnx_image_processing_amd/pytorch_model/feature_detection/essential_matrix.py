@@ -24,7 +24,8 @@ class _EssentialHead(nn.Module):
                    epsilon, unused_score, distance_type, nms_radius, score_threshold, normalize_descriptors,
                    sampling_mode, border_margin, top_k, n_iter, n_iter_manifold):
         self.max_keypoints = max_keypoints
-        self.joint_batch_limit = 8                # pairs per call up to which image1 / image2 share the front end's launches
+        self.pair_launches = True                 # image1 / image2 share the front end's launches (False: one call per image)
+        self.pair_launches_by_pointer = isinstance(self, ShiTomasiAngleSparseBADSinkhornWithEssentialMatrix)
         self.nms_radius = nms_radius
         self.score_threshold = score_threshold
         self.top_k = top_k
@@ -61,10 +62,13 @@ class _EssentialHead(nn.Module):
         if image1.shape != image2.shape:
             raise RuntimeError(f"image shapes differ: {tuple(image1.shape)} vs {tuple(image2.shape)}")
         b = image1.shape[0]
-        if b <= self.joint_batch_limit:
-            # few pairs per call (the visual-odometry host: ONE): both images through every front-end kernel as one
-            # batch of 2B -- half the launches / graph nodes of the per-call path for one small copy; the kernels treat
-            # images independently, so the halves are what the two separate calls give
+        if self.pair_launches and self.pair_launches_by_pointer and image1.dtype == image2.dtype:
+            # both images through every front-end kernel in ONE launch (ops.ImagePair: two base pointers, nothing is
+            # concatenated): half the launches / graph nodes, one tail per stage instead of two
+            kj, sj, dj, packed = self._describe(ops.ImagePair(image1, image2))
+            k1, k2, s1, s2, d1, d2 = kj[:b], kj[b:], sj[:b], sj[b:], dj[:b], dj[b:]
+        elif self.pair_launches and b <= 8:
+            # (front ends without two-pointer entry points: few pairs per call share the launches through one small copy)
             kj, sj, dj, packed = self._describe(torch.cat([image1, image2], dim=0))
             k1, k2, s1, s2, d1, d2 = kj[:b], kj[b:], sj[:b], sj[b:], dj[:b], dj[b:]
         else:

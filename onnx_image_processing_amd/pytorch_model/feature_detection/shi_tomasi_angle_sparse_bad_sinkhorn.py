@@ -4,6 +4,7 @@ import torch
 from torch import nn
 
 from ... import _native as N
+from ... import ops
 from ..descriptor.bad import SparseBAD
 from ..matching.sinkhorn import SinkhornMatcher, SinkhornMatcherWithFilters
 from ..utils.keypoint_utils import detect_keypoints
@@ -18,7 +19,7 @@ class _AngleMatcherBase(nn.Module):
     def _init_common(self, max_keypoints, block_size, patch_size, sigma, num_pairs, binarize, soft_binarize,
                      temperature, nms_radius, score_threshold, normalize_descriptors, sampling_mode, border_margin):
         self.max_keypoints = max_keypoints
-        self.joint_batch_limit = 8                # pairs per call up to which image1 / image2 share the front end's launches
+        self.pair_launches = True                 # image1 / image2 share the front end's launches (False: one call per image)
         self.nms_radius = nms_radius
         self.score_threshold = score_threshold
         self.detector = ShiTomasiWithAngle(block_size=block_size, patch_size=patch_size, sigma=sigma)
@@ -37,13 +38,13 @@ class _AngleMatcherBase(nn.Module):
         return kp, d, packed
 
     def _detect_describe_pair(self, image1, image2):
-        """-> (k1, d1, k2, d2, packed).  Few pairs per call: both images through every front-end kernel as one batch of
-        2B (half the launches / graph nodes for one small copy; the kernels treat images independently)."""
+        """-> (k1, d1, k2, d2, packed).  Both images go through every front-end kernel in ONE launch (ops.ImagePair: two
+        base pointers, nothing is concatenated); the kernels treat images independently."""
         if image1.shape != image2.shape:
             raise RuntimeError(f"image shapes differ: {tuple(image1.shape)} vs {tuple(image2.shape)}")
         b = image1.shape[0]
-        if b <= self.joint_batch_limit and image1.dtype == image2.dtype:
-            kp, d, packed = self._detect_describe(torch.cat([image1, image2], dim=0))
+        if self.pair_launches and image1.dtype == image2.dtype:
+            kp, d, packed = self._detect_describe(ops.ImagePair(image1, image2))
             return kp[:b], d[:b], kp[b:], d[b:], packed
         k1, d1, packed = self._detect_describe(image1)
         k2, d2, _ = self._detect_describe(image2)

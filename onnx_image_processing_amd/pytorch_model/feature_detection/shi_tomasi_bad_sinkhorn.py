@@ -48,6 +48,18 @@ class ShiTomasiBADSinkhornMatcher(nn.Module):
             raise RuntimeError(f"image shapes differ: {tuple(image1.shape)} vs {tuple(image2.shape)}")
         bad = self.detector.descriptor
         packed = bad.mode == N.MI_BAD_HARD and self.matcher.distance_type == "l2"
+        if getattr(self, "pair_launches", True) and image1.dtype == image2.dtype:
+            # both images through every front-end kernel in ONE launch (ops.ImagePair: two base pointers, nothing concatenated)
+            b = image1.shape[0]
+            image = ops.ImagePair(image1, image2)
+            scores = self.detector.corner_detector(image).squeeze(1)
+            kp, _ = detect_keypoints(scores, self.nms_radius, self.max_keypoints, self.score_threshold, 0)
+            del scores
+            d, bits = ops.sparse_bad(image, kp, bad.pair_geom, bad.pair_thr, bad.mode, bad.temperature,
+                                     self.normalize_descriptors, want_desc=not packed, want_bits=packed,
+                                     plan=self._plan(bad))
+            out = bits if packed else d
+            return [kp[:b], kp[b:]], [out[:b], out[b:]], packed
         kpts, descs = [], []
         for image in (image1, image2):
             scores = self.detector.corner_detector(image).squeeze(1)

@@ -4,6 +4,7 @@ import torch
 from torch import nn
 
 from ... import _native as N
+from ... import ops
 from ..descriptor.bad import SparseBAD
 from ..detector.shi_tomasi import ShiTomasiScore
 from ..matching.sinkhorn import SinkhornMatcher
@@ -43,7 +44,7 @@ class ShiTomasiSparseBADSinkhornMatcher(nn.Module):
     ) -> None:
         super().__init__()
         self.max_keypoints = max_keypoints
-        self.joint_batch_limit = 8                # pairs per call up to which image1 / image2 share the front end's launches
+        self.pair_launches = True                 # image1 / image2 share the front end's launches (False: one call per image)
         self.nms_radius = nms_radius
         self.score_threshold = score_threshold
         self.corner_detector = ShiTomasiScore(block_size=block_size, sobel_size=sobel_size)
@@ -68,13 +69,14 @@ class ShiTomasiSparseBADSinkhornMatcher(nn.Module):
             raise RuntimeError(f"image shapes differ: {tuple(image1.shape)} vs {tuple(image2.shape)}")
         packed = self.descriptor.mode == N.MI_BAD_HARD and self.matcher.distance_type == "l2"
         b = image1.shape[0]
-        if b <= self.joint_batch_limit and image1.dtype == image2.dtype:
-            # few pairs per call (the reference harness: ONE, sample/image_matching.py:313-328): both images through
-            # every front-end kernel as one batch of 2B -- half the launches / graph nodes for one small copy; the
-            # kernels treat images independently, so the halves are what the separate calls give
-            image = torch.cat([image1, image2], dim=0)
+        if self.pair_launches and image1.dtype == image2.dtype:
+            # both images through every front-end kernel in ONE launch (ops.ImagePair: two base pointers, nothing is
+            # concatenated): half the launches / graph nodes and one tail per stage instead of two; the kernels treat
+            # images independently, so the halves are what the separate calls give
+            image = ops.ImagePair(image1, image2)
             scores = self.corner_detector(image).squeeze(1)
             kp, _ = detect_keypoints(scores, self.nms_radius, self.max_keypoints, self.score_threshold, self.border_margin)
+            del scores
             d = self.descriptor.forward_bits(image, kp) if packed else self.descriptor(image, kp)
             return [kp[:b], kp[b:]], [d[:b], d[b:]], packed
         kpts, descs = [], []

@@ -1257,8 +1257,8 @@ def test_vo_model_extensions_equal_forward(mods):
         assert torch.equal(x, y)
     assert torch.equal(out[4], e) and int(want[3].sum()) > 30
     # few pairs per call share the front end's launches (both images as one batch of 2B): the separate calls' outputs
-    assert model.joint_batch_limit >= 3
-    model.joint_batch_limit = 0
+    assert model.pair_launches
+    model.pair_launches = False
     for x, y in zip(model(gpu(a), gpu(b)), (k1, k2, p, e)):
         assert torch.equal(x, y)
 

@@ -295,7 +295,7 @@ def test_hipgraph_replay_through_the_forked_streams(mods, form):
     topo = graph_topology(graphed.graph)
     if os.environ.get("MI_REPORT"):
         print(f"[graph topology, {form}] {topo}")
-    assert topo["nodes"] > 30 and topo["edges"] >= topo["nodes"] - 1
+    assert topo["nodes"] >= 30 and topo["edges"] >= topo["nodes"] - 1      # (unsplit: 30 nodes since both images share the front end's launches)
     assert (topo["forks"] > 0) == (form == "pinned_fork") and (topo["joins"] > 0) == (form == "pinned_fork"), (form, topo)
     for _ in range(2):
         for x, y in zip(graphed(gpu(a), gpu(b)), eager):
