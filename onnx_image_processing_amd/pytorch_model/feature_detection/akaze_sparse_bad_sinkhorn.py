@@ -40,15 +40,20 @@ class AKAZESparseBADSinkhornMatcher(nn.Module):
                                        distance_type=distance_type)
 
     def _detect_describe_pair(self, image1, image2):
-        """Both images' keypoints and descriptors.  Detection -- AKAZE scales, NMS / top-k, orientation -- runs on the two
-        batches as ONE batch of 2B images (the first scale reads them where they lie: no concatenation); the
-        descriptors are evaluated per image."""
+        """Both images' keypoints and descriptors.  Detection -- AKAZE scales, NMS / top-k, orientation -- and description
+        run on the two batches as ONE batch of 2B images (the first scale and the descriptor kernel read them where they
+        lie: no concatenation)."""
         packed = self.descriptor.mode == N.MI_BAD_HARD and self.matcher.distance_type == "l2"
         b = image1.shape[0]
         scores, attain, scale_images = self.detector.detect_select(image1, image2)
         kp, _ = detect_keypoints(scores.squeeze(1), self.nms_radius, self.max_keypoints, self.score_threshold,
                                  self.border_margin)
         theta = self.detector.orientation_at_keypoints(attain, scale_images, kp)
+        if image1.dtype == image2.dtype:
+            from ... import ops
+            pair = ops.ImagePair(image1, image2)
+            d = self.descriptor.forward_bits(pair, kp, theta) if packed else self.descriptor(pair, kp, theta)
+            return kp[:b], d[:b], kp[b:], d[b:], packed
         out = []
         for im, k, t in ((image1, kp[:b], theta[:b]), (image2, kp[b:], theta[b:])):
             k, t = k.contiguous(), t.contiguous()
