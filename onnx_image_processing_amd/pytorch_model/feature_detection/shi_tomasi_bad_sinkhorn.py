@@ -26,6 +26,7 @@ class ShiTomasiBADSinkhornMatcher(nn.Module):
                  normalize_descriptors: bool = True) -> None:
         super().__init__()
         self.max_keypoints = max_keypoints
+        self.pair_launches = True                 # image1 / image2 share the front end's launches (False: one call per image)
         self.nms_radius = nms_radius
         self.score_threshold = score_threshold
         self.normalize_descriptors = normalize_descriptors
@@ -48,7 +49,7 @@ class ShiTomasiBADSinkhornMatcher(nn.Module):
             raise RuntimeError(f"image shapes differ: {tuple(image1.shape)} vs {tuple(image2.shape)}")
         bad = self.detector.descriptor
         packed = bad.mode == N.MI_BAD_HARD and self.matcher.distance_type == "l2"
-        if getattr(self, "pair_launches", True) and image1.dtype == image2.dtype:
+        if self.pair_launches and image1.dtype == image2.dtype:
             # both images through every front-end kernel in ONE launch (ops.ImagePair: two base pointers, nothing concatenated)
             b = image1.shape[0]
             image = ops.ImagePair(image1, image2)

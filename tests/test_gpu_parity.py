@@ -646,6 +646,52 @@ def test_oriented_bad_small_window_equals_full_window(mods):
         ops.sparse_bad_oriented(imgs[0], gpu(kp), gpu(theta), m.pair_geom, m.pair_thr, N.MI_BAD_HARD, 10.0, True, max_reach=-1.0)
 
 
+def test_pair_entries_equal_two_calls(mods):
+    """mi_corner_response_pair / mi_sparse_bad_pair / mi_angle_at_keypoints_pair / mi_sparse_bad_oriented_pair (image1 and
+    image2 of a matcher behind ONE launch, two base pointers, ops.ImagePair) against one call per image batch: identical
+    outputs for float32 and uint8 frames, blocks 3 and 5, bits and float descriptors, a batch large enough for K1's
+    ticket schedule -- and the matchers built on them against their one-call-per-image form (pair_launches = False)."""
+    from onnx_image_processing_amd import _native as N, ops
+    from onnx_image_processing_amd.pytorch_model.feature_detection import (ShiTomasiAngleSparseBADSinkhornMatcher,
+                                                                           ShiTomasiBADSinkhornMatcher)
+    from onnx_image_processing_amd.pytorch_model.orientation.angle_estimation import AngleEstimator
+    for n, h, w in ((3, 120, 160), (70, 128, 256)):
+        a, b = synth_batch(7000 + n, n, h, w)
+        for conv in (lambda x: gpu(x), lambda x: gpu(x.astype(np.uint8))):
+            ia, ib = conv(a), conv(b)
+            pair = ops.ImagePair(ia, ib)
+            for bs in (3, 5):
+                want = torch.cat([ops.corner_response(ia, bs), ops.corner_response(ib, bs)])
+                assert torch.equal(ops.corner_response(pair, bs), want), (n, bs, ia.dtype)
+            kp, _ = ops.nms_topk(want.squeeze(1), 3, 64, 0.0, 7)
+            kp[0, :3] = torch.tensor([[-1.0, -1.0], [0.0, 0.0], [h - 1.0, w - 1.0]], device=DEV)
+            m = mods["SparseBAD"](512, binarize=True, soft_binarize=False).to(DEV)
+            for packed in (True, False):
+                f = (lambda im, k: m.forward_bits(im, k)) if packed else (lambda im, k: m(im, k))
+                assert torch.equal(f(pair, kp), torch.cat([f(ia, kp[:n]), f(ib, kp[n:])])), (n, packed, ia.dtype)
+            est = AngleEstimator(15, 2.5).to(DEV)
+            theta = est.at_keypoints(pair, kp)
+            assert torch.equal(theta, torch.cat([est.at_keypoints(ia, kp[:n]), est.at_keypoints(ib, kp[n:])]))
+            for kw in (dict(binarize=True, soft_binarize=False), dict(binarize=False)):
+                mo = mods["SparseBAD"](256, **kw).to(DEV)
+                got = mo(pair, kp, theta)
+                assert torch.equal(got, torch.cat([mo(ia, kp[:n], theta[:n]), mo(ib, kp[n:], theta[n:])])), (n, kw)
+            with pytest.raises(RuntimeError):
+                mo(pair, kp, torch.zeros((2 * n, 1, h, w), device=DEV))              # a dense angle map: one batch only
+    with pytest.raises(RuntimeError):
+        ops.ImagePair(gpu(a), gpu(b[:1]))
+    # the matchers
+    a, b = synth_batch(7100, 2, 120, 160)
+    cfg = dict(max_keypoints=96, num_pairs=512, binarize=True, soft_binarize=False, epsilon=0.05, nms_radius=3)
+    for cls in (mods["ShiTomasiSparseBADSinkhornMatcher"], ShiTomasiAngleSparseBADSinkhornMatcher, ShiTomasiBADSinkhornMatcher):
+        model = cls(**cfg).to(DEV)
+        assert model.pair_launches if hasattr(model, "pair_launches") else True
+        got = model(gpu(a), gpu(b))
+        model.pair_launches = False
+        for x, y in zip(got, model(gpu(a), gpu(b))):
+            assert torch.equal(x, y), cls.__name__
+
+
 def test_oriented_bad_fast_kernels_equal_the_generic_kernel(mods):
     """The matchers' rotation-aware BAD kernel (all loads up front, straight-line pair phase, fp32 threshold test with
     the product's exact residual; packed bits or float descriptors) against the generic kernel (debug key 13 = 1):
