@@ -66,25 +66,27 @@ class _EssentialHead(nn.Module):
             # both images through every front-end kernel in ONE launch (ops.ImagePair: two base pointers, nothing is
             # concatenated): half the launches / graph nodes, one tail per stage instead of two
             kj, sj, dj, packed = self._describe(ops.ImagePair(image1, image2))
-            k1, k2, s1, s2, d1, d2 = kj[:b], kj[b:], sj[:b], sj[b:], dj[:b], dj[b:]
         elif self.pair_launches and b <= 8:
             # (front ends without two-pointer entry points: few pairs per call share the launches through one small copy)
             kj, sj, dj, packed = self._describe(torch.cat([image1, image2], dim=0))
-            k1, k2, s1, s2, d1, d2 = kj[:b], kj[b:], sj[:b], sj[b:], dj[:b], dj[b:]
         else:
+            kj = None
             k1, s1, d1, packed = self._describe(image1)
             k2, s2, d2, _ = self._describe(image2)
-        q1, q2 = self._normalised(k1.float()), self._normalised(k2.float())
+            q1, q2, ok1, ok2 = self._normalised(k1.float()), self._normalised(k2.float()), s1 > 0, s2 > 0
+        if kj is not None:                                   # the stacked keypoints: normalised and validity-tested once
+            qj, okj = self._normalised(kj.float()), sj > 0
+            k1, k2, d1, d2, q1, q2, ok1, ok2 = kj[:b], kj[b:], dj[:b], dj[b:], qj[:b], qj[b:], okj[:b], okj[b:]
         m = self.matcher
         if packed and m.use_dot_storage and ops.dots_supported(d1.shape[0], d1.shape[1], d2.shape[1], m.epsilon) \
                 and self.estimator.top_k <= 8:
             probs, u, v, state = ops.sinkhorn_bits(d1, d2, self.descriptor.normalize_descriptors, m.epsilon, m.unused_score,
                                                    m.iterations, want_p=want_p, return_state=True)
             sol = SinkhornSolution("dots", state, d2.shape[1], state[3], m.epsilon, u, v)
-            e = self.estimator.estimate_from_solution(sol, q1, q2, s1 > 0, s2 > 0)
+            e = self.estimator.estimate_from_solution(sol, q1, q2, ok1, ok2)
             return k1, k2, probs, e, sol
         probs = m.forward_bits(d1, d2, self.descriptor.normalize_descriptors) if packed else m(d1, d2)
-        return k1, k2, probs, self.estimator.estimate(probs, q1, q2, s1 > 0, s2 > 0), None
+        return k1, k2, probs, self.estimator.estimate(probs, q1, q2, ok1, ok2), None
 
     @torch.no_grad()
     def forward(self, image1: torch.Tensor, image2: torch.Tensor):
