@@ -1600,6 +1600,9 @@ def test_dense_variant_480x640_k512_reference_fixture(mods):
     check_match_sets(match_dict(mk[0][0], mk[1][0], mk[2][0], mk[3][0]),
                      match_dict(g["mk1"][0], g["mk2"][0], g["mscores"][0], g["mvalid"][0]), mcfg["max_matches"])
     # end to end (exact bits): every row's best match is the reference's; the probabilities move with the ~0.04 % bits
+    # that differ between the reference's inexact fp32 integral image and the exact evaluation here -- inherent to the
+    # reference (its own two runs of different conv algorithms differ the same way); the matcher ON THE REFERENCE'S BITS
+    # is held to 1e-4 above, so 0.06 on the row maxima is the bound of the descriptor stage, not of the solver
     mine = p.cpu().numpy()[:, :k, :k]
     assert np.array_equal(mine.argmax(2), g["P_rowarg"])
     assert np.abs(mine.max(2) - g["P_rowmax"]).max() < 0.06
