@@ -247,19 +247,19 @@ __global__ __launch_bounds__(64) void bad_oriented_rest_kernel(OrientedArgs A, i
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The matchers' instance (round 4): nearest sampling, hard bits only, uint8-valued window, 64 * GROUPS pairs.
-// Same arithmetic as bad_oriented_kernel<int, false, OW> -- the position / centre expressions are the same
-// functions -- rebuilt around what bounded that kernel (178 us per 65 k keypoints): its pair loop was a rolled loop
-// with the mode switches inside and TWO dependent global loads (geometry word, threshold) per 64 pairs, each a full
-// round trip that four waves per SIMD cannot hide.  Here
+// The matchers' instance (round 4): nearest sampling, uint8-valued window, 64 * GROUPS pairs; packed hard bits or the
+// float descriptor.  Same values as bad_oriented_kernel<int, ., OW>, rebuilt around what bounded that kernel (178 us per
+// 65 k keypoints; SQ counters: vector pipe ~100 % busy, every instruction four cycles, two dependent global loads --
+// geometry word, threshold -- inside its rolled pair loop):
 //   * every load of the wave -- the 48 (60) window rows, the GROUPS geometry words and thresholds -- is issued before
-//     the first is used; the angle's sine / cosine and the integer thresholds floor(t * area) are computed under them;
-//   * the pair phase is straight-line code for all GROUPS groups: 8 * GROUPS table reads in flight, one
-//     integer compare per pair (d <= floor(t * area) is d <= t * area for an integer d);
+//     the first is used; the angle's sine / cosine are computed under them;
+//   * window rows are BUFFER loads whose row offset is a scalar operand (one s_add per row for a window inside the image);
 //   * the table's rows are OW + 2 = even words long, so the row pass reads and writes 8 bytes per instruction
 //     (conflict-free: 50-word stride = every even bank once per 32 lanes) -- half the LDS instructions of the first pass;
-//   * "is this window uint8-valued" costs cvt, cvt_ubyte0, compare per pixel instead of two converts and three compares.
+//   * "is this window uint8-valued" costs one convert and one v_bitop3 per pixel;
+//   * the pair phase is straight-line code for all GROUPS groups (its own comment below).
 // A keypoint whose window is not uint8-valued is flagged status = 0 and left to bad_oriented_rest_kernel.
+// 132 us per 65 k keypoints at 512 bits (123.7 in the VO step), 1110 vector + 176 scalar instructions per keypoint.
 // clamp(x, 0, hi) for hi >= 0 as ONE v_med3_i32 (the compiler cannot assume hi >= 0 and emits min + compare + select)
 __device__ __forceinline__ int med3_0(int x, int hi) {
   int r;
