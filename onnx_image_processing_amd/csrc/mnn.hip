@@ -250,7 +250,9 @@ struct ZSourceDots {
   }
 };
 
-template <typename SRC, int E8, int RW, int NW>
+// FULL: m == 512 * E8 and n a multiple of the band height (the export configuration): no row or column of the band lies
+// past the matrix, the per-element "inside?" select is dropped
+template <typename SRC, int E8, int RW, int NW, bool FULL = false>
 __global__ __launch_bounds__(64 * NW) void mnn_band_kernel(SRC src, int n, int m, const float *__restrict__ u,
                                                            const float *__restrict__ v,
                                                            const float2 *__restrict__ col_info,
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(64 * NW) void mnn_band_kernel(SRC src, int n, int m
       for (int q = 0; q < 8; ++q) {
         const int j = e * 512 + lane * 8 + q;
         float p = mi_prob_exp((x[q] + ui) + vv[e][q]);                         // sinkhorn.py:145,206
-        p = (live && j < m) ? p : -1.0f;
+        if constexpr (!FULL) p = (live && j < m) ? p : -1.0f;
         if (p > rbest) { rbest = p; rj = j; }
         if (p > cbest[e][q]) { cbest[e][q] = p; cidx[e][q] = i; }
       }
@@ -404,8 +406,15 @@ int mnn_from_source(SRC src, const float2 *col_info, int batch, int n, int m, co
   if (workspace_bytes < duals_bytes(batch, n, m)) return MI_E_CAPACITY;
   const DualsWork w = duals_carve(workspace, batch, n, m);
   const int nb = ceil_div(n, DUALS_BAND);
-  if (m <= 512) {
+  const bool full = n % DUALS_BAND == 0;
+  if (m == 512 && full) {
+    hipLaunchKernelGGL((mnn_band_kernel<SRC, 1, 4, 8, true>), dim3(nb, batch), dim3(512), 0, s, src, n, m, u, v, col_info,
+                       w.row_best, w.col_part);
+  } else if (m <= 512) {
     hipLaunchKernelGGL((mnn_band_kernel<SRC, 1, 4, 8>), dim3(nb, batch), dim3(512), 0, s, src, n, m, u, v, col_info,
+                       w.row_best, w.col_part);
+  } else if (m == 1024 && full) {
+    hipLaunchKernelGGL((mnn_band_kernel<SRC, 2, 4, 8, true>), dim3(nb, batch), dim3(512), 0, s, src, n, m, u, v, col_info,
                        w.row_best, w.col_part);
   } else {
     hipLaunchKernelGGL((mnn_band_kernel<SRC, 2, 4, 8>), dim3(nb, batch), dim3(512), 0, s, src, n, m, u, v, col_info,
