@@ -36,16 +36,20 @@ constexpr int CB_T = 128;  // block tile edge (bits path)
 // DOTS = true : write the exact integer dot products as uint16 (pitch in uint16 elements) plus the
 //               per-descriptor (scale, squared norm) pairs; K6 rebuilds z from them on the fly,
 //               which halves the bytes every Sinkhorn iteration has to stream.
-template <bool DOTS>
-__global__ __launch_bounds__(256) void cost_bits_kernel(const uint32_t *__restrict__ bits1,
+// WORDS > 0: the descriptor length in 32-bit words at compile time (16 / 8: the two learned tables) -- the k loop is then
+// straight-line code: the LDS reads and the bit expansion of later steps run under the MFMAs of earlier ones (rolled, every
+// step waited for its own four LDS reads); WORDS = 0: any length.
+template <bool DOTS, int WORDS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void cost_bits_kernel(const uint32_t *__restrict__ bits1,
                                                         const uint32_t *__restrict__ bits2, int n, int m,
-                                                        int words, int normalized, float eps,
+                                                        int words_rt, int normalized, float eps,
                                                         float *__restrict__ z, int pitch,
                                                         uint16_t *__restrict__ dots,
                                                         float2 *__restrict__ row_info,
                                                         float2 *__restrict__ col_info, uint4 *__restrict__ zero16,
                                                         size_t zero_count) {
   extern __shared__ uint32_t lds_u[];
+  const int words = WORDS > 0 ? WORDS : words_rt;
   // side job for mi_match_pairs: clear the next stage's hand-off area (the single-launch Sinkhorn's granule tags),
   // which saves that stage its own zeroing kernel (common.h: mi_zero_async) on the one-pair-per-call path; zero_count 16-byte words, all
   // workgroups share them
@@ -132,8 +136,7 @@ __global__ __launch_bounds__(256) void cost_bits_kernel(const uint32_t *__restri
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0;
 
-#pragma unroll 4
-  for (int ks = 0; ks < words; ++ks) {
+  auto kstep = [&](int ks) {
     v4i fa[2], fb[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -145,6 +148,13 @@ __global__ __launch_bounds__(256) void cost_bits_kernel(const uint32_t *__restri
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
         acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+  };
+  if constexpr (WORDS > 0) {
+#pragma unroll
+    for (int ks = 0; ks < WORDS; ++ks) kstep(ks);
+  } else {
+#pragma unroll 4
+    for (int ks = 0; ks < words; ++ks) kstep(ks);
   }
 
   if constexpr (DOTS) {
@@ -406,7 +416,8 @@ extern "C" int mi_cost_logscores_bits(const uint32_t *bits1, const uint32_t *bit
   const size_t lds = (size_t)2 * CB_T * (words + 1) * 4 + 4 * CB_T * 4;
   dim3 grid(ceil_div(m, CB_T), ceil_div(n, CB_T), batch);
   uint4 *const no_zero = nullptr;
-  hipLaunchKernelGGL(cost_bits_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, bits1, bits2, n, m,
+  auto kern = words == 16 ? cost_bits_kernel<false, 16> : words == 8 ? cost_bits_kernel<false, 8> : cost_bits_kernel<false, 0>;
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, bits1, bits2, n, m,
                      words, normalized, (float)epsilon, z, pitch, nullptr, nullptr, nullptr, no_zero, (size_t)0);
   return mi_launch_status();
 }
@@ -426,7 +437,8 @@ int mi_cost_dots_bits_zeroing(const uint32_t *bits1, const uint32_t *bits2, int 
   const size_t stage = (size_t)CB_T * (CB_T + 8) * 2;
   if (lds < stage) lds = stage;
   dim3 grid(ceil_div(m, CB_T), ceil_div(n, CB_T), batch);
-  hipLaunchKernelGGL(cost_bits_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, bits1, bits2, n, m, words,
+  auto kern = words == 16 ? cost_bits_kernel<true, 16> : words == 8 ? cost_bits_kernel<true, 8> : cost_bits_kernel<true, 0>;
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, bits1, bits2, n, m, words,
                      normalized, 1.0f, nullptr, pitch, dots, reinterpret_cast<float2 *>(row_info),
                      reinterpret_cast<float2 *>(col_info), reinterpret_cast<uint4 *>(zero_ptr),
                      zero_ptr ? zero_bytes / 16 : (size_t)0);
