@@ -35,7 +35,9 @@ extern "C" {
  * key 12: fused AKAZE scale (mi_akaze_scale / mi_akaze_scale_select), 0 = streaming rolling-window kernel where it
  * applies (default), 1 = LDS-tile kernel / per-step kernels (same maps bit for bit).
  * key 13: mi_sparse_bad_oriented asked for packed bits only (nearest sampling, 256 / 512 pairs), 0 = the unrolled bits
- * kernel (default), 1 = the generic kernel (same bits). */
+ * kernel (default), 1 = the generic kernel (same bits).
+ * key 14: mi_cost_dots_bits / mi_cost_logscores_bits at 256 / 512 bits: 0 = dot products on the FP4 MFMA (default), 1 = on
+ * the int8 MFMA (the same integers). */
 MI_API int mi_debug_set(int key, int value);
 /* top-k kernel phase time stamps (100 MHz clock) of workgroup 0 into `buffer` (8 x uint64, device memory); NULL = off */
 MI_API int mi_debug_topk_stamps(void *buffer);

@@ -11,6 +11,9 @@
 //              chain, no reduced precision: epsilon = 0.05 multiplies any cost error by 20).
 // l1 path    : |a-b| sums on the VALU from the same LDS tiles.
 #include "common.h"
+#include "hooks.h"
+
+#include <type_traits>
 
 namespace {
 
@@ -39,7 +42,24 @@ constexpr int CB_T = 128;  // block tile edge (bits path)
 // WORDS > 0: the descriptor length in 32-bit words at compile time (16 / 8: the two learned tables) -- the k loop is then
 // straight-line code: the LDS reads and the bit expansion of later steps run under the MFMAs of earlier ones (rolled, every
 // step waited for its own four LDS reads); WORDS = 0: any length.
-template <bool DOTS, int WORDS>
+// FP4 = true (gfx950, WORDS even): the dot products through v_mfma_f32_32x32x64_f8f6f4 on FP4 (E2M1) operands -- a bit
+// becomes the nibble 0x2 = 1.0 or 0x0 = 0.0, the products are 0 / 1 and their fp32 sum (<= 4096) is exact, so the result is
+// the same popcount.  Twice the K per instruction at the cycles of the int8 form, and the expansion is two instructions
+// per operand dword instead of three for half as many dwords: which K index a bit lands on is free as long as both
+// operands use the same order, so dword d of a lane's 32 bits simply takes the bits d, d + 4, d + 8, ... where they
+// already sit -- ((w << 1) >> d) & 0x22222222 -- instead of being spread out bit by bit.
+typedef int v8i __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ v8i nibbles_fp4(uint32_t w) {
+  v8i r;
+  r[0] = (int)((w << 1) & 0x22222222u);
+  r[1] = (int)(w & 0x22222222u);
+  r[2] = (int)((w >> 1) & 0x22222222u);
+  r[3] = (int)((w >> 2) & 0x22222222u);
+  r[4] = r[5] = r[6] = r[7] = 0;
+  return r;
+}
+
+template <bool DOTS, int WORDS, bool FP4 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void cost_bits_kernel(const uint32_t *__restrict__ bits1,
                                                         const uint32_t *__restrict__ bits2, int n, int m,
                                                         int words_rt, int normalized, float eps,
@@ -128,7 +148,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;   // wave's 64x64 sub-tile
   const int lr = lane & 31, lh = lane >> 5;
-  v16i acc[2][2];
+  typedef typename std::conditional<FP4, v16f, v16i>::type acc_t;
+  acc_t acc[2][2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -136,7 +157,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0;
 
+  static_assert(!FP4 || (WORDS > 0 && WORDS % 2 == 0), "the FP4 form takes two words per step");
   auto kstep = [&](int ks) {
+    if constexpr (FP4) {
+      v8i fa[2], fb[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        fa[q] = nibbles_fp4(sa[(wm + q * 32 + lr) * wp + 2 * ks + lh]);
+        fb[q] = nibbles_fp4(sb[(wn + q * 32 + lr) * wp + 2 * ks + lh]);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[mi], fb[ni], acc[mi][ni], 4, 4, 0, 0, 0, 0);
+      return;
+    } else {
     v4i fa[2], fb[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -148,8 +184,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
         acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+    }
   };
-  if constexpr (WORDS > 0) {
+  if constexpr (FP4) {
+#pragma unroll
+    for (int ks = 0; ks < WORDS / 2; ++ks) kstep(ks);
+  } else if constexpr (WORDS > 0) {
 #pragma unroll
     for (int ks = 0; ks < WORDS; ++ks) kstep(ks);
   } else {
@@ -172,7 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int e = 0; e < 16; ++e) {
           const int rl = wm + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
           const int cl = wn + ni * 32 + lr;
-          stage[rl * SP16 + cl] = (uint16_t)acc[mi][ni][e];
+          stage[rl * SP16 + cl] = (uint16_t)(int)acc[mi][ni][e];
         }
     __syncthreads();
     uint16_t *db = dots + (size_t)b * (size_t)n * pitch;
@@ -416,7 +456,8 @@ extern "C" int mi_cost_logscores_bits(const uint32_t *bits1, const uint32_t *bit
   const size_t lds = (size_t)2 * CB_T * (words + 1) * 4 + 4 * CB_T * 4;
   dim3 grid(ceil_div(m, CB_T), ceil_div(n, CB_T), batch);
   uint4 *const no_zero = nullptr;
-  auto kern = words == 16 ? cost_bits_kernel<false, 16> : words == 8 ? cost_bits_kernel<false, 8> : cost_bits_kernel<false, 0>;
+  auto kern = words == 16 ? cost_bits_kernel<false, 16, true> : words == 8 ? cost_bits_kernel<false, 8, true> : cost_bits_kernel<false, 0>;
+  if (MI_HOOK(cost_impl, 0) == 1) kern = words == 16 ? cost_bits_kernel<false, 16> : words == 8 ? cost_bits_kernel<false, 8> : cost_bits_kernel<false, 0>;
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, bits1, bits2, n, m,
                      words, normalized, (float)epsilon, z, pitch, nullptr, nullptr, nullptr, no_zero, (size_t)0);
   return mi_launch_status();
@@ -437,7 +478,8 @@ int mi_cost_dots_bits_zeroing(const uint32_t *bits1, const uint32_t *bits2, int 
   const size_t stage = (size_t)CB_T * (CB_T + 8) * 2;
   if (lds < stage) lds = stage;
   dim3 grid(ceil_div(m, CB_T), ceil_div(n, CB_T), batch);
-  auto kern = words == 16 ? cost_bits_kernel<true, 16> : words == 8 ? cost_bits_kernel<true, 8> : cost_bits_kernel<true, 0>;
+  auto kern = words == 16 ? cost_bits_kernel<true, 16, true> : words == 8 ? cost_bits_kernel<true, 8, true> : cost_bits_kernel<true, 0>;
+  if (MI_HOOK(cost_impl, 0) == 1) kern = words == 16 ? cost_bits_kernel<true, 16> : words == 8 ? cost_bits_kernel<true, 8> : cost_bits_kernel<true, 0>;
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, bits1, bits2, n, m, words,
                      normalized, 1.0f, nullptr, pitch, dots, reinterpret_cast<float2 *>(row_info),
                      reinterpret_cast<float2 *>(col_info), reinterpret_cast<uint4 *>(zero_ptr),
