@@ -53,7 +53,8 @@ CFG = dict(block_size=3, num_pairs=NUM_PAIRS, binarize=True, soft_binarize=False
            normalize_descriptors=True, sampling_mode="nearest")
 MNN = dict(max_matches=100, threshold=0.1)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
-I8_MFMA_PEAK_TOPS = 5000.0  # dense int8 MFMA peak (MI355X_MICROARCH.md; the 2:1-sparsity headline is not used)
+FP4_MFMA_PEAK_TOPS = 10000.0  # dense FP6 / FP4 MFMA peak (MI355X_MICROARCH.md; the 2:1-sparsity headline is not used): the
+                              # packed descriptors' dot products run on v_mfma_f32_32x32x64_f8f6f4 (bit -> nibble 1.0 / 0.0, exact)
 
 
 # ----------------------------------------------------------------------------------------------- timing plumbing
@@ -537,7 +538,7 @@ def side_model(name: str):
         # BASELINE configs[2] in its "dense BAD cost matrix" reading: the reference's ShiTomasiBADSinkhornMatcher
         # (feature_detection/shi_tomasi_bad_sinkhorn.py:162-219) -- NMS / top-k WITHOUT border margin, descriptors = the dense
         # response map sampled at the keypoints (evaluated there exactly; the 4.2 GB map is never built), K x K cost on
-        # the int8 MFMA path.  Pinned to the reference at 640x480 by tests/golden/dense_c3_480x640_k512.npz.
+        # the MFMA path.  Pinned to the reference at 640x480 by tests/golden/dense_c3_480x640_k512.npz.
         from onnx_image_processing_amd.pytorch_model.feature_detection import ShiTomasiBADSinkhornMatcher
         dcfg = {kk: v for kk, v in CFG.items() if kk != "sampling_mode"}
         return (ShiTomasiBADSinkhornMatcher(max_keypoints=1024, **dcfg), 1080, 1920, 1024,
@@ -1074,11 +1075,12 @@ def main() -> None:
             if "mi_cost_dots_bits" in stages:
                 t = float(np.mean(stages["mi_cost_dots_bits"]))
                 ops_ = 2.0 * B * K * K * NUM_PAIRS
-                other["mi_cost_dots_bits (int8 MFMA)"] = {
+                other["mi_cost_dots_bits (FP4 MFMA, exact popcounts)"] = {
                     "ops_per_call": ops_, "unit": "Top/s", "achieved": ops_ / (t * 1e-3) / 1e12,
-                    "peak": I8_MFMA_PEAK_TOPS, "frac": ops_ / (t * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
+                    "peak": FP4_MFMA_PEAK_TOPS, "frac": ops_ / (t * 1e-3) / 1e12 / FP4_MFMA_PEAK_TOPS,
                     "bytes_written_per_call": 2.0 * B * K * K,
-                    "note": "co-limited by its uint16 store stream; MFMA busy counters in profiles/ (DESIGN.md K5)"}
+                    "hbm_frac_of_its_store_stream": 2.0 * B * K * K / (t * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "note": "bound by its uint16 store stream (2 B per matrix element), not by the matrix pipe; MFMA busy counters in profiles/ (DESIGN.md K5)"}
             line["roofline_other"] = other
         if world == 1 and not args.single_call and not u8_main:
             records = out[:args.cpu_pairs].cpu().numpy() if 0 < args.cpu_pairs <= B else None

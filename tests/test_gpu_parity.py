@@ -287,6 +287,42 @@ def test_sinkhorn_bits_vs_float_vs_oracle(mods, n, m, d):
             assert ok, (name, normalized, worst)
 
 
+@pytest.mark.parametrize("b,n,m,bits", [(2, 512, 512, 512), (3, 300, 77, 256), (1, 40, 1000, 512), (2, 130, 130, 96)])
+def test_packed_dot_products_are_exact_popcounts(mods, b, n, m, bits):
+    """mi_cost_dots_bits: the uint16 dot products of packed hard-bit descriptors are popcount(a & b) EXACTLY -- on the FP4
+    MFMA (256 / 512 bits: a bit becomes the nibble 1.0 / 0.0, fp32 sums <= 4096 are exact; default), on the int8 MFMA
+    (debug key 14 = 1; also what other lengths run) and against numpy, for all-ones / all-zeros / random descriptors and
+    shapes that are not multiples of the tile; the per-descriptor (scale, squared norm) pairs agree too, and the fp32
+    log-scores of mi_cost_logscores_bits are the same floats from both."""
+    from onnx_image_processing_amd import _native as N, ops
+    rng = np.random.default_rng(bits + n)
+    w = bits // 32
+    b1 = rng.integers(0, 2 ** 32, size=(b, n, w), dtype=np.uint64).astype(np.uint32)
+    b2 = rng.integers(0, 2 ** 32, size=(b, m, w), dtype=np.uint64).astype(np.uint32)
+    b1[0, 0], b1[0, 1], b2[0, 0], b2[0, 1] = 0xFFFFFFFF, 0, 0xFFFFFFFF, 0
+    b1[0, 2], b2[0, 2] = 0xAAAAAAAA, 0x55555555
+    b2[0, 3] = b1[0, 3]
+    t1, t2 = gpu(b1.view(np.int32)), gpu(b2.view(np.int32))
+    want = np.zeros((b, n, m), np.int64)
+    for k in range(w):
+        x = b1[:, :, None, k] & b2[:, None, :, k]
+        want += np.unpackbits(np.ascontiguousarray(x).view(np.uint8).reshape(b, n, m, 4), axis=-1).sum(-1, dtype=np.int64)
+
+    def dots():
+        _, _, _, (d, ri, ci, pitch, _) = ops.sinkhorn_bits(t1, t2, True, 0.05, 1.0, 1, return_state=True)
+        return d[:, :, :m].clone(), ri.clone(), ci.clone()
+    got = dots()
+    assert np.array_equal(got[0].cpu().numpy().astype(np.int64), want)
+    z = ops.cost_logscores_bits(t1, t2, True, 0.05)[0][:, :, :m].clone()
+    with N.debug_library() as lib:
+        assert lib.mi_debug_set(14, 1) == 0
+        alt = dots()
+        z_alt = ops.cost_logscores_bits(t1, t2, True, 0.05)[0][:, :, :m].clone()
+    for x, y in zip(got, alt):
+        assert torch.equal(x, y)
+    assert torch.equal(z, z_alt)
+
+
 @pytest.mark.parametrize("eps,unused", [(0.035, 1.0), (0.05, 0.2), (0.2, 1.0), (1.0, 3.0), (0.03, 1.0)])
 def test_sinkhorn_dots_bounded_shift_vs_row_maximum(mods, eps, unused):
     """The bounded-shift row pass (one analytic shift per pair; taken when 2*sqnorm_bound/eps*log2(e) < 90) and

@@ -2,7 +2,7 @@
 # Round profile on the GPU box (run through gpurun from the repo root):
 #   bench line, rocprofv3 kernel statistics of the same command, the PMC passes the guide prescribes for HBM traffic
 #   (FETCH_SIZE, WRITE_SIZE -- separate runs, --kernel-trace only) and the MFMA passes for the cost kernel
-#   (busy cycles and I8 MOPS, separate runs), then the same statistics for the one-pair-per-call path and for
+#   (busy cycles and F6F4 MOPS -- the packed-descriptor dot products run on the FP4 MFMA --, separate runs), then the same statistics for the one-pair-per-call path and for
 #   BASELINE configs[2] / [3].  The program itself follows `--` (never a shell or env wrapper).
 # Outputs land in gpurun_out/round/; tools/profile_summarise.py turns them into gpurun_out/round/summary/<tag>_*
 # (copy those into profiles/).
@@ -20,7 +20,7 @@ echo bench done
 PIN="--pin-schedule 0 --no-side"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats -- python3 "$B" --steps 20 --warmup 3 --cpu-pairs 0 --no-extras $PIN > "$OUT/stats.log" 2>&1
 echo stats done
-for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_I8; do
+for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F6F4; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d "$OUT/pmc_$c" -o pmc -- python3 "$B" --steps 3 --warmup 1 --cpu-pairs 0 --no-extras $PIN > "$OUT/pmc_$c.log" 2>&1
   echo pmc $c done
 done

@@ -138,10 +138,11 @@ json.dump(out, open(os.path.join(dst, f"{tag}_bench_pmc_traffic.json"), "w"), in
 
 # MFMA counters of the cost kernel (north_star: "MFMA utilisation on the cost matrix"); three separate passes
 try:
-    busy, cu, mops = pmc_rows("SQ_VALU_MFMA_BUSY_CYCLES"), pmc_rows("SQ_BUSY_CU_CYCLES"), pmc_rows("SQ_INSTS_VALU_MFMA_MOPS_I8")
+    busy, cu, mops = pmc_rows("SQ_VALU_MFMA_BUSY_CYCLES"), pmc_rows("SQ_BUSY_CU_CYCLES"), pmc_rows("SQ_INSTS_VALU_MFMA_MOPS_F6F4")
     mf = {"note": "rocprofv3 --pmc, one counter per pass over `bench.py --steps 3 --warmup 1 --no-extras --pin-schedule 0`; per-launch sums over the "
                   "chip.  SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CU_CYCLES * 4 SIMDs) is the fraction of the kernel's busy "
-                  "SIMD-cycles with the MFMA pipe occupied; MOPS_I8 * 512 = integer multiply-add operations issued",
+                  "SIMD-cycles with the MFMA pipe occupied; MOPS_F6F4 * 512 = multiply-add operations issued on the FP4 MFMA (the packed "
+                  "descriptors' dot products: a bit = the nibble 1.0 / 0.0, exact fp32 sums)",
           "pairs_per_gpu": PAIRS, "kernels": {}}
     for k in busy:
         if "cost" not in k:
@@ -149,9 +150,9 @@ try:
         b = sum(busy[k]) / len(busy[k])
         c = sum(cu.get(k, [0])) / max(1, len(cu.get(k, [0])))
         m = sum(mops.get(k, [0])) / max(1, len(mops.get(k, [0])))
-        mf["kernels"][k] = {"SQ_VALU_MFMA_BUSY_CYCLES": b, "SQ_BUSY_CU_CYCLES": c, "SQ_INSTS_VALU_MFMA_MOPS_I8": m,
+        mf["kernels"][k] = {"SQ_VALU_MFMA_BUSY_CYCLES": b, "SQ_BUSY_CU_CYCLES": c, "SQ_INSTS_VALU_MFMA_MOPS_F6F4": m,
                             "mfma_busy_fraction_of_busy_simd_cycles": (b / (4.0 * c)) if c else None,
-                            "int8_ops_issued": m * 512.0, "int8_ops_algorithmic": 2.0 * PAIRS * 512 ** 3}
+                            "fp4_ops_issued": m * 512.0, "ops_algorithmic": 2.0 * PAIRS * 512 ** 3}
     json.dump(mf, open(os.path.join(dst, f"{tag}_bench_pmc_mfma.json"), "w"), indent=1)
 except Exception as e:      # noqa: BLE001
     print("mfma summary skipped:", e)
