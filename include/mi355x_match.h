@@ -268,7 +268,8 @@ MI_API int mi_sparse_bad_oriented_pair(const float *image_a, const float *image_
  * the reference's Python-float arithmetic does.
  * _bits: descriptors are packed hard bits (num_bits % 32 == 0, <= 4096); `normalized` selects
  *     desc = bit/sqrt(popcount) (cost = 2 - 2 dot/sqrt(pa pb)) or desc = bit (cost = Hamming).
- *     Dot products are exact (v_mfma_i32_32x32x32_i8 on 0/1 bytes).
+ *     Dot products are exact: popcount(a & b) on the matrix cores (256 / 512 bits: v_mfma_f32_32x32x64_f8f6f4 on
+ *     FP4 operands, a bit = the nibble 1.0 / 0.0, fp32 sums <= 4096 exact; other lengths: v_mfma_i32_32x32x32_i8 on 0/1 bytes).
  * _f32: arbitrary float descriptors (n,d)/(m,d); L2 via v_mfma_f32_32x32x2_f32, L1 on the VALU. */
 MI_API int mi_cost_logscores_bits(const uint32_t *bits1, const uint32_t *bits2, int batch, int n, int m,
                            int num_bits, int normalized, double epsilon, float *z, int pitch,

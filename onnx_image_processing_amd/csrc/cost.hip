@@ -2,9 +2,10 @@
 // Semantics: reference pytorch_model/matching/sinkhorn.py:95-108 (cost) and :178
 // (Z = -cost/epsilon; the constant dustbin padding of :187 is applied inside K6).
 //
-// bits path  : hard-binarised descriptors stay packed (64 B per 512-bit descriptor); each
-//              32-bit word is expanded to 0/1 bytes in registers and fed to
-//              v_mfma_i32_32x32x32_i8, so dot(a,b) = popcount(a & b) is exact.  The epilogue
+// bits path  : hard-binarised descriptors stay packed (64 B per 512-bit descriptor); their bits are
+//              expanded in registers -- to FP4 nibbles for v_mfma_f32_32x32x64_f8f6f4 (256 / 512 bits),
+//              to 0/1 bytes for v_mfma_i32_32x32x32_i8 (other lengths) -- so dot(a,b) = popcount(a & b)
+//              is exact.  The epilogue
 //              applies cost = |a|^2 + |b|^2 - 2 a.b with a = bit/sqrt(pop) (normalised) or
 //              a = bit (Hamming) in fp32 and writes the n x m core of Z.
 // f32 path   : arbitrary float descriptors through v_mfma_f32_32x32x2_f32 (exact fp32 fma
