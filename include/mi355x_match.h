@@ -81,9 +81,15 @@ enum { MI_DIST_L2 = 0, MI_DIST_L1 = 1 };
 enum {
   MI_SOLVER_DEFAULT = 0,
   MI_SOLVER_MULTI_LAUNCH = 1, /* never the single-launch Sinkhorn form */
-  MI_SOLVER_NO_FORK = 2       /* never fork onto helper streams: every kernel of the call on `stream` (e.g. for a
+  MI_SOLVER_NO_FORK = 2,      /* never fork onto helper streams: every kernel of the call on `stream` (e.g. for a
                                  capture that must not contain cross-stream branches, or a device with one hardware
                                  queue); bit-identical results, the >= 64-pair Sinkhorn runs ~8 % slower */
+  MI_SOLVER_DOTS_BELOW_1024 = 4 /* mi_sinkhorn_dots only: the caller vouches that every dot product is < 1024 (descriptors
+                                 of at most 1023 bits -- mi_match_pairs sets it by itself from num_bits).  The row
+                                 kernel of the batched form then reads a uint16 as the fp16 denormal dot * 2^-24 and
+                                 multiplies in one mixed-precision instruction instead of converting first; the same
+                                 duals bit for bit.  A value >= 1024 under this flag reads as some other fp16: wrong
+                                 duals, no fault. */
 };
 /* stream schedules of mi_sinkhorn_dots for >= 64 pairs (see the conventions above) */
 enum {

@@ -37,7 +37,9 @@ extern "C" {
  * key 13: mi_sparse_bad_oriented asked for packed bits only (nearest sampling, 256 / 512 pairs), 0 = the unrolled bits
  * kernel (default), 1 = the generic kernel (same bits).
  * key 14: mi_cost_dots_bits / mi_cost_logscores_bits at 256 / 512 bits: 0 = dot products on the FP4 MFMA (default), 1 = on
- * the int8 MFMA (the same integers). */
+ * the int8 MFMA (the same integers).
+ * key 15: mi_sinkhorn_dots under MI_SOLVER_DOTS_BELOW_1024: 1 = the row kernel reads the uint16 dots as fp16 denormals
+ * (v_fma_mix_f32; default), 0 = converts them first (the same duals bit for bit). */
 MI_API int mi_debug_set(int key, int value);
 /* top-k kernel phase time stamps (100 MHz clock) of workgroup 0 into `buffer` (8 x uint64, device memory); NULL = off */
 MI_API int mi_debug_topk_stamps(void *buffer);

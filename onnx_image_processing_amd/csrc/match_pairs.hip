@@ -176,7 +176,8 @@ int match_pairs_impl(const PIX *image1, const PIX *image2, int batch, int h, int
   const double sqnorm_bound = params->normalize_descriptors ? 1.0 : (double)pbits;
   if ((e = mi_sinkhorn_dots_impl(L.dots, L.row_info, L.col_info, batch, k, k, L.pitch, params->epsilon,
                                  params->unused_score, sqnorm_bound, params->sinkhorn_iterations, L.u, L.v, nullptr, L.sk_ws,
-                                 L.sk_bytes, params->flags, handoff_bytes > 0, stream)) != MI_OK)
+                                 L.sk_bytes, params->flags | (pbits < 1024 ? MI_SOLVER_DOTS_BELOW_1024 : 0), handoff_bytes > 0,
+                                 stream)) != MI_OK)
     return e;
   // matching/match_extraction.py:46-184 straight from the duals
   return mi_mnn_from_duals_dots(L.dots, L.row_info, L.col_info, batch, k, k, L.pitch, params->epsilon, L.u, L.v,

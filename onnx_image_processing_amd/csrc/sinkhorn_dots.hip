@@ -128,7 +128,23 @@ __device__ __forceinline__ float combine_column(const float *__restrict__ part_b
 // re-enters in u_i and in the dustbin-column entry.  Per-column data come from aligned, padded
 // arrays (16-byte loads): tp = t_j (0 in the padding), wp = nie*nb_j + v_j (-inf in the padding:
 // such a column contributes nowhere), the latter rebuilt by the combine kernel every iteration.
-template <int E8, int RW, int NW, bool FAST>
+// fp32(half(bits of w's low / high 16 bits) * t): one v_fma_mix_f32 (addend +0: the product is never negative here)
+__device__ __forceinline__ float mix_mul_lo(uint32_t w, float t) {
+  float p;
+  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(p) : "v"(w), "v"(t));
+  return p;
+}
+__device__ __forceinline__ float mix_mul_hi(uint32_t w, float t) {
+  float p;
+  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(p) : "v"(w), "v"(t));
+  return p;
+}
+
+// MIX (round 4; the caller vouches for dots < 1024, MI_SOLVER_DOTS_BELOW_1024): a uint16 below 1024 read as an fp16 is the
+// denormal dot * 2^-24, which v_fma_mix_f32 widens on the fly -- dot * t becomes ONE instruction (fma(half, t, +0): the
+// same single rounding as the multiply, scaled by 2^-24) instead of a convert and a multiply, and the row factor carries
+// the 2^24 back (an exact scaling, and the fma forms the exact product before it rounds): the same x bit for bit.
+template <int E8, int RW, int NW, bool FAST, bool MIX = false>
 __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *__restrict__ dots, int n, int m,
                                                                int pitch, const float2 *__restrict__ row_info,
                                                                ZParams zp, const float *__restrict__ v,
@@ -254,6 +270,7 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
     const float2 riv = row_info[(size_t)b * n + min(row0 + myrow, n - 1)];
     const float g0 = -2.0f * zp.neg_inv_eps * riv.x;
     giv = FAST ? g0 * SKD_L2E : g0;
+    if constexpr (MIX) giv *= 16777216.0f;       // 2^24, exact (|g| < 2^11): undoes the 2^-24 of the half-read dots
     civ = riv.y * zp.neg_inv_eps;
     xdv = xd0 - civ;
   }
@@ -269,6 +286,7 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
       const float2 ri = row_info[(size_t)b * n + min(i, n - 1)];                     // wave-uniform
       const float g0 = -2.0f * zp.neg_inv_eps * ri.x;
       gi = FAST ? g0 * SKD_L2E : g0;
+      if constexpr (MIX) gi *= 16777216.0f;
       ci[r] = ri.y * zp.neg_inv_eps;
       xd[r] = xd0 - ci[r];
     }
@@ -281,17 +299,26 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
           // two columns per instruction: v_pk_mul_f32 / v_pk_fma_f32 (the same IEEE operations; a packed fma costs 1.9 ns
           // against 2 x 1.5)
           typedef float v2f __attribute__((ext_vector_type(2)));
-          const v2f dot = {(float)(w4[q >> 1] & 0xFFFFu), (float)(w4[q >> 1] >> 16)};
           const v2f tt = {tq[e][q], tq[e][q + 1]}, ww = {wq[e][q], wq[e][q + 1]}, gg = {gi, gi};
-          const v2f xx = __builtin_elementwise_fma(dot * tt, gg, ww);
+          v2f dt;
+          if constexpr (MIX) {
+            dt.x = mix_mul_lo(w4[q >> 1], tt.x);
+            dt.y = mix_mul_hi(w4[q >> 1], tt.y);
+          } else {
+            const v2f dot = {(float)(w4[q >> 1] & 0xFFFFu), (float)(w4[q >> 1] >> 16)};
+            dt = dot * tt;
+          }
+          const v2f xx = __builtin_elementwise_fma(dt, gg, ww);
           x[r][e][q] = xx.x;
           x[r][e][q + 1] = xx.y;
         }
       } else {                 // the two-chunk instance: the pairs' register tuples cost it a wave of occupancy (65 VGPRs)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          const float dot = (float)((q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu));
-          x[r][e][q] = __builtin_fmaf(dot * tq[e][q], gi, wq[e][q]);
+          float dt;
+          if constexpr (MIX) dt = (q & 1) ? mix_mul_hi(w4[q >> 1], tq[e][q]) : mix_mul_lo(w4[q >> 1], tq[e][q]);
+          else dt = (float)((q & 1) ? (w4[q >> 1] >> 16) : (w4[q >> 1] & 0xFFFFu)) * tq[e][q];
+          x[r][e][q] = __builtin_fmaf(dt, gi, wq[e][q]);
         }
       }
       if constexpr (!FAST)
@@ -943,7 +970,7 @@ ForkJoin *fork_join_for(hipStream_t s) {
   });
 }
 
-template <int E8, int RW, int NW, bool FAST>
+template <int E8, int RW, int NW, bool FAST, bool MIX = false>
 int launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int batch, int n, int m, int pitch,
                  ZParams zp, int iterations, float *u, float *v, float *part, float *wp, float *tp, float *aux,
                  float log_m, float log_n, unsigned *statusw, bool no_fork, hipStream_t s) {
@@ -993,7 +1020,7 @@ int launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int ba
       float *u0 = u + (size_t)b0 * (n + 1), *v0 = v + (size_t)b0 * (m + 1);
       float *part0 = part + (size_t)b0 * (nb + 1) * (size_t)(m + 1);
       float *wp0 = wp + (size_t)b0 * CP, *tp0 = tp + (size_t)b0 * CP, *aux0 = aux + (size_t)b0 * SKD_AUX;
-      hipLaunchKernelGGL((sk_band_dots_kernel<E8, RW, NW, FAST>), dim3(nb + 1, nbatch), dim3(64 * NW), 0, st, d0, n, m, pitch,
+      hipLaunchKernelGGL((sk_band_dots_kernel<E8, RW, NW, FAST, MIX>), dim3(nb + 1, nbatch), dim3(64 * NW), 0, st, d0, n, m, pitch,
                          ri0, zp, v0, u0, part0, log_m, vz, wp0, tp0, CP, aux0);
       hipLaunchKernelGGL(sk_vcombine_dots_kernel, dim3(ceil_div(m + 1, 256), nbatch), dim3(256), 0, st, part0, m, nb + 1,
                          v0, log_n, vz, ci0, zp.neg_inv_eps, wp0, CP, aux0);
@@ -1195,7 +1222,7 @@ int mi_sinkhorn_dots_impl(const uint16_t *dots, const float *row_info, const flo
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
   if (pitch < m || pitch % 8 != 0 || ((uintptr_t)dots % 16) != 0 || ((uintptr_t)workspace % 16) != 0) return MI_E_ALIGN;
   if (iterations <= 0 || !(epsilon >= MI_DOTS_MIN_EPSILON)) return MI_E_PARAM;   // below it: the fp32-Z form (clamped cost)
-  if ((flags & ~(MI_SOLVER_MULTI_LAUNCH | MI_SOLVER_NO_FORK)) != 0) return MI_E_PARAM;
+  if ((flags & ~(MI_SOLVER_MULTI_LAUNCH | MI_SOLVER_NO_FORK | MI_SOLVER_DOTS_BELOW_1024)) != 0) return MI_E_PARAM;
   const size_t need = mi_sinkhorn_dots_workspace_bytes(batch, n, m);
   if (need == 0) return MI_E_PARAM;                 // m > 1024: use the fp32 form
   if (workspace_bytes < need) return MI_E_CAPACITY;
@@ -1241,10 +1268,17 @@ int mi_sinkhorn_dots_impl(const uint16_t *dots, const float *row_info, const flo
                          zp, u, v, p);
     return mi_launch_status();
   }
-#define SKD_LAUNCH(E8, RW, FAST) launch_dots<E8, RW, 8, FAST>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, wp, tp, aux, log_m, log_n, statusw, (flags & MI_SOLVER_NO_FORK) != 0, s)
+  // dots vouched to be < 1024 (MI_SOLVER_DOTS_BELOW_1024): the row kernel reads them as fp16 denormals (MIX above)
+  const bool mix = (flags & MI_SOLVER_DOTS_BELOW_1024) != 0 && MI_HOOK(sinkhorn_mix, 1) != 0;
+#define SKD_LAUNCH(E8, RW, FAST, MIX) launch_dots<E8, RW, 8, FAST, MIX>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, wp, tp, aux, log_m, log_n, statusw, (flags & MI_SOLVER_NO_FORK) != 0, s)
   int e;
-  if (m <= 512) e = fast ? SKD_LAUNCH(1, 4, true) : SKD_LAUNCH(1, 4, false);
-  else e = fast ? SKD_LAUNCH(2, 2, true) : SKD_LAUNCH(2, 2, false);
+  if (m <= 512) {
+    if (mix) e = fast ? SKD_LAUNCH(1, 4, true, true) : SKD_LAUNCH(1, 4, false, true);
+    else e = fast ? SKD_LAUNCH(1, 4, true, false) : SKD_LAUNCH(1, 4, false, false);
+  } else {
+    if (mix) e = fast ? SKD_LAUNCH(2, 2, true, true) : SKD_LAUNCH(2, 2, false, true);
+    else e = fast ? SKD_LAUNCH(2, 2, true, false) : SKD_LAUNCH(2, 2, false, false);
+  }
 #undef SKD_LAUNCH
   if (e != MI_OK) return e;
   if (p) {

@@ -71,6 +71,9 @@ TILE_COUNTER_BYTES = 16640          # include/mi355x_match.h MI_TILE_COUNTER_BYT
 # MI_SOLVER_NO_FORK keeps the >= 64-pair Sinkhorn on the caller's stream (no helper streams, no events, no tuning).
 # A preference of this Python layer (the C library has no process-wide switch); results are identical either way.
 MI_SOLVER_DEFAULT, MI_SOLVER_MULTI_LAUNCH, MI_SOLVER_NO_FORK = 0, 1, 2
+# (not a preference: sinkhorn_bits sets it by itself when the descriptors have fewer than 1024 bits, which is what lets
+# mi_sinkhorn_dots' row kernel read the uint16 dot products as fp16 denormals)
+MI_SOLVER_DOTS_BELOW_1024 = 4
 _solver_flags = MI_SOLVER_DEFAULT
 
 
@@ -402,8 +405,8 @@ def sinkhorn_bits(bits1: torch.Tensor, bits2: torch.Tensor, normalized: bool, ep
     work = torch.empty(((wbytes + 7) // 8,), dtype=torch.int64, device=dev)
     N.call("mi_sinkhorn_dots", dots.data_ptr(), row_info.data_ptr(), col_info.data_ptr(), b, n, m, pitch,
            float(epsilon), float(unused_score), 1.0 if normalized else float(words * 32), int(iterations),
-           u.data_ptr(), v.data_ptr(), p.data_ptr() if p is not None else None, work.data_ptr(), wbytes, _solver_flags,
-           N.stream_ptr())
+           u.data_ptr(), v.data_ptr(), p.data_ptr() if p is not None else None, work.data_ptr(), wbytes,
+           _solver_flags | (MI_SOLVER_DOTS_BELOW_1024 if words * 32 < 1024 else 0), N.stream_ptr())
     if return_state:
         status = N.load().mi_sinkhorn_dots_status_word(work.data_ptr(), b, n, m)
         return p, u, v, (dots, row_info, col_info, pitch, (work, status))

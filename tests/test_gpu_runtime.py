@@ -75,6 +75,37 @@ def test_sinkhorn_stream_schedules_agree(mods):
         ops.set_solver_flags(4)
 
 
+@pytest.mark.parametrize("batch,n,m,bits,eps", [(64, 512, 512, 256, 0.05), (40, 300, 277, 512, 0.05), (33, 700, 1024, 256, 0.1),
+                                               (3, 130, 900, 992, 0.05), (64, 512, 512, 256, 0.03), (9, 512, 512, 512, 0.2)])
+def test_sinkhorn_row_kernel_reading_the_dots_as_fp16_denormals(mods, batch, n, m, bits, eps):
+    """With fewer than 1024 descriptor bits every dot product is < 1024, and the uint16 read as an fp16 is the denormal
+    dot * 2^-24: mi_sinkhorn_dots' row kernel (MI_SOLVER_DOTS_BELOW_1024, which ops.sinkhorn_bits and mi_match_pairs set
+    by themselves) multiplies it in one v_fma_mix_f32 instead of converting first and carries the 2^24 in the row factor.
+    Exact scalings around the same roundings: duals and P are identical with it (default) and without (debug key 15 =
+    0) -- one and two 512-column chunks, ragged extents, the largest value the flag admits (992 set bits against
+    themselves), zero dots, both row kernels (eps = 0.03 takes the row-maximum one)."""
+    from onnx_image_processing_amd import _native as N, ops
+    rng = np.random.default_rng(n + m)
+    w = bits // 32
+    b1 = rng.integers(0, 2 ** 32, size=(batch, n, w), dtype=np.uint64).astype(np.uint32)
+    b2 = rng.integers(0, 2 ** 32, size=(batch, m, w), dtype=np.uint64).astype(np.uint32)
+    k = min(n, m) // 3
+    b2[:, :k] = b1[:, :k]
+    b1[:, 0], b2[:, 0] = 0xFFFFFFFF, 0xFFFFFFFF          # dot product = bits
+    b1[:, 1] = 0
+    b2[:, 2] = ~b1[:, 2]                                  # dot product 0 against a non-empty descriptor
+    t1, t2 = gpu(b1.view(np.int32)), gpu(b2.view(np.int32))
+    run = lambda: [t.clone() for t in ops.sinkhorn_bits(t1, t2, True, eps, 1.0, 10, return_duals=True)]
+    got = run()
+    assert all(bool(torch.isfinite(t).all()) for t in got[1:])
+    with N.debug_library() as lib:
+        assert lib.mi_debug_set(15, 0) == 0
+        want = run()
+        assert lib.mi_debug_set(15, 2) != 0
+    for x, y in zip(got, want):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("n,m", [(300, 280), (520, 700)])
 def test_fp32_sinkhorn_stream_schedules_agree(mods, n, m):
     """mi_sinkhorn (fp32 log-scores: float descriptors, the reference's default configuration) for >= 64 pairs runs as

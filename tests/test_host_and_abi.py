@@ -87,7 +87,7 @@ def test_sinkhorn_form_decision_is_a_host_check(lib_path):
         assert dbg.mi_debug_sinkhorn_dots_form(1, 512, 512, 0, 4, 256) == 1
     lib = _native.load()
     ptr = ctypes.cast(ctypes.create_string_buffer(64), ctypes.c_void_p)
-    assert lib.mi_sinkhorn_dots(ptr, ptr, ptr, 1, 8, 8, 8, 0.05, 1.0, 1.0, 5, ptr, ptr, None, ptr, 1 << 20, 4, None) == -3   # unknown flag
+    assert lib.mi_sinkhorn_dots(ptr, ptr, ptr, 1, 8, 8, 8, 0.05, 1.0, 1.0, 5, ptr, ptr, None, ptr, 1 << 20, 8, None) == -3   # unknown flag
     base = ctypes.create_string_buffer(1 << 16)
     addr = ctypes.addressof(base)
     assert lib.mi_sinkhorn_dots_status_word(None, 1, 8, 8) is None
