@@ -144,7 +144,13 @@ __device__ __forceinline__ float mix_mul_hi(uint32_t w, float t) {
 // denormal dot * 2^-24, which v_fma_mix_f32 widens on the fly -- dot * t becomes ONE instruction (fma(half, t, +0): the
 // same single rounding as the multiply, scaled by 2^-24) instead of a convert and a multiply, and the row factor carries
 // the 2^24 back (an exact scaling, and the fma forms the exact product before it rounds): the same x bit for bit.
-template <int E8, int RW, int NW, bool FAST, bool MIX = false>
+// SPLIT (round 4; 512 < m <= 1024; launched with NW = 16: 32-row bands, half the partial sums): instead of one wave holding
+// two 512-column chunks of two rows (E8 = 2, RW = 2), the waves of a workgroup pair up -- wave 2g holds columns 0..511 and wave 2g + 1 columns 512..1023 of the SAME four rows --
+// and run the one-chunk code (four rows reduced together, the per-row scalars lane-parallel, the packed multiply-adds);
+// the two half sums of a row meet through LDS (total = left + right in both waves).  The sums associate differently from
+// the two-chunk kernel's (rounding only: no other kernel restates m > 512; the column kernel takes the band count as an
+// argument).  C3 (128 pairs, K = 1024): the call 1.237 -> 1.127 ms, the column kernel 13.9 -> 8.1 us.
+template <int E8, int RW, int NW, bool FAST, bool MIX = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *__restrict__ dots, int n, int m,
                                                                int pitch, const float2 *__restrict__ row_info,
                                                                ZParams zp, const float *__restrict__ v,
@@ -153,10 +159,14 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
                                                                const float *__restrict__ wp,
                                                                const float *__restrict__ tp, int cpitch,
                                                                const float *__restrict__ aux) {
-  constexpr int BAND = NW * RW;   // NW waves x RW rows each
+  static_assert(!SPLIT || (E8 == 1 && RW == 4 && NW % 2 == 0 && FAST), "the split form is the one-chunk bounded-shift kernel");
+  constexpr int RG = SPLIT ? NW / 2 : NW;   // row groups of the workgroup
+  constexpr int BAND = RG * RW;   // RG groups x RW rows each
   constexpr int NT = 64 * NW;
   constexpr int NC = 512 * E8;    // columns covered by one wave
-  __shared__ float red[NW][NC + 1];
+  constexpr int NCW = SPLIT ? 2 * NC : NC;   // columns covered by the workgroup
+  __shared__ float red[RG][NCW + 1];
+  __shared__ float halfsum[SPLIT ? NW : 1][4];   // SPLIT: a wave's four half-row sums, for its partner; and the dustbin band's scratch
   // the wave index is uniform: readfirstlane lets the compiler keep row numbers, row_info and the live flags in
   // SGPRs (scalar loads) instead of per-lane copies
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -165,26 +175,28 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
   float *pb = part + ((size_t)b * (nb + 1) + band) * (size_t)(m + 1);
   const float vd = v_is_zero ? 0.0f : vb[m];
   const float dust = zp.dust;
-  const int row0 = band * BAND + wave * RW;
+  const int rg = SPLIT ? wave >> 1 : wave, half = SPLIT ? wave & 1 : 0, cbase = half * NC;
+  const int row0 = band * BAND + rg * RW;
 
   if (band == nb) {
+    auto scr = [&](int w, int i) -> float & { if constexpr (SPLIT) return halfsum[w][i]; else return red[w][i]; };
     // dustbin row: u_n = log m - LSE_j(dust + v_j); its log-probabilities B_j = dust + u_n + v_j
     float mx = dust + vd;
     for (int j = threadIdx.x; j < m; j += NT) mx = fmaxf(mx, dust + (v_is_zero ? 0.0f : vb[j]));
     mx = wave_max_dpp(mx);
-    if (lane == 0) red[wave][0] = mx;
+    if (lane == 0) scr(wave, 0) = mx;
     __syncthreads();
-    mx = red[0][0];
+    mx = scr(0, 0);
 #pragma unroll
-    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w][0]);
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, scr(w, 0));
     float s = 0.0f;
     for (int j = threadIdx.x; j < m; j += NT) s += expf((dust + (v_is_zero ? 0.0f : vb[j])) - mx);
     s = wave_sum_dpp(s);
-    if (lane == 0) red[wave][1] = s;
+    if (lane == 0) scr(wave, 1) = s;
     __syncthreads();
-    s = red[0][1];
+    s = scr(0, 1);
 #pragma unroll
-    for (int w = 1; w < NW; ++w) s += red[w][1];
+    for (int w = 1; w < NW; ++w) s += scr(w, 1);
     s += expf((dust + vd) - mx);
     const float un = log_m - (logf(s) + mx);
     if (threadIdx.x == 0) u[(size_t)b * (n + 1) + n] = un;
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
   float4 tl[E8][2], wl[E8][2];
 #pragma unroll
   for (int e = 0; e < E8; ++e) {
-    const int j = e * 512 + lane * 8;
+    const int j = cbase + e * 512 + lane * 8;
     tl[e][0] = *reinterpret_cast<const float4 *>(tp + (size_t)b * cpitch + j);
     tl[e][1] = *reinterpret_cast<const float4 *>(tp + (size_t)b * cpitch + j + 4);
     wl[e][0] = *reinterpret_cast<const float4 *>(wp + (size_t)b * cpitch + j);
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
     for (int e = 0; e < E8; ++e) {
       // no branch around the load (a branch ends the run of loads in flight: the rows were fetched two at a
       // time, one memory round trip per pair); lanes past the matrix read a valid chunk of the row
-      const int j = e * 512 + lane * 8;
+      const int j = cbase + e * 512 + lane * 8;
       raw[r][e] = *reinterpret_cast<const uint4 *>(src + min(j, pitch - 8));   // pitch >= round_up(m,8)
     }
   }
@@ -372,9 +384,16 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
     float nmv = nm[0];
     if constexpr (!FAST) nmv = myrow == 1 ? nm[1] : myrow == 2 ? nm[2] : myrow == 3 ? nm[3] : nm[0];
     edv = __builtin_amdgcn_exp2f(__builtin_fmaf(xdv, SKD_L2E, nmv));
-    const float stv = wave_sum4_rows(s) + edv;
+    float rowsum = wave_sum4_rows(s);
+    if constexpr (SPLIT) {                         // left half + right half, the same expression in both waves
+      if ((lane & 15) == 0) halfsum[wave][lane >> 4] = rowsum;
+      __syncthreads();
+      const float other = halfsum[wave ^ 1][lane >> 4];
+      rowsum = half == 0 ? rowsum + other : other + rowsum;
+    }
+    const float stv = rowsum + edv;
     const bool livev = row0 + myrow < n;
-    if ((lane & 15) == 0 && livev)                                                  // sinkhorn.py:139
+    if ((lane & 15) == 0 && livev && half == 0)                                     // sinkhorn.py:139
       u[(size_t)b * (n + 1) + row0 + myrow] = (nmv - __builtin_amdgcn_logf(stv)) * SKD_LN2 - civ;
     wgtv = livev ? __builtin_amdgcn_rcpf(stv) : 0.0f;
   } else {
@@ -402,15 +421,15 @@ __global__ __launch_bounds__(64 * NW) void sk_band_dots_kernel(const uint16_t *_
 #pragma unroll
   for (int e = 0; e < E8; ++e)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) red[wave][e * 512 + lane * 8 + q] = colsum[e][q];
-  if (lane == 0) red[wave][NC] = dustcol;
+    for (int q = 0; q < 8; ++q) red[rg][cbase + e * 512 + lane * 8 + q] = colsum[e][q];
+  if (lane == 0 && half == 0) red[rg][NCW] = dustcol;
   __syncthreads();
-  for (int c = threadIdx.x; c <= NC; c += NT) {
-    const int j = (c == NC) ? m : c;
-    if (c < NC && j >= m) continue;
+  for (int c = threadIdx.x; c <= NCW; c += NT) {
+    const int j = (c == NCW) ? m : c;
+    if (c < NCW && j >= m) continue;
     float t = red[0][c];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) t += red[w][c];
+    for (int w = 1; w < RG; ++w) t += red[w][c];
     pb[j] = t;
   }
 }
@@ -970,12 +989,12 @@ ForkJoin *fork_join_for(hipStream_t s) {
   });
 }
 
-template <int E8, int RW, int NW, bool FAST, bool MIX = false>
+template <int E8, int RW, int NW, bool FAST, bool MIX = false, bool SPLIT = false>
 int launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int batch, int n, int m, int pitch,
                  ZParams zp, int iterations, float *u, float *v, float *part, float *wp, float *tp, float *aux,
                  float log_m, float log_n, unsigned *statusw, bool no_fork, hipStream_t s) {
-  const int nb = ceil_div(n, NW * RW);
-  constexpr int CP = 512 * E8;    // padded column count of wp / tp
+  const int nb = ceil_div(n, (SPLIT ? NW / 2 : NW) * RW);
+  constexpr int CP = 512 * E8 * (SPLIT ? 2 : 1);    // padded column count of wp / tp
   hipLaunchKernelGGL(sk_dots_init_kernel, dim3(CP / 256, batch), dim3(256), 0, s, ci, m, CP, zp.neg_inv_eps, wp, tp,
                      aux, statusw);
   // An iteration is a big row kernel and a tiny column kernel that depend on each other, so between them
@@ -1020,7 +1039,7 @@ int launch_dots(const uint16_t *dots, const float2 *ri, const float2 *ci, int ba
       float *u0 = u + (size_t)b0 * (n + 1), *v0 = v + (size_t)b0 * (m + 1);
       float *part0 = part + (size_t)b0 * (nb + 1) * (size_t)(m + 1);
       float *wp0 = wp + (size_t)b0 * CP, *tp0 = tp + (size_t)b0 * CP, *aux0 = aux + (size_t)b0 * SKD_AUX;
-      hipLaunchKernelGGL((sk_band_dots_kernel<E8, RW, NW, FAST, MIX>), dim3(nb + 1, nbatch), dim3(64 * NW), 0, st, d0, n, m, pitch,
+      hipLaunchKernelGGL((sk_band_dots_kernel<E8, RW, NW, FAST, MIX, SPLIT>), dim3(nb + 1, nbatch), dim3(64 * NW), 0, st, d0, n, m, pitch,
                          ri0, zp, v0, u0, part0, log_m, vz, wp0, tp0, CP, aux0);
       hipLaunchKernelGGL(sk_vcombine_dots_kernel, dim3(ceil_div(m + 1, 256), nbatch), dim3(256), 0, st, part0, m, nb + 1,
                          v0, log_n, vz, ci0, zp.neg_inv_eps, wp0, CP, aux0);
@@ -1270,16 +1289,20 @@ int mi_sinkhorn_dots_impl(const uint16_t *dots, const float *row_info, const flo
   }
   // dots vouched to be < 1024 (MI_SOLVER_DOTS_BELOW_1024): the row kernel reads them as fp16 denormals (MIX above)
   const bool mix = (flags & MI_SOLVER_DOTS_BELOW_1024) != 0 && MI_HOOK(sinkhorn_mix, 1) != 0;
-#define SKD_LAUNCH(E8, RW, FAST, MIX) launch_dots<E8, RW, 8, FAST, MIX>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, wp, tp, aux, log_m, log_n, statusw, (flags & MI_SOLVER_NO_FORK) != 0, s)
+#define SKD_LAUNCH_NW(E8, RW, NW, FAST, MIX, SPLIT) launch_dots<E8, RW, NW, FAST, MIX, SPLIT>(dots, ri, ci, batch, n, m, pitch, zp, iterations, u, v, part, wp, tp, aux, log_m, log_n, statusw, (flags & MI_SOLVER_NO_FORK) != 0, s)
+#define SKD_LAUNCH(E8, RW, FAST, MIX, SPLIT) SKD_LAUNCH_NW(E8, RW, 8, FAST, MIX, SPLIT)
   int e;
   if (m <= 512) {
-    if (mix) e = fast ? SKD_LAUNCH(1, 4, true, true) : SKD_LAUNCH(1, 4, false, true);
-    else e = fast ? SKD_LAUNCH(1, 4, true, false) : SKD_LAUNCH(1, 4, false, false);
+    if (mix) e = fast ? SKD_LAUNCH(1, 4, true, true, false) : SKD_LAUNCH(1, 4, false, true, false);
+    else e = fast ? SKD_LAUNCH(1, 4, true, false, false) : SKD_LAUNCH(1, 4, false, false, false);
+  } else if (fast && MI_HOOK(sinkhorn_pair_waves, 1) != 0) {   // two waves per row group, one 512-column chunk each (SPLIT above)
+    e = mix ? SKD_LAUNCH_NW(1, 4, 16, true, true, true) : SKD_LAUNCH_NW(1, 4, 16, true, false, true);
   } else {
-    if (mix) e = fast ? SKD_LAUNCH(2, 2, true, true) : SKD_LAUNCH(2, 2, false, true);
-    else e = fast ? SKD_LAUNCH(2, 2, true, false) : SKD_LAUNCH(2, 2, false, false);
+    if (mix) e = fast ? SKD_LAUNCH(2, 2, true, true, false) : SKD_LAUNCH(2, 2, false, true, false);
+    else e = fast ? SKD_LAUNCH(2, 2, true, false, false) : SKD_LAUNCH(2, 2, false, false, false);
   }
 #undef SKD_LAUNCH
+#undef SKD_LAUNCH_NW
   if (e != MI_OK) return e;
   if (p) {
     hipLaunchKernelGGL(sk_exp_dots_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, dots, n, m, pitch, ri, ci,

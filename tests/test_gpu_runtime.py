@@ -106,6 +106,40 @@ def test_sinkhorn_row_kernel_reading_the_dots_as_fp16_denormals(mods, batch, n, 
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("batch,n,m,bits", [(33, 700, 1024, 256), (3, 130, 900, 512), (64, 1024, 1024, 512), (2, 1000, 513, 256)])
+def test_sinkhorn_wide_rows_split_over_wave_pairs(mods, batch, n, m, bits):
+    """512 < m <= 1024: the bounded-shift row kernel gives the two 512-column chunks of a row to two waves (the one-chunk
+    code per wave, the half sums of a row meeting in LDS) instead of holding both chunks in one wave.  The sums associate
+    differently, nothing else: duals and P agree with the two-chunk kernel (debug key 16 = 0) to rounding, and with the
+    fp64 oracle to the usual bound; ragged extents, rows past n in the last band, m = 513 (the right half nearly empty)."""
+    from onnx_image_processing_amd import _native as N, ops
+    rng = np.random.default_rng(n + m)
+    w = bits // 32
+    b1 = rng.integers(0, 2 ** 32, size=(batch, n, w), dtype=np.uint64).astype(np.uint32)
+    b2 = rng.integers(0, 2 ** 32, size=(batch, m, w), dtype=np.uint64).astype(np.uint32)
+    k = min(n, m) // 3
+    b2[:, m - k:] = b1[:, :k]                              # the matches sit in the right half
+    b1[:, 1] = 0
+    t1, t2 = gpu(b1.view(np.int32)), gpu(b2.view(np.int32))
+    run = lambda: [t.clone() for t in ops.sinkhorn_bits(t1, t2, True, 0.05, 1.0, 10, return_duals=True)]
+    got = run()
+    with N.debug_library() as lib:
+        assert lib.mi_debug_set(16, 0) == 0
+        want = run()
+        assert lib.mi_debug_set(16, 2) != 0
+    assert all(bool(torch.isfinite(t).all()) for t in got[1:])
+    assert float((got[0][:, :n, :m] - want[0][:, :n, :m]).abs().max()) < 3e-5                # P (entries <= 1; an ulp of a dual of magnitude 40 is 4e-6)
+    assert float(((got[0] - want[0]).abs() / want[0].clamp_min(1.0)).max()) < 1e-5            # dustbin row / column: up to ~n
+    for x, y in zip(got[1:], want[1:]):                                       # duals
+        assert float((x - y).abs().max()) < 5e-4
+    unpack = lambda b: np.unpackbits(np.ascontiguousarray(b).view(np.uint8), axis=-1, bitorder="little").astype(np.float64)
+    d1, d2 = unpack(b1[:1]), unpack(b2[:1])
+    d1 /= np.maximum(np.linalg.norm(d1, axis=-1, keepdims=True), 1e-12)
+    d2 /= np.maximum(np.linalg.norm(d2, axis=-1, keepdims=True), 1e-12)
+    ref = O.sinkhorn_match(d1, d2, 10, 0.05, 1.0, dtype=np.float64)
+    assert float(np.abs(got[0][:1, :n, :m].cpu().numpy() - ref[:, :n, :m]).max()) < 1e-4
+
+
 @pytest.mark.parametrize("n,m", [(300, 280), (520, 700)])
 def test_fp32_sinkhorn_stream_schedules_agree(mods, n, m):
     """mi_sinkhorn (fp32 log-scores: float descriptors, the reference's default configuration) for >= 64 pairs runs as
