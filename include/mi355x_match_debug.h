@@ -41,7 +41,9 @@ extern "C" {
  * key 15: mi_sinkhorn_dots under MI_SOLVER_DOTS_BELOW_1024: 1 = the row kernel reads the uint16 dots as fp16 denormals
  * (v_fma_mix_f32; default), 0 = converts them first (the same duals bit for bit).
  * key 16: mi_sinkhorn_dots with 512 < m <= 1024 (bounded-shift row kernel): 1 = two waves per row group, one 512-column
- * chunk each, 32-row bands (default), 0 = two chunks per wave, 16-row bands (the sums associate differently: duals equal to rounding). */
+ * chunk each, 32-row bands (default), 0 = two chunks per wave, 16-row bands (the sums associate differently: duals equal to rounding).
+ * key 17: mi_mnn_from_duals / mi_mnn_from_duals_dots with 512 < m <= 1024: 1 = two waves per row group, one 512-column
+ * chunk each (default), 0 = two chunks per wave (the same matches: winners are exact maxima). */
 MI_API int mi_debug_set(int key, int value);
 /* top-k kernel phase time stamps (100 MHz clock) of workgroup 0 into `buffer` (8 x uint64, device memory); NULL = off */
 MI_API int mi_debug_topk_stamps(void *buffer);

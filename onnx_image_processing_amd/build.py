@@ -26,7 +26,7 @@ INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 
 SOURCES = ["corner.hip", "nms.hip", "topk.hip", "bad.hip", "bad_oriented.hip", "bad_dense.hip", "orient.hip", "cost.hip", "sinkhorn.hip", "sinkhorn_dots.hip", "mnn.hip", "akaze.hip", "akaze_stream.hip", "essential.hip", "detectors.hip", "match_pairs.hip"]
 # sources that read a hook of csrc/hooks.h: compiled a second time for the debug library; every other object is shared
-HOOKED = ["corner.hip", "topk.hip", "sinkhorn.hip", "sinkhorn_dots.hip", "akaze.hip", "bad_oriented.hip", "cost.hip"]
+HOOKED = ["corner.hip", "topk.hip", "sinkhorn.hip", "sinkhorn_dots.hip", "akaze.hip", "bad_oriented.hip", "cost.hip", "mnn.hip"]
 DEBUG_ONLY = ["hooks.hip"]
 # -ffp-contract=off: the corner response must not fuse a*b+c (bit parity with the reference's
 # op-by-op fp32); IEEE sqrt/div are hipcc's defaults and are relied upon.

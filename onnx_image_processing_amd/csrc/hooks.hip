@@ -34,6 +34,7 @@ MI_API int mi_debug_set(int key, int value) {
     mi_hooks.cost_impl = 0;
     mi_hooks.sinkhorn_mix = 1;
     mi_hooks.sinkhorn_pair_waves = 1;
+    mi_hooks.mnn_pair_waves = 1;
     mi_hooks.corner_clk = nullptr; mi_hooks.topk_prof = nullptr;
     return MI_OK;
   }
@@ -50,6 +51,7 @@ MI_API int mi_debug_set(int key, int value) {
   if (key == 14 && (value == 0 || value == 1)) { mi_hooks.cost_impl = value; return MI_OK; }
   if (key == 15 && (value == 0 || value == 1)) { mi_hooks.sinkhorn_mix = value; return MI_OK; }
   if (key == 16 && (value == 0 || value == 1)) { mi_hooks.sinkhorn_pair_waves = value; return MI_OK; }
+  if (key == 17 && (value == 0 || value == 1)) { mi_hooks.mnn_pair_waves = value; return MI_OK; }
   if (key == 11 && value >= -1 && value <= 2) { mi_hooks.sinkhorn_schedule = value; return MI_OK; }
   return MI_E_PARAM;
 }

@@ -5,6 +5,7 @@
 // valid = score > 0; non-matches carry score -1 exactly as the reference's top-k over
 // `where(valid, score, -1)` does, and slots beyond n (n < max_matches) are zero-padded.
 #include "common.h"
+#include "hooks.h"
 
 #include <math.h>
 
@@ -252,18 +253,30 @@ struct ZSourceDots {
 
 // FULL: m == 512 * E8 and n a multiple of the band height (the export configuration): no row or column of the band lies
 // past the matrix, the per-element "inside?" select is dropped
-template <typename SRC, int E8, int RW, int NW, bool FULL = false>
-__global__ __launch_bounds__(64 * NW) void mnn_band_kernel(SRC src, int n, int m, const float *__restrict__ u,
+// SPLIT (round 4; 512 < m <= 1024, NW = 16): the two 512-column chunks of a row go to two waves (wave 2g: columns 0..511,
+// wave 2g + 1: 512..1023 of the same RW rows) running the one-chunk code -- half the registers per lane, twice the
+// waves per SIMD -- and the two half-row winners meet in LDS.  Winners are maxima of (score, index) keys: exact,
+// whatever the grouping, so the matches are those of the two-chunk kernel.  waves_per_eu(8, 8) for this form only: 64
+// VGPRs with 11 dwords of scratch, two 16-wave workgroups per CU (78 KB of LDS each) -- 139.9 us per 128 pairs of
+// 1024 x 1024 against 166.6 at 75 VGPRs (one workgroup per CU) and 158.5 for the two-chunk kernel (137 VGPRs).  The
+// one-chunk kernel itself loses by the same squeeze (77 -> 110 us per 448 pairs): its three 8-wave workgroups per CU
+// already overlap each other's phases.
+template <typename SRC, int E8, int RW, int NW, bool FULL = false, bool SPLIT = false>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(SPLIT ? 8 : 1, 8))) void mnn_band_kernel(SRC src, int n, int m, const float *__restrict__ u,
                                                            const float *__restrict__ v,
                                                            const float2 *__restrict__ col_info,
                                                            uint64_t *__restrict__ row_best,
                                                            uint64_t *__restrict__ col_part) {
-  constexpr int BAND = NW * RW;
-  constexpr int NC = 512 * E8;
-  __shared__ uint64_t red[NW][NC];
+  static_assert(!SPLIT || (E8 == 1 && NW % 2 == 0), "the split form runs the one-chunk code on wave pairs");
+  constexpr int RG = SPLIT ? NW / 2 : NW;        // row groups of the workgroup
+  constexpr int BAND = RG * RW;
+  constexpr int NC = 512 * E8 * (SPLIT ? 2 : 1);   // columns covered by the workgroup
+  __shared__ uint64_t red[RG][NC];
+  __shared__ uint64_t halfkey[SPLIT ? NW : 1][RW];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: rows in SGPRs
   const int b = blockIdx.y, band = blockIdx.x, nb = gridDim.x;
-  const int row0 = band * BAND + wave * RW;
+  const int rg = SPLIT ? wave >> 1 : wave, half = SPLIT ? wave & 1 : 0, cbase = half * 512;
+  const int row0 = band * BAND + rg * RW;
 
   // all rows of the wave are requested before anything else (a load issued where it is used costs the wave one
   // memory round trip per row), ahead of the column data's trip through LDS
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(64 * NW) void mnn_band_kernel(SRC src, int n, int m
     uis[r] = u[(size_t)b * (n + 1) + ic];
     rowd[r] = src.load_row(b, n, ic);
 #pragma unroll
-    for (int e = 0; e < E8; ++e) raw[r][e] = src.load_raw(b, n, ic, e * 512 + lane * 8, m);
+    for (int e = 0; e < E8; ++e) raw[r][e] = src.load_raw(b, n, ic, cbase + e * 512 + lane * 8, m);
   }
   // per-column data: the workgroup fetches v and col_info once with coalesced loads and every lane picks its
   // eight consecutive columns out of LDS (sixteen strided 4- and 8-byte loads per lane otherwise: the address
@@ -307,8 +320,8 @@ __global__ __launch_bounds__(64 * NW) void mnn_band_kernel(SRC src, int n, int m
   for (int e = 0; e < E8; ++e)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      vv[e][q] = s_v[e * 512 + lane * 8 + q];
-      ci[e][q] = s_ci[e * 512 + lane * 8 + q];
+      vv[e][q] = s_v[cbase + e * 512 + lane * 8 + q];
+      ci[e][q] = s_ci[cbase + e * 512 + lane * 8 + q];
     }
 
   float cbest[E8][8];      // per-lane column winners over this wave's rows: rows ascend, strict > keeps the first
@@ -333,7 +346,7 @@ __global__ __launch_bounds__(64 * NW) void mnn_band_kernel(SRC src, int n, int m
       src.finish(x, ci[e]);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int j = e * 512 + lane * 8 + q;
+        const int j = cbase + e * 512 + lane * 8 + q;
         float p = mi_prob_exp((x[q] + ui) + vv[e][q]);                         // sinkhorn.py:145,206
         if constexpr (!FULL) p = (live && j < m) ? p : -1.0f;
         if (p > rbest) { rbest = p; rj = j; }
@@ -342,18 +355,28 @@ __global__ __launch_bounds__(64 * NW) void mnn_band_kernel(SRC src, int n, int m
     }
     uint64_t key = rbest >= 0.0f ? best_key(rbest, (uint32_t)rj) : 0ull;
     key = wave_max_u64(key);
-    if (lane == 0 && live) row_best[(size_t)b * n + i] = key;
+    if constexpr (SPLIT) {
+      if (lane == 0) halfkey[wave][r] = key;
+    } else {
+      if (lane == 0 && live) row_best[(size_t)b * n + i] = key;
+    }
   }
 #pragma unroll
   for (int e = 0; e < E8; ++e)
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-      red[wave][e * 512 + lane * 8 + q] = cbest[e][q] >= 0.0f ? best_key(cbest[e][q], (uint32_t)cidx[e][q]) : 0ull;
+      red[rg][cbase + e * 512 + lane * 8 + q] = cbest[e][q] >= 0.0f ? best_key(cbest[e][q], (uint32_t)cidx[e][q]) : 0ull;
   __syncthreads();
+  if constexpr (SPLIT) {                         // the rows' winners: the better of the two halves
+    if (half == 0 && lane < RW && row0 + lane < n) {
+      const uint64_t a = halfkey[wave][lane], c = halfkey[wave + 1][lane];
+      row_best[(size_t)b * n + row0 + lane] = c > a ? c : a;
+    }
+  }
   for (int c = threadIdx.x; c < NC && c < m; c += 64 * NW) {
     uint64_t k = red[0][c];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) k = red[w][c] > k ? red[w][c] : k;
+    for (int w = 1; w < RG; ++w) k = red[w][c] > k ? red[w][c] : k;
     col_part[((size_t)b * nb + band) * m + c] = k;
   }
 }
@@ -413,12 +436,15 @@ int mnn_from_source(SRC src, const float2 *col_info, int batch, int n, int m, co
   } else if (m <= 512) {
     hipLaunchKernelGGL((mnn_band_kernel<SRC, 1, 4, 8>), dim3(nb, batch), dim3(512), 0, s, src, n, m, u, v, col_info,
                        w.row_best, w.col_part);
-  } else if (m == 1024 && full) {
-    hipLaunchKernelGGL((mnn_band_kernel<SRC, 2, 4, 8, true>), dim3(nb, batch), dim3(512), 0, s, src, n, m, u, v, col_info,
-                       w.row_best, w.col_part);
-  } else {
+  } else if (MI_HOOK(mnn_pair_waves, 1) == 0) {
     hipLaunchKernelGGL((mnn_band_kernel<SRC, 2, 4, 8>), dim3(nb, batch), dim3(512), 0, s, src, n, m, u, v, col_info,
                        w.row_best, w.col_part);
+  } else if (m == 1024 && full) {                  // 512 < m <= 1024: two waves per row group, one chunk each (SPLIT)
+    hipLaunchKernelGGL((mnn_band_kernel<SRC, 1, 4, 16, true, true>), dim3(nb, batch), dim3(1024), 0, s, src, n, m, u, v,
+                       col_info, w.row_best, w.col_part);
+  } else {
+    hipLaunchKernelGGL((mnn_band_kernel<SRC, 1, 4, 16, false, true>), dim3(nb, batch), dim3(1024), 0, s, src, n, m, u, v,
+                       col_info, w.row_best, w.col_part);
   }
   if (batch <= 32) {
     // few pairs: the select kernel merges the bands' column winners itself (one launch less on the latency path)

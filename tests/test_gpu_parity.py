@@ -1099,7 +1099,7 @@ def test_akaze_argument_checks(mods):
 
 
 # ------------------------------------------------------------------ matches straight from the duals
-@pytest.mark.parametrize("n,m", [(512, 512), (40, 56), (300, 77), (33, 1000), (700, 520)])
+@pytest.mark.parametrize("n,m", [(512, 512), (40, 56), (300, 77), (33, 1000), (700, 520), (1024, 1024), (96, 1024)])
 def test_mnn_from_duals_equals_two_step(mods, n, m):
     """mi_mnn_from_duals[_dots] == mi_sinkhorn(P) + mi_mnn_extract, bit for bit (incl. indices)."""
     from onnx_image_processing_amd import ops
