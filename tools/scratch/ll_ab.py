@@ -1,0 +1,27 @@
+"""A/B of the Sinkhorn row kernels' dispatch order (debug key 18) on one box: ms per call, 20 iterations."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from onnx_image_processing_amd import _native as N, ops
+
+def bench(batch, n, m, lib, key, reps=30):
+    rng = np.random.default_rng(1)
+    b1 = torch.from_numpy(rng.integers(0, 2 ** 32, size=(batch, n, 16), dtype=np.uint64).astype(np.uint32).view(np.int32)).cuda()
+    b2 = torch.from_numpy(rng.integers(0, 2 ** 32, size=(batch, m, 16), dtype=np.uint64).astype(np.uint32).view(np.int32)).cuda()
+    out = {}
+    for val in (1, 0, 1, 0):
+        assert lib.mi_debug_set(key, val) == 0
+        for _ in range(12):
+            ops.sinkhorn_bits(b1, b2, True, 0.05, 1.0, 20, return_duals=True, want_p=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ops.sinkhorn_bits(b1, b2, True, 0.05, 1.0, 20, return_duals=True, want_p=False)
+        torch.cuda.synchronize()
+        out.setdefault(val, []).append((time.perf_counter() - t0) / reps * 1e3)
+    return out
+
+with N.debug_library() as lib:
+    key = int(sys.argv[1]) if len(sys.argv) > 1 else 18
+    for shape in ((128, 512, 512), (448, 512, 512), (128, 1024, 1024), (64, 512, 512)):
+        print(shape, {k: [round(x, 4) for x in v] for k, v in bench(*shape, lib, key).items()}, flush=True)
