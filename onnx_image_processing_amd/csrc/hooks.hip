@@ -35,6 +35,8 @@ MI_API int mi_debug_set(int key, int value) {
     mi_hooks.sinkhorn_mix = 1;
     mi_hooks.sinkhorn_pair_waves = 1;
     mi_hooks.mnn_pair_waves = 1;
+    mi_hooks.mnn_one_pass = 1;
+    mi_hooks.sinkhorn_exp_rows = 1;
     mi_hooks.corner_clk = nullptr; mi_hooks.topk_prof = nullptr;
     return MI_OK;
   }
@@ -52,6 +54,8 @@ MI_API int mi_debug_set(int key, int value) {
   if (key == 15 && (value == 0 || value == 1)) { mi_hooks.sinkhorn_mix = value; return MI_OK; }
   if (key == 16 && (value == 0 || value == 1)) { mi_hooks.sinkhorn_pair_waves = value; return MI_OK; }
   if (key == 17 && (value == 0 || value == 1)) { mi_hooks.mnn_pair_waves = value; return MI_OK; }
+  if (key == 19 && (value == 0 || value == 1)) { mi_hooks.mnn_one_pass = value; return MI_OK; }
+  if (key == 18 && (value == 0 || value == 1)) { mi_hooks.sinkhorn_exp_rows = value; return MI_OK; }
   if (key == 11 && value >= -1 && value <= 2) { mi_hooks.sinkhorn_schedule = value; return MI_OK; }
   return MI_E_PARAM;
 }

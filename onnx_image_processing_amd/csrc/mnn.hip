@@ -64,6 +64,58 @@ __global__ __launch_bounds__(256) void mnn_col_kernel(const float *__restrict__ 
   }
 }
 
+// Rows AND columns in one pass over P (round 4; m <= 1024): the two kernels above each walk P in loops of dependent loads
+// (174 + 150 us per 448 pairs of 513 x 513: 2.7-3.2 TB/s, P read twice).  Here a workgroup takes 32 rows (8 waves x 4), a
+// lane the columns lane, lane + 64, ... of its wave's rows with every load issued up front; the rows' winners leave by a
+// wave maximum, the columns' winners are merged over the waves in LDS and then over the workgroups of the pair by a 64-bit
+// atomic maximum on col_best (zeroed ahead of the launch): maxima of (score, inverted index) keys are exact whatever the
+// order, so row_best / col_best are what the two kernels above produce.
+template <int Q>
+__global__ __launch_bounds__(512) void mnn_p_kernel(const float *__restrict__ p, int n, int m, uint64_t *__restrict__ row_best,
+                                                    unsigned long long *__restrict__ col_best) {
+  constexpr int NW = 8, RW = 4;
+  __shared__ uint64_t red[NW][Q * 64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y, row0 = ((int)blockIdx.x * NW + wave) * RW;
+  float x[RW][Q];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const float *pr = p + ((size_t)b * (n + 1) + min(row0 + r, n - 1)) * (size_t)(m + 1);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) x[r][q] = pr[min(q * 64 + lane, m - 1)];
+  }
+  float cbest[Q];
+  int cidx[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) { cbest[q] = -1.0f; cidx[q] = 0; }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int i = row0 + r;
+    const bool live = i < n;
+    float rbest = -1.0f;
+    int rj = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int j = q * 64 + lane;
+      const float v = (live && j < m) ? x[r][q] : -1.0f;
+      if (v > rbest) { rbest = v; rj = j; }               // columns ascend within a lane: strict > keeps the first
+      if (v > cbest[q]) { cbest[q] = v; cidx[q] = i; }    // rows ascend: likewise
+    }
+    uint64_t key = rbest >= 0.0f ? best_key(rbest, (uint32_t)rj) : 0ull;
+    key = wave_max_u64(key);
+    if (lane == 0 && live) row_best[(size_t)b * n + i] = key;
+  }
+#pragma unroll
+  for (int q = 0; q < Q; ++q) red[wave][q * 64 + lane] = cbest[q] >= 0.0f ? best_key(cbest[q], (uint32_t)cidx[q]) : 0ull;
+  __syncthreads();
+  for (int c = threadIdx.x; c < Q * 64 && c < m; c += 64 * NW) {
+    uint64_t k = red[0][c];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) k = red[w][c] > k ? red[w][c] : k;
+    if (k != 0ull) atomicMax(col_best + (size_t)b * m + c, (unsigned long long)k);
+  }
+}
+
 // col_part != NULL (m <= 1024): the per-band column winners of mnn_band_kernel are merged here, in the prologue, instead
 // of by a separate mnn_colmerge_kernel launch (one dependent launch less; what one pair per call is made of)
 __global__ __launch_bounds__(MX_THREADS) void mnn_select_kernel(
@@ -513,8 +565,19 @@ extern "C" int mi_mnn_extract(const float *p, int batch, int n, int m, const flo
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
   if (n > MX_MAX || max_matches <= 0) return MI_E_PARAM;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(mnn_row_kernel, dim3(ceil_div(n, 4), batch), dim3(256), 0, s, p, n, m, row_best);
-  hipLaunchKernelGGL(mnn_col_kernel, dim3(ceil_div(m, 64), batch), dim3(256), 0, s, p, n, m, col_best);
+  if (m <= 1024 && MI_HOOK(mnn_one_pass, 1) != 0) {
+    const int e = mi_zero_async(col_best, (size_t)batch * m * sizeof(uint64_t), s);   // (a kernel, not hipMemsetAsync: common.h)
+    if (e != MI_OK) return e;
+    if (m <= 512)
+      hipLaunchKernelGGL(mnn_p_kernel<8>, dim3(ceil_div(n, 32), batch), dim3(512), 0, s, p, n, m, row_best,
+                         reinterpret_cast<unsigned long long *>(col_best));
+    else
+      hipLaunchKernelGGL(mnn_p_kernel<16>, dim3(ceil_div(n, 32), batch), dim3(512), 0, s, p, n, m, row_best,
+                         reinterpret_cast<unsigned long long *>(col_best));
+  } else {
+    hipLaunchKernelGGL(mnn_row_kernel, dim3(ceil_div(n, 4), batch), dim3(256), 0, s, p, n, m, row_best);
+    hipLaunchKernelGGL(mnn_col_kernel, dim3(ceil_div(m, 64), batch), dim3(256), 0, s, p, n, m, col_best);
+  }
   hipLaunchKernelGGL(mnn_select_kernel, dim3(batch), dim3(MX_THREADS), 0, s, n, m, row_best, col_best,
                      (const uint64_t *)nullptr, 0, kpts1, kpts2, max_matches, threshold, (const uint32_t *)nullptr, mk1,
                      mk2, scores, valid, match_ij);

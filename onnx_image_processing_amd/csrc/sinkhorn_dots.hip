@@ -494,6 +494,66 @@ __global__ __launch_bounds__(256) void sk_exp_dots_kernel(const uint16_t *__rest
   }
 }
 
+// The same P, four rows per wave with every load issued before the first use (round 4).  The kernel above walks a row
+// in a loop of nine dependent round trips (three loads, exp, store, next 64 columns): 308 us per 448 pairs of 512 x 512 =
+// 2.3 TB/s for 235 MB of dots read and 472 MB of P written.  Here a lane owns columns lane, lane + 64, ... (its stores are
+// 256 contiguous bytes per instruction), the per-column data (col_info, v) are loaded once per wave for its RW rows, the
+// RW x 8 E8 dot products of the wave's rows by as many independent 2-byte loads.  The expressions are the kernel's above,
+// operand for operand: the same P bit for bit (and so the same as mnn_band_kernel's registers).
+template <int E8>
+__global__ __launch_bounds__(256) void sk_exp_rows_kernel(const uint16_t *__restrict__ dots, int n, int m, int pitch,
+                                                          const float2 *__restrict__ row_info,
+                                                          const float2 *__restrict__ col_info, ZParams zp,
+                                                          const float *__restrict__ u, const float *__restrict__ v,
+                                                          float *__restrict__ p) {
+  constexpr int RW = 4, Q = 8 * E8;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y, nbands = (int)gridDim.x - 1;
+  const float *vb = v + (size_t)b * (m + 1);
+  if ((int)blockIdx.x == nbands) {                   // the dustbin row
+    const float un = u[(size_t)b * (n + 1) + n];
+    float *pr = p + ((size_t)b * (n + 1) + n) * (size_t)(m + 1);
+    for (int j = threadIdx.x; j <= m; j += 256) pr[j] = mi_prob_exp((zp.dust + un) + vb[j]);
+    return;
+  }
+  const int row0 = ((int)blockIdx.x * 4 + wave) * RW;
+  if (row0 >= n) return;
+  uint16_t raw[RW][Q];
+  float ui[RW];
+  float2 ri[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int ic = min(row0 + r, n - 1);
+    ui[r] = u[(size_t)b * (n + 1) + ic];
+    ri[r] = row_info[(size_t)b * n + ic];
+    const uint16_t *dr = dots + ((size_t)b * n + ic) * pitch;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) raw[r][q] = dr[min(q * 64 + lane, pitch - 1)];
+  }
+  float vv[Q];
+  float2 ci[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int j = min(q * 64 + lane, m - 1);
+    vv[q] = vb[j];
+    ci[q] = col_info[(size_t)b * m + j];
+  }
+  const float vd = vb[m];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    if (row0 + r >= n) break;                        // wave-uniform
+    float *pr = p + ((size_t)b * (n + 1) + row0 + r) * (size_t)(m + 1);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int j = q * 64 + lane;
+      const float zz = z_of((float)raw[r][q], ri[r], ci[q], zp.neg_inv_eps);
+      const float val = mi_prob_exp((zz + ui[r]) + vv[q]);           // sinkhorn.py:145,206
+      if (j < m) pr[j] = val;
+    }
+    if (lane == 0) pr[m] = mi_prob_exp((zp.dust + ui[r]) + vd);      // the dustbin column
+  }
+}
+
 // ---- single-launch form for a few pairs (the one-pair-per-call latency path) ---------------------------------
 // With one pair per call the 41 dependent launches above are all latency: each kernel boundary costs more than
 // the work between two of them (MI355X_MICROARCH.md, "boundary" row).  Here ONE launch runs every iteration: the
@@ -1129,6 +1189,17 @@ int dots_cpitch(int m) { return m <= 512 ? 512 : 1024; }
 // single-launch form: two granule buffers of nb band rows per pair (then the status word, which every shape has)
 bool persist_shape(int batch, int n, int m) { return batch <= SKP_MAX_BATCH && n <= 512 && m <= 512; }
 int persist_grid(int batch, int n) { return 8 * ceil_div(n, 32) * ceil_div(batch, 8); }
+// P from the duals (key 18: 1 = four rows per wave, every load up front; 0 = the one-row-per-wave loop; the same P)
+void launch_exp(const uint16_t *dots, int n, int m, int pitch, const float2 *ri, const float2 *ci, ZParams zp, const float *u,
+                const float *v, float *p, int batch, hipStream_t s) {
+  if (MI_HOOK(sinkhorn_exp_rows, 1) == 0)
+    hipLaunchKernelGGL(sk_exp_dots_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, dots, n, m, pitch, ri, ci, zp, u, v, p);
+  else if (m <= 512)
+    hipLaunchKernelGGL(sk_exp_rows_kernel<1>, dim3(ceil_div(n, 16) + 1, batch), dim3(256), 0, s, dots, n, m, pitch, ri, ci, zp, u, v, p);
+  else
+    hipLaunchKernelGGL(sk_exp_rows_kernel<2>, dim3(ceil_div(n, 16) + 1, batch), dim3(256), 0, s, dots, n, m, pitch, ri, ci, zp, u, v, p);
+}
+
 // Workgroups of the single-launch kernel the current device can hold at once: occupancy per compute unit x compute
 // units, the smaller of the two row-pass variants, asked once per device (0 when the query fails: multi-launch form).
 // A CU-masked or partitioned device reports what it really has, which is the point.
@@ -1283,8 +1354,7 @@ int mi_sinkhorn_dots_impl(const uint16_t *dots, const float *row_info, const flo
 #undef SKP_LAUNCH
     MI_CHECK_LAUNCH();
     if (p)
-      hipLaunchKernelGGL(sk_exp_dots_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, dots, n, m, pitch, ri, ci,
-                         zp, u, v, p);
+      launch_exp(dots, n, m, pitch, ri, ci, zp, u, v, p, batch, s);
     return mi_launch_status();
   }
   // dots vouched to be < 1024 (MI_SOLVER_DOTS_BELOW_1024): the row kernel reads them as fp16 denormals (MIX above)
@@ -1305,8 +1375,7 @@ int mi_sinkhorn_dots_impl(const uint16_t *dots, const float *row_info, const flo
 #undef SKD_LAUNCH_NW
   if (e != MI_OK) return e;
   if (p) {
-    hipLaunchKernelGGL(sk_exp_dots_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, dots, n, m, pitch, ri, ci,
-                       zp, u, v, p);
+    launch_exp(dots, n, m, pitch, ri, ci, zp, u, v, p, batch, s);
   }
   return mi_launch_status();
 }

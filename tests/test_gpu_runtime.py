@@ -140,6 +140,56 @@ def test_sinkhorn_wide_rows_split_over_wave_pairs(mods, batch, n, m, bits):
     assert float(np.abs(got[0][:1, :n, :m].cpu().numpy() - ref[:, :n, :m]).max()) < 1e-4
 
 
+@pytest.mark.parametrize("batch,n,m", [(3, 512, 512), (2, 300, 277), (2, 33, 1000), (2, 1024, 1024), (1, 5, 3), (9, 130, 512)])
+def test_sinkhorn_dots_p_kernel_with_loads_up_front(mods, batch, n, m):
+    """The P output of mi_sinkhorn_dots: four rows per wave with every load issued before the first use (default) against
+    the one-row-per-wave loop (debug key 18 = 0): the same expressions on the same operands, P identical bit for bit --
+    core, dustbin row, dustbin column, ragged extents, one and two 512-column chunks, rows past n in the last wave."""
+    from onnx_image_processing_amd import _native as N, ops
+    rng = np.random.default_rng(batch + n + m)
+    b1 = rng.integers(0, 2 ** 32, size=(batch, n, 8), dtype=np.uint64).astype(np.uint32)
+    b2 = rng.integers(0, 2 ** 32, size=(batch, m, 8), dtype=np.uint64).astype(np.uint32)
+    k = min(n, m) // 3
+    b2[:, :k] = b1[:, :k]
+    t1, t2 = gpu(b1.view(np.int32)), gpu(b2.view(np.int32))
+    run = lambda: ops.sinkhorn_bits(t1, t2, True, 0.05, 1.0, 6).clone()
+    got = run()
+    with N.debug_library() as lib:
+        assert lib.mi_debug_set(18, 0) == 0
+        want = run()
+        assert lib.mi_debug_set(18, 2) != 0
+    assert got.shape == (batch, n + 1, m + 1) and bool(torch.isfinite(got).all())
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("batch,n,m", [(3, 512, 512), (2, 300, 277), (2, 33, 1000), (2, 1024, 1024), (1, 5, 3), (5, 130, 512)])
+def test_mnn_extract_in_one_pass_over_p(mods, batch, n, m):
+    """mi_mnn_extract on a materialised P: row and column winners in ONE pass (a band of 32 rows per workgroup, loads up
+    front, the columns' winners merged across workgroups by a 64-bit atomic maximum) against the row kernel + column
+    kernel pair (debug key 19 = 0).  Winners are exact maxima of (score, index) keys: every output identical -- with
+    exact ties (duplicated rows and columns), all-zero rows, ragged extents and two 512-column chunks."""
+    from onnx_image_processing_amd import _native as N, ops
+    rng = np.random.default_rng(batch * 1000 + n + m)
+    pm = rng.random((batch, n + 1, m + 1), dtype=np.float32) ** 8
+    pm[:, : min(n, m), : min(n, m)] += np.eye(min(n, m), dtype=np.float32)[None] * (rng.random((batch, min(n, m), 1), dtype=np.float32) > 0.5)
+    if n > 4 and m > 4:
+        pm[:, 3] = pm[:, 2]                      # exact ties between rows ...
+        pm[:, :, 4] = pm[:, :, 1]                # ... and between columns
+        pm[:, 1, :] = 0.0                        # an all-zero row
+    pt = gpu(pm)
+    k1 = gpu(rng.integers(0, 400, (batch, n, 2)).astype(np.float32))
+    k2 = gpu(rng.integers(0, 400, (batch, m, 2)).astype(np.float32))
+    run = lambda: [t.clone() for t in ops.mnn_extract(pt, k1, k2, 50, 0.05, return_indices=True)]
+    got = run()
+    with N.debug_library() as lib:
+        assert lib.mi_debug_set(19, 0) == 0
+        want = run()
+        assert lib.mi_debug_set(19, 2) != 0
+    for x, y in zip(got, want):
+        assert torch.equal(x, y)
+    assert int(got[3].sum()) > 0
+
+
 @pytest.mark.parametrize("n,m", [(300, 280), (520, 700)])
 def test_fp32_sinkhorn_stream_schedules_agree(mods, n, m):
     """mi_sinkhorn (fp32 log-scores: float descriptors, the reference's default configuration) for >= 64 pairs runs as
