@@ -44,7 +44,7 @@ extern "C" {
  * chunk each, 32-row bands (default), 0 = two chunks per wave, 16-row bands (the sums associate differently: duals equal to rounding).
  * key 17: mi_mnn_from_duals / mi_mnn_from_duals_dots with 512 < m <= 1024: 1 = two waves per row group, one 512-column
  * chunk each (default), 0 = two chunks per wave (the same matches: winners are exact maxima).
- * key 18: the P output of mi_sinkhorn_dots: 1 = four rows per wave, every load issued up front (default), 0 = one row per
+ * key 18: the P output of mi_sinkhorn_dots / mi_sinkhorn: 1 = four rows per wave, every load issued up front (default), 0 = one row per
  * wave in a loop of dependent round trips (the same P bit for bit).
  * key 19: mi_mnn_extract with m <= 1024: 1 = row and column winners in one pass over P (default), 0 = a row kernel and a
  * column kernel (the same winners: exact maxima). */

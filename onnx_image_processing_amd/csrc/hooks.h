@@ -24,7 +24,7 @@ struct MiHooks {
   std::atomic<int> sinkhorn_mix{1};         // key 15: 1 = under MI_SOLVER_DOTS_BELOW_1024 the row kernel reads the dots as fp16 denormals (v_fma_mix_f32), 0 = converts them
   std::atomic<int> sinkhorn_pair_waves{1};     // key 16: 512 < m <= 1024, bounded-shift row kernel: 1 = two waves per row group with one chunk each, 0 = two chunks per wave
   std::atomic<int> mnn_pair_waves{1};          // key 17: matches from the duals, 512 < m <= 1024: 1 = two waves per row group with one chunk each, 0 = two chunks per wave
-  std::atomic<int> sinkhorn_exp_rows{1};       // key 18: P of mi_sinkhorn_dots: 1 = four rows per wave with every load up front, 0 = one row per wave in a loop
+  std::atomic<int> sinkhorn_exp_rows{1};       // key 18: P of mi_sinkhorn_dots / mi_sinkhorn: 1 = four rows per wave with every load up front, 0 = one row per wave in a loop
   std::atomic<int> mnn_one_pass{1};            // key 19: mi_mnn_extract: 1 = rows and columns in one pass over P (m <= 1024), 0 = a row kernel and a column kernel
   std::atomic<int> topk_split{-1};             // key 10: workgroups per image of the top-k histogram pass (-1 = automatic)
   std::atomic<unsigned long long *> corner_clk{nullptr};   // mi_debug_clock_probe

@@ -235,6 +235,62 @@ __global__ __launch_bounds__(256) void sk_exp_kernel(const float *__restrict__ z
   }
 }
 
+// The same P, four rows per wave with every load issued before the first use (round 4; m <= 1024): the loop above is nine
+// dependent round trips per row.  A lane owns columns lane, lane + 64, ...: loads and stores of 256 contiguous bytes per
+// instruction, v loaded once per wave for its rows.  The same expressions: the same P bit for bit.
+template <int Q>
+__global__ __launch_bounds__(256) void sk_exp_rows_kernel(const float *__restrict__ z, int n, int m, int pitch, float dust,
+                                                          const float *__restrict__ u, const float *__restrict__ v,
+                                                          float *__restrict__ p) {
+  constexpr int RW = 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.y, nbands = (int)gridDim.x - 1;
+  const float *vb = v + (size_t)b * (m + 1);
+  if ((int)blockIdx.x == nbands) {                   // the dustbin row
+    const float un = u[(size_t)b * (n + 1) + n];
+    float *pr = p + ((size_t)b * (n + 1) + n) * (size_t)(m + 1);
+    for (int j = threadIdx.x; j <= m; j += 256) pr[j] = mi_prob_exp((dust + un) + vb[j]);
+    return;
+  }
+  const int row0 = ((int)blockIdx.x * 4 + wave) * RW;
+  if (row0 >= n) return;
+  float zz[RW][Q], ui[RW];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int ic = min(row0 + r, n - 1);
+    ui[r] = u[(size_t)b * (n + 1) + ic];
+    const float *zr = z + ((size_t)b * n + ic) * pitch;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) zz[r][q] = zr[min(q * 64 + lane, m - 1)];
+  }
+  float vv[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) vv[q] = vb[min(q * 64 + lane, m - 1)];
+  const float vd = vb[m];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    if (row0 + r >= n) break;                        // wave-uniform
+    float *pr = p + ((size_t)b * (n + 1) + row0 + r) * (size_t)(m + 1);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int j = q * 64 + lane;
+      const float val = mi_prob_exp((zz[r][q] + ui[r]) + vv[q]);     // sinkhorn.py:145,206
+      if (j < m) pr[j] = val;
+    }
+    if (lane == 0) pr[m] = mi_prob_exp((dust + ui[r]) + vd);         // the dustbin column
+  }
+}
+
+void launch_exp(const float *z, int n, int m, int pitch, float dust, const float *u, const float *v, float *p, int batch,
+                hipStream_t s) {
+  if (m > 1024 || MI_HOOK(sinkhorn_exp_rows, 1) == 0)
+    hipLaunchKernelGGL(sk_exp_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, z, n, m, pitch, dust, u, v, p);
+  else if (m <= 512)
+    hipLaunchKernelGGL(sk_exp_rows_kernel<8>, dim3(ceil_div(n, 16) + 1, batch), dim3(256), 0, s, z, n, m, pitch, dust, u, v, p);
+  else
+    hipLaunchKernelGGL(sk_exp_rows_kernel<16>, dim3(ceil_div(n, 16) + 1, batch), dim3(256), 0, s, z, n, m, pitch, dust, u, v, p);
+}
+
 // ---- fused iteration, probability form: ONE exp per matrix element per iteration ----------------
 // After the row pass the row-normalised entries are already known:
 //     P_ij = exp(Z_ij + u_i + v_j) = e_ij / s_i,  e_ij = exp(Z_ij + v_j - max_i),  s_i = sum_j e_ij
@@ -817,8 +873,7 @@ extern "C" int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, f
     else fr = launch_fused<4, 2, 8>(z, batch, n, m, pitch, dustbin_logscore, iterations, u, v, part, vp, log_m, log_n, s);
     if (fr != MI_OK) return fr;
     if (p) {
-      hipLaunchKernelGGL(sk_exp_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, z, n, m, pitch,
-                         dustbin_logscore, u, v, p);
+      launch_exp(z, n, m, pitch, dustbin_logscore, u, v, p, batch, s);
     }
     return mi_launch_status();
   }
@@ -841,8 +896,7 @@ extern "C" int mi_sinkhorn(const float *z, int batch, int n, int m, int pitch, f
     else hipLaunchKernelGGL(sk_col_kernel<1>, cgrid, dim3(256), 0, s, z, n, m, pitch, dustbin_logscore, u, v, log_n);
   }
   if (p) {
-    hipLaunchKernelGGL(sk_exp_kernel, dim3(ceil_div(n + 1, 4), batch), dim3(256), 0, s, z, n, m, pitch,
-                       dustbin_logscore, u, v, p);
+    launch_exp(z, n, m, pitch, dustbin_logscore, u, v, p, batch, s);
   }
   return mi_launch_status();
 }

@@ -142,7 +142,7 @@ def test_sinkhorn_wide_rows_split_over_wave_pairs(mods, batch, n, m, bits):
 
 @pytest.mark.parametrize("batch,n,m", [(3, 512, 512), (2, 300, 277), (2, 33, 1000), (2, 1024, 1024), (1, 5, 3), (9, 130, 512)])
 def test_sinkhorn_dots_p_kernel_with_loads_up_front(mods, batch, n, m):
-    """The P output of mi_sinkhorn_dots: four rows per wave with every load issued before the first use (default) against
+    """The P output of mi_sinkhorn_dots and of mi_sinkhorn: four rows per wave with every load issued before the first use (default) against
     the one-row-per-wave loop (debug key 18 = 0): the same expressions on the same operands, P identical bit for bit --
     core, dustbin row, dustbin column, ragged extents, one and two 512-column chunks, rows past n in the last wave."""
     from onnx_image_processing_amd import _native as N, ops
@@ -152,14 +152,19 @@ def test_sinkhorn_dots_p_kernel_with_loads_up_front(mods, batch, n, m):
     k = min(n, m) // 3
     b2[:, :k] = b1[:, :k]
     t1, t2 = gpu(b1.view(np.int32)), gpu(b2.view(np.int32))
-    run = lambda: ops.sinkhorn_bits(t1, t2, True, 0.05, 1.0, 6).clone()
+    def run():
+        out = [ops.sinkhorn_bits(t1, t2, True, 0.05, 1.0, 6).clone()]
+        z, pitch = ops.cost_logscores_bits(t1, t2, True, 0.05)          # the fp32-Z form's P kernel (mi_sinkhorn)
+        out.append(ops.sinkhorn(z, m, pitch, -1.0 / 0.05, 6).clone())
+        return out
     got = run()
     with N.debug_library() as lib:
         assert lib.mi_debug_set(18, 0) == 0
         want = run()
         assert lib.mi_debug_set(18, 2) != 0
-    assert got.shape == (batch, n + 1, m + 1) and bool(torch.isfinite(got).all())
-    assert torch.equal(got, want)
+    for x, y in zip(got, want):
+        assert x.shape == (batch, n + 1, m + 1) and bool(torch.isfinite(x).all())
+        assert torch.equal(x, y)
 
 
 @pytest.mark.parametrize("batch,n,m", [(3, 512, 512), (2, 300, 277), (2, 33, 1000), (2, 1024, 1024), (1, 5, 3), (5, 130, 512)])
