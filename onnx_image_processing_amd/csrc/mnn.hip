@@ -602,9 +602,17 @@ __global__ __launch_bounds__(256) void match_filters_kernel(float *__restrict__ 
   if (i >= n) return;
   float *pr = p + (size_t)b * plane_stride + (size_t)i * row_stride;
   float a1 = -INFINITY, a2 = -INFINITY;             // lane-local two largest
-  for (int j = lane; j < m; j += 64) {
-    const float x = pr[j];
-    if (x > a1) { a2 = a1; a1 = x; } else if (x > a2) { a2 = x; }
+  for (int j0 = 0; j0 < m; j0 += 512) {             // eight loads in flight, then the same updates in the same order
+    float x[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = j0 + q * 64 + lane;
+      x[q] = j < m ? pr[j] : -INFINITY;             // (-inf changes neither maximum: x > a1 / x > a2 are false)
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (x[q] > a1) { a2 = a1; a1 = x[q]; } else if (x[q] > a2) { a2 = x[q]; }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
