@@ -354,7 +354,9 @@ MI_API int mi_match_filter_masks(const float *p, int batch, int n, int m, int ha
  * p (batch, n+1, m+1); kpts1 (batch,n,2); kpts2 (batch,m,2).  Workspace: row_best (batch*n) u64,
  * col_best (batch*m) u64.  Outputs mk1/mk2 (batch,max_matches,2), scores (batch,max_matches),
  * valid (batch,max_matches) u8, match_ij (batch,max_matches,2) i32 (may be NULL).
- * n <= 4096.  Ties: first index (argmax), then (score desc, row asc) for the top-max_matches. */
+ * n <= 4096.  Ties: first index (argmax), then (score desc, row asc) for the top-max_matches.
+ * m <= 1024: one pass over p (row and column winners together; col_best, 8-byte aligned, is cleared by the call and
+ * filled by 64-bit atomic maxima -- exact, so the order of arrival cannot be seen); larger m: a row and a column pass. */
 MI_API int mi_mnn_extract(const float *p, int batch, int n, int m, const float *kpts1, const float *kpts2,
                    int max_matches, float threshold, uint64_t *row_best, uint64_t *col_best,
                    float *mk1, float *mk2, float *scores, uint8_t *valid, int32_t *match_ij,
