@@ -564,6 +564,7 @@ extern "C" int mi_mnn_extract(const float *p, int batch, int n, int m, const flo
   if (!p || !kpts1 || !kpts2 || !row_best || !col_best || !mk1 || !mk2 || !scores || !valid) return MI_E_NULL;
   if (batch <= 0 || n <= 0 || m <= 0 || batch > 65535) return MI_E_SHAPE;
   if (n > MX_MAX || max_matches <= 0) return MI_E_PARAM;
+  if (((uintptr_t)row_best % 8) != 0 || ((uintptr_t)col_best % 8) != 0) return MI_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   if (m <= 1024 && MI_HOOK(mnn_one_pass, 1) != 0) {
     const int e = mi_zero_async(col_best, (size_t)batch * m * sizeof(uint64_t), s);   // (a kernel, not hipMemsetAsync: common.h)
