@@ -19,8 +19,8 @@
 
 namespace {
 
-__constant__ int FAST_DY[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};     // fast.py:47-52
-__constant__ int FAST_DX[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
+constexpr int FAST_DY[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};     // fast.py:47-52
+constexpr int FAST_DX[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
 
 __device__ __forceinline__ bool run9(uint32_t bits16) {
   uint32_t x = bits16 | ((bits16 & 0xFFu) << 16);      // 24-bit circular buffer (:160-165)
