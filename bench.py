@@ -20,6 +20,7 @@ K=512; pairs are independent, so ranks hold different pairs (weak scaling).  Pri
 Beside `value` the line carries (N = 1 only, all measured after the timed region, none of them part of `value`):
   roofline      K1 corner response (the stencil north_star sets the 60 % target on), float32 input, 8 B/px
   u8_ingest     the same workload on uint8 frames resident in HBM (5 B/px K1), with its own roofline object
+  p_materialised  the same workload with P written by forward() and read by the extractor (the reference's two modules)
   streamed      uint8 frames in pinned host memory, H2D on a copy stream double-buffered against compute
   latency       one pair per call and eight pairs per call (the reference harness's pattern,
                 sample/image_matching.py:313-328): eager and hipGraph replay, submit -> results on the device
@@ -432,6 +433,31 @@ def measure_latency(model, img1, img2, a8, b8, iters: int = 200) -> dict:
     out["what"] = ("MatchExtractionWrapper(ShiTomasiSparseBADSinkhornMatcher), frames resident in HBM, host synchronised "
                    f"after every call, mean of {iters} calls; forms: see bench.py measure_latency")
     return out
+
+
+def measure_two_step(model, img1: torch.Tensor, img2: torch.Tensor, steps: int) -> dict:
+    """The default workload with the (K+1) x (K+1) matrix P WRITTEN by the matcher's forward() and read back by the
+    extractor -- feature_detection/match_extraction_wrapper.py:82-113 taken literally (mi_sinkhorn_dots with a P output, then
+    mi_mnn_extract on it) instead of the matches straight from the Sinkhorn solution.  Same records (asserted in the GPU
+    suite); 1.8 KB more HBM traffic per matrix row."""
+    from onnx_image_processing_amd import distributed as D
+    B = img1.shape[0]
+    fused = model.fuse_extraction
+    model.fuse_extraction = False
+    try:
+        for _ in range(3):
+            rec = D.pack_records(*model(img1, img2))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rec = D.pack_records(*model(img1, img2))
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+    finally:
+        model.fuse_extraction = fused
+    return {"value": B / (ms * 1e-3), "unit": "image-pairs/sec", "ms_per_step": ms, "steps": steps,
+            "mean_valid_matches_per_pair": float(rec[..., 5].sum().item()) / B,
+            "what": "float32 frames resident in HBM; the matcher's forward() writes P (B, K+1, K+1), MutualNearestNeighborMatcher reads it"}
 
 
 def measure_u8_and_streamed(model, a8: np.ndarray, b8: np.ndarray, steps: int) -> tuple[dict, dict]:
@@ -1091,6 +1117,8 @@ def main() -> None:
                 line["u8_ingest"], line["streamed"] = measure_u8_and_streamed(model, a8, b8, min(args.steps, 100))
                 stage("one-pair-per-call latency")
                 line["latency"] = measure_latency(model, img1, img2, a8, b8)
+                stage("P materialised (the reference's two modules used literally)")
+                line["p_materialised"] = measure_two_step(model, img1, img2, min(args.steps, 50))
             if args.cpu_pairs > 0:
                 stage("cpu_baseline")
                 line["cpu_baseline"] = cpu_baseline(min(args.cpu_pairs, B), records, parallel=not args.no_host_parallel)
